@@ -1,0 +1,207 @@
+"""
+Sparse handles: scipy matrix <-> opaque backend handle.
+
+Functional equivalents of the reference's handle helpers
+(reference sparse_dot_mkl/_mkl_interface/_common.py:245-384 create, 387-642 export,
+671-722 destroy / order / convert), written around a small RAII class so a handle can never leak
+on an error path (the reference leaks the pre-conversion CSC handle in _gram_matrix.py:61-64).
+
+Differences from the reference that are deliberate:
+  * int32 AND int64 index arrays are accepted as they are -- the caller's matrix is never
+    modified to match an "interface integer" (reference _common.py:175-178 casts in place);
+  * results whose nnz exceeds INT32_MAX are exported through the *_64 entry points
+    automatically instead of failing with an ILP64 hint.
+"""
+import ctypes as _ct
+
+import numpy as _np
+from scipy import sparse as _sps
+
+from ._checks import (_check_return_value, _is_double, _output_dtypes, _type_letters, is_bsr, is_csc, is_csr,
+                      _NAMED_TYPES)
+from ._constants import LAYOUT_CODE_C, SPARSE_INDEX_BASE_ZERO, SPARSE_OPERATION_NON_TRANSPOSE
+from ._library import MI, sparse_matrix_t
+
+_INT32_MAX = _np.iinfo(_np.int32).max
+
+
+def _index_arrays(matrix):
+    """indptr / indices as contiguous arrays of ONE integer dtype (int32 or int64)."""
+    indptr, indices = matrix.indptr, matrix.indices
+    want = _np.int64 if (indptr.dtype.itemsize > 4 or indices.dtype.itemsize > 4) else _np.int32
+    if indptr.dtype.kind not in "iu" or indices.dtype.kind not in "iu":
+        raise ValueError("sparse index arrays must be integer typed")
+    indptr = _np.ascontiguousarray(indptr, dtype=want)
+    indices = _np.ascontiguousarray(indices, dtype=want)
+    return indptr, indices, ("_64" if want is _np.int64 else "")
+
+
+class SparseHandle:
+    """Owns one backend handle (and keeps the numpy buffers it aliases alive)."""
+
+    def __init__(self, ptr, letter, keepalive=()):
+        self.ptr = ptr
+        self.letter = letter
+        self._keep = keepalive
+
+    # -- construction ---------------------------------------------------------------------------
+    @classmethod
+    def from_scipy(cls, matrix):
+        dbl, cplx = _is_double(matrix)
+        letter = _type_letters[(dbl, cplx)]
+        ref = sparse_matrix_t()
+        if is_csr(matrix) or is_csc(matrix):
+            fmt = "csr" if is_csr(matrix) else "csc"
+            major = matrix.shape[0] if fmt == "csr" else matrix.shape[1]
+            indptr, indices, sfx = _index_arrays(matrix)
+            data = _np.ascontiguousarray(matrix.data)
+            if data.shape[0] != indices.shape[0] or indptr.shape[0] != major + 1:
+                raise ValueError("malformed %s matrix: index / data array lengths disagree with its shape" % fmt)
+            name = "mi_sparse_%s_create_%s%s" % (letter, fmt, sfx)
+            step = indptr.itemsize
+            ret = MI.call(name, _ct.byref(ref), SPARSE_INDEX_BASE_ZERO, matrix.shape[0], matrix.shape[1],
+                          indptr.ctypes.data, indptr.ctypes.data + step, indices.ctypes.data, data.ctypes.data)
+            keep = (indptr, indices, data)
+        elif is_bsr(matrix):
+            r, c = matrix.blocksize
+            if r != c:
+                raise ValueError("BSR handles require square blocks; %s blocks provided" % (matrix.blocksize,))
+            if matrix.shape[0] % r or matrix.shape[1] % r:
+                raise ValueError("BSR blocks %s do not align with dims %s" % (matrix.blocksize, matrix.shape))
+            indptr, indices, sfx = _index_arrays(matrix)
+            data = _np.ascontiguousarray(matrix.data)  # (nblocks, r, r), each block row-major
+            name = "mi_sparse_%s_create_bsr%s" % (letter, sfx)
+            step = indptr.itemsize
+            ret = MI.call(name, _ct.byref(ref), SPARSE_INDEX_BASE_ZERO, LAYOUT_CODE_C, matrix.shape[0] // r,
+                          matrix.shape[1] // r, r, indptr.ctypes.data, indptr.ctypes.data + step,
+                          indices.ctypes.data, data.ctypes.data)
+            keep = (indptr, indices, data)
+        else:
+            raise ValueError("Matrix is not CSC, CSR, or BSR")
+        _check_return_value(ret, name)
+        return cls(ref, letter, keep)
+
+    # -- life cycle ---------------------------------------------------------------------------------
+    def destroy(self):
+        if self.ptr is not None:
+            ptr, self.ptr = self.ptr, None
+            self._keep = ()
+            _check_return_value(MI.call("mi_sparse_destroy", ptr), "mi_sparse_destroy")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            self.destroy()
+        except ValueError:
+            if exc_type is None:
+                raise
+        return False
+
+    def __del__(self):
+        try:
+            if self.ptr is not None:
+                MI.call("mi_sparse_destroy", self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+    # -- operations on the handle ---------------------------------------------------------------------
+    def order(self):
+        _check_return_value(MI.call("mi_sparse_order", self.ptr), "mi_sparse_order")
+
+    def convert_csr(self):
+        out = sparse_matrix_t()
+        ret = MI.call("mi_sparse_convert_csr", self.ptr, SPARSE_OPERATION_NON_TRANSPOSE, _ct.byref(out))
+        new = SparseHandle(out, self.letter)
+        try:
+            _check_return_value(ret, "mi_sparse_convert_csr")
+        except ValueError:
+            new.ptr = None if not out else out
+            try:
+                new.destroy()
+            except ValueError:
+                pass
+            raise
+        return new
+
+    def info(self):
+        rows, cols, nnz = _ct.c_int64(), _ct.c_int64(), _ct.c_int64()
+        letter = _ct.create_string_buffer(2)
+        ib = _ct.c_int()
+        ret = MI.call("mi_sparse_get_info", self.ptr, _ct.byref(rows), _ct.byref(cols), _ct.byref(nnz), letter,
+                      _ct.byref(ib))
+        _check_return_value(ret, "mi_sparse_get_info")
+        return rows.value, cols.value, nnz.value, letter.raw[:1].decode(), ib.value
+
+    def export(self, output_type="csr_matrix"):
+        """Copy the handle's matrix out into a scipy object of class `output_type`
+        ('csr_matrix', 'csc_array', ...).  BSR outputs are re-blocked by scipy from the CSR copy
+        (pass blocksize via export_bsr)."""
+        output_type = output_type.lower()
+        fmt = output_type[:3]
+        if fmt not in ("csr", "csc"):
+            raise ValueError("Only CSR, CSC, and BSR output types are supported")
+        ctor = _NAMED_TYPES[output_type]
+        rows, cols, nnz, letter, index_bytes = self.info()
+        dtype = _output_dtypes[{"s": (False, False), "d": (True, False), "c": (False, True), "z": (True, True)}[letter]]
+        if rows == 0 or cols == 0 or nnz == 0:
+            return ctor((rows, cols), dtype=dtype)
+        wide = index_bytes == 8 or nnz > _INT32_MAX or max(rows, cols) > _INT32_MAX
+        itype = _np.int64 if wide else _np.int32
+        ctype = _ct.c_int64 if wide else _ct.c_int32
+        name = "mi_sparse_%s_export_%s%s" % (letter, fmt, "_64" if wide else "")
+        base = _ct.c_int()
+        r, c = ctype(), ctype()
+        p_start, p_end, p_idx, p_val = _ct.c_void_p(), _ct.c_void_p(), _ct.c_void_p(), _ct.c_void_p()
+        ret = MI.call(name, self.ptr, _ct.byref(base), _ct.byref(r), _ct.byref(c), _ct.byref(p_start),
+                      _ct.byref(p_end), _ct.byref(p_idx), _ct.byref(p_val))
+        _check_return_value(ret, name)
+        if base.value != 0:
+            raise ValueError("1-indexing (F-style) is not supported")
+        major = rows if fmt == "csr" else cols
+
+        def view(ptr, count, np_dtype):
+            buf = (_ct.c_char * (count * _np.dtype(np_dtype).itemsize)).from_address(ptr.value)
+            return _np.frombuffer(buf, dtype=np_dtype, count=count).copy()  # library memory dies with the handle
+
+        indptr = view(p_start, major + 1, itype)  # rows_end == rows_start + 1: one contiguous indptr
+        total = int(indptr[-1] - indptr[0])
+        if total < 0 or total > rows * cols:
+            raise ValueError("Matrix (%d x %d) is attempting to index %d elements" % (rows, cols, total))
+        indices = view(p_idx, total, itype)
+        data = view(p_val, total, dtype)
+        return ctor((data, indices, indptr), shape=(rows, cols))
+
+
+# ---- reference-style functional surface (same call shapes as the reference's helpers) ----------------
+def _create_mi_sparse(matrix):
+    """scipy CSR / CSC / BSR -> (handle, double_precision, complex_type)."""
+    dbl, cplx = _is_double(matrix)
+    return SparseHandle.from_scipy(matrix), dbl, cplx
+
+
+def _export_mi(handle, double_precision=None, complex_type=False, output_type="csr_matrix"):
+    """handle -> scipy matrix of class `output_type` (precision arguments are accepted for call
+    compatibility; the handle knows its own value type)."""
+    if handle is None or handle.ptr is None or not handle.ptr:
+        raise ValueError("mi_sparse_export returned 1 (SPARSE_STATUS_NOT_INITIALIZED)")
+    return handle.export(output_type)
+
+
+def _destroy_mi_handle(handle):
+    if handle is None or handle.ptr is None:
+        raise ValueError("mi_sparse_destroy returned 1 (SPARSE_STATUS_NOT_INITIALIZED)")
+    handle.destroy()
+
+
+def _order_mi_handle(handle):
+    handle.order()
+
+
+def _convert_to_csr(handle, destroy_original=False):
+    new = handle.convert_csr()
+    if destroy_original:
+        handle.destroy()
+    return new

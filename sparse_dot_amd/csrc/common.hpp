@@ -1,0 +1,319 @@
+// common.hpp -- internals shared by every translation unit of libmi_sparse.so.
+//
+// Host side: status / error plumbing, per-thread context (device, stream, scratch arena),
+// device-buffer RAII, pointer-location detection, the sparse handle.
+// Device side: value-type traits (real + complex arithmetic), 16-byte vector wrapper, wave
+// helpers.  gfx950 only: wavefront = 64 lanes everywhere.
+#pragma once
+
+#ifdef MI_HIP_EMU
+#include "hip_emu.hpp"  // tools/hip_emu: developer-only host emulation of the kernels' source
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/mi_sparse.h"
+
+namespace mi {
+// Launch helper: converts the arguments to the kernel's parameter types (so call sites need no
+// casts) and hides the <<< >>> syntax from the host-emulation build.
+template <typename... KArgs, typename... Args>
+inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t stream, Args&&... args)
+{
+#ifdef MI_HIP_EMU
+    (void)stream;
+    hip_emu::launch(kernel, grid, block, smem, static_cast<KArgs>(args)...);
+#else
+    kernel<<<grid, block, smem, stream>>>(static_cast<KArgs>(args)...);
+#endif
+}
+}  // namespace mi
+#define MI_LAUNCH(kernel, grid, block, stream, ...) ::mi::launch_k(kernel, grid, block, 0, stream, __VA_ARGS__)
+#define MI_LAUNCH_SMEM(kernel, grid, block, smem, stream, ...) \
+    ::mi::launch_k(kernel, grid, block, smem, stream, __VA_ARGS__)
+#ifdef MI_HIP_EMU
+#define MI_DYN_SMEM(name) char* name = hip_emu::dyn_smem()
+#else
+#define MI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+namespace mi {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------------------
+// complex value type (layout-compatible with mi_complex8 / mi_complex16 and numpy complex)
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+struct cx {
+    R re, im;
+};
+using cfloat = cx<float>;
+using cdouble = cx<double>;
+
+template <typename T>
+struct vt {  // real types
+    using real = T;
+    static constexpr bool is_complex = false;
+    static __host__ __device__ __forceinline__ T zero() { return T(0); }
+    static __host__ __device__ __forceinline__ T one() { return T(1); }
+    static __host__ __device__ __forceinline__ T mul(T a, T b) { return a * b; }
+    static __host__ __device__ __forceinline__ T add(T a, T b) { return a + b; }
+    static __host__ __device__ __forceinline__ T fma(T a, T b, T c) { return a * b + c; }
+    static __host__ __device__ __forceinline__ T conj(T a) { return a; }
+    static __host__ __device__ __forceinline__ bool is_zero(T a) { return a == T(0); }
+};
+template <typename R>
+struct vt<cx<R>> {
+    using real = R;
+    using T = cx<R>;
+    static constexpr bool is_complex = true;
+    static __host__ __device__ __forceinline__ T zero() { return T{R(0), R(0)}; }
+    static __host__ __device__ __forceinline__ T one() { return T{R(1), R(0)}; }
+    static __host__ __device__ __forceinline__ T mul(T a, T b)
+    {
+        return T{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+    }
+    static __host__ __device__ __forceinline__ T add(T a, T b) { return T{a.re + b.re, a.im + b.im}; }
+    static __host__ __device__ __forceinline__ T fma(T a, T b, T c)
+    {
+        return T{c.re + a.re * b.re - a.im * b.im, c.im + a.re * b.im + a.im * b.re};
+    }
+    static __host__ __device__ __forceinline__ T conj(T a) { return T{a.re, -a.im}; }
+    static __host__ __device__ __forceinline__ bool is_zero(T a) { return a.re == R(0) && a.im == R(0); }
+};
+
+template <typename T>
+struct type_char;
+template <>
+struct type_char<float> {
+    static constexpr char value = 's';
+};
+template <>
+struct type_char<double> {
+    static constexpr char value = 'd';
+};
+template <>
+struct type_char<cfloat> {
+    static constexpr char value = 'c';
+};
+template <>
+struct type_char<cdouble> {
+    static constexpr char value = 'z';
+};
+
+inline size_t value_bytes(char t) { return t == 's' ? 4 : (t == 'd' || t == 'c') ? 8 : 16; }
+
+// V consecutive values moved with one memory instruction (16 B when V * sizeof(T) == 16)
+template <typename T, int V>
+struct alignas(V * sizeof(T) >= 16 ? 16 : V * sizeof(T)) vec {
+    T v[V];
+};
+
+// atomic accumulate (LDS or global).  Real types map to the hardware float / double atomic add
+// (-munsafe-fp-atomics); complex does the two components independently.
+template <typename T>
+__device__ __forceinline__ void atomic_accum(T* p, T x)
+{
+    atomicAdd(p, x);
+}
+template <typename R>
+__device__ __forceinline__ void atomic_accum(cx<R>* p, cx<R> x)
+{
+    atomicAdd(&p->re, x.re);
+    atomicAdd(&p->im, x.im);
+}
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+void clear_error();
+
+struct status_error {  // thrown inside the library, converted to a status code at the C boundary
+    int status;
+};
+
+[[noreturn]] void fail(int status, const char* fmt, ...);
+
+#define MI_HIP_CHECK(expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            (void)hipGetLastError();                                                                    \
+            ::mi::fail(_e == hipErrorOutOfMemory ? MI_SPARSE_STATUS_ALLOC_FAILED                        \
+                                                 : MI_SPARSE_STATUS_EXECUTION_FAILED,                   \
+                       "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);      \
+        }                                                                                               \
+    } while (0)
+
+// run `body` and map exceptions to MKL-style status codes; never lets anything escape the C ABI
+template <typename F>
+inline int guarded(F&& body) noexcept
+{
+    try {
+        clear_error();
+        body();
+        return MI_SPARSE_STATUS_SUCCESS;
+    } catch (const status_error& e) {
+        return e.status;
+    } catch (const std::bad_alloc&) {
+        set_error("host allocation failed");
+        return MI_SPARSE_STATUS_ALLOC_FAILED;
+    } catch (...) {
+        set_error("unexpected internal exception");
+        return MI_SPARSE_STATUS_INTERNAL_ERROR;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-thread context
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {  // owning device allocation
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept
+    {
+        if (this != &o) {
+            release();
+            p = o.p;
+            bytes = o.bytes;
+            o.p = nullptr;
+            o.bytes = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t n);  // throws ALLOC_FAILED; n == 0 still yields a valid (tiny) allocation
+    void release();
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+struct Context {
+    bool initialised = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // grow-only scratch arena; kernels on one stream execute in order, so a later call may reuse
+    // the arena as soon as it is enqueued behind the earlier one
+    DevBuf scratch;
+    size_t scratch_used = 0;
+    std::vector<DevBuf> retired;  // old arenas kept alive until the next synchronise
+    void ensure();                // lazy HIP init for this host thread
+    void* scratch_alloc(size_t bytes);  // 256-B aligned slice, valid until scratch_reset()
+    void scratch_reset() { scratch_used = 0; }
+    void sync();
+};
+Context& ctx();
+
+// where does a caller pointer live?
+enum class Loc { Host, Device };
+Loc locate(const void* p);
+
+// dense / index array as seen by kernels: either the caller's device pointer or a staged copy
+struct Staged {
+    void* dev = nullptr;   // pointer kernels use
+    void* host = nullptr;  // caller's host pointer (nullptr when the caller passed device memory)
+    size_t bytes = 0;
+    DevBuf own;
+    // in: copy host -> device now.  out: call copy_back() after the kernels.
+    void stage_in(const void* p, size_t n, bool copy_contents);
+    void copy_back();
+};
+
+// ------------------------------------------------------------------------------------------------
+// the handle
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t HANDLE_MAGIC = 0x4d495350u;  // 'MISP'
+
+// canonical device CSR: 64-bit row pointer, 32-bit column index, values of the handle's type
+struct Csr {
+    int64_t rows = 0, cols = 0, nnz = 0;
+    int64_t* ptr = nullptr;  // rows + 1
+    int32_t* col = nullptr;  // nnz
+    void* val = nullptr;     // nnz
+    DevBuf ptr_own, col_own, val_own;  // storage when the library owns it (else aliases caller HBM)
+    bool valid = false;
+    bool sorted = false;  // column indices known to be ascending inside every row
+};
+
+struct HostExport {  // library-owned host copies handed out by export_* (valid until destroy)
+    std::vector<char> ptr, col, val;
+};
+
+struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.hip)
+    int chunk = 0;
+    int64_t nchunks = 0;
+    DevBuf chunk_row;  // int32[nchunks + 1]
+};
+
+}  // namespace mi
+
+struct mi_sparse_matrix {
+    uint32_t magic = mi::HANDLE_MAGIC;
+    char vtype = 's';       // 's' 'd' 'c' 'z'
+    int index_bytes = 4;    // flavour the handle was created with (4 / 8)
+    int64_t rows = 0, cols = 0;
+    char origin = 'r';      // 'r' created as CSR, 'c' as CSC, 'b' as BSR, 'l' library result
+    mi::Csr csr;            // CSR of A
+    mi::Csr csrT;           // CSR of A^T  (== the CSC arrays of A)
+    // caller's HOST arrays, kept for mi_sparse_order's write-back (nullptr when device / result)
+    void* user_col = nullptr;
+    void* user_val = nullptr;
+    int user_base = 0;
+    mi::SpmmPlan plan, planT;
+    mi::HostExport exp_csr, exp_csc;
+    std::mutex mtx;  // guards lazy derivation of csr / csrT / plans
+};
+
+namespace mi {
+
+mi_sparse_matrix* check_handle(mi_sparse_matrix_t h);  // throws NOT_INITIALIZED
+Csr& need_csr(mi_sparse_matrix* h);                    // derive (transpose) if only csrT is there
+Csr& need_csrT(mi_sparse_matrix* h);
+void transpose_csr(char vtype, const Csr& in, Csr& out, bool conj);  // out := in^T (stable, sorted rows)
+void sort_csr(char vtype, Csr& a);                     // in-place order of every row
+mi_sparse_matrix* new_result_handle(char vtype, int index_bytes, int64_t rows, int64_t cols);
+
+// device-side exclusive scan of int64 counts (n entries) into out[n + 1]; returns the total
+int64_t exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t n);
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// dispatch a callable templated on the value type:  by_type(vtype, [&](auto tag){ using T = decltype(tag); ... })
+template <typename F>
+inline void by_type(char vtype, F&& f)
+{
+    switch (vtype) {
+        case 's': f(float{}); break;
+        case 'd': f(double{}); break;
+        case 'c': f(cfloat{}); break;
+        case 'z': f(cdouble{}); break;
+        default: fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "bad value type %d", (int)vtype);
+    }
+}
+
+// options (mi_sparse_set_option)
+struct Options {
+    int64_t spmm_chunk = 256;      // work items (nnz + row ends) per wave in the SpMM kernel
+    int64_t spmm_force_generic = 0;
+    int64_t spgemm_force_global = 0;
+};
+Options& options();
+
+}  // namespace mi

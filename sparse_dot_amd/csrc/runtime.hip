@@ -1,0 +1,352 @@
+// runtime.hip -- errors, per-thread context, device memory, service entry points, scan.
+#include <cstdarg>
+
+#include "common.hpp"
+
+namespace mi {
+
+// ---- errors ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = {0};
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+void clear_error() { g_err[0] = 0; }
+
+void fail(int status, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    throw status_error{status};
+}
+
+// ---- device memory -----------------------------------------------------------------------------
+void DevBuf::alloc(size_t n)
+{
+    release();
+    ctx().ensure();
+    const size_t want = n ? n : 16;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+        fail(MI_SPARSE_STATUS_ALLOC_FAILED, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    }
+    bytes = want;
+}
+
+void DevBuf::release()
+{
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+}
+
+// ---- context -----------------------------------------------------------------------------------
+static thread_local Context* g_ctx = nullptr;
+
+Context& ctx()
+{
+    if (!g_ctx) g_ctx = new Context();  // intentionally leaked at thread exit (HIP may be gone)
+    return *g_ctx;
+}
+
+void Context::ensure()
+{
+    if (initialised) return;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        fail(MI_SPARSE_STATUS_EXECUTION_FAILED,
+             "no HIP device available (%s); libmi_sparse has no CPU path",
+             e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    if (device >= n) fail(MI_SPARSE_STATUS_INVALID_VALUE, "device %d out of range (%d devices)", device, n);
+    MI_HIP_CHECK(hipSetDevice(device));
+    initialised = true;
+}
+
+void* Context::scratch_alloc(size_t bytes)
+{
+    ensure();
+    const size_t off = (scratch_used + 255) & ~size_t(255);
+    const size_t need = off + (bytes ? bytes : 1);
+    if (need > scratch.bytes) {
+        // grow: the old arena may still be read by kernels already enqueued -> retire, free at sync
+        size_t cap = scratch.bytes ? scratch.bytes : (size_t(1) << 20);
+        while (cap < need) cap *= 2;
+        if (scratch_used == 0) {
+            // nothing of this call lives in the old arena; earlier calls' kernels might still use it
+            retired.push_back(std::move(scratch));
+            scratch.alloc(cap);
+            scratch_used = (bytes ? bytes : 1);
+            return scratch.p;
+        }
+        // mid-call growth: keep the old arena alive for this call's earlier slices
+        retired.push_back(std::move(scratch));
+        scratch.alloc(cap);
+        scratch_used = (bytes ? bytes : 1);
+        return scratch.p;
+    }
+    scratch_used = need;
+    return static_cast<char*>(scratch.p) + off;
+}
+
+void Context::sync()
+{
+    ensure();
+    MI_HIP_CHECK(hipStreamSynchronize(stream));
+    retired.clear();
+}
+
+// ---- pointer location --------------------------------------------------------------------------
+Loc locate(const void* p)
+{
+    if (!p) return Loc::Host;
+    ctx().ensure();
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'd host memory is "invalid value" to HIP
+        return Loc::Host;
+    }
+    switch (attr.type) {
+        case hipMemoryTypeDevice:
+        case hipMemoryTypeManaged:
+#ifndef MI_HIP_EMU
+        case hipMemoryTypeArray:
+#endif
+            return Loc::Device;
+        default:
+            return Loc::Host;
+    }
+}
+
+void Staged::stage_in(const void* p, size_t n, bool copy_contents)
+{
+    bytes = n;
+    if (locate(p) == Loc::Device) {
+        dev = const_cast<void*>(p);
+        host = nullptr;
+        return;
+    }
+    host = const_cast<void*>(p);
+    own.alloc(n);
+    dev = own.p;
+    if (copy_contents && n) MI_HIP_CHECK(hipMemcpyAsync(dev, p, n, hipMemcpyHostToDevice, ctx().stream));
+}
+
+void Staged::copy_back()
+{
+    if (!host) return;
+    if (bytes) MI_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx().stream));
+    ctx().sync();
+}
+
+Options& options()
+{
+    static Options o;
+    return o;
+}
+
+// ---- exclusive scan ----------------------------------------------------------------------------
+// Three-kernel scan: per-block sums -> single-block scan of the sums -> add back.  n is at most a
+// few tens of millions (row counts), so this is never the bottleneck.
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;  // per thread -> 2048 per block
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_block_sums(const int64_t* in, int64_t n, int64_t* sums)
+{
+    __shared__ int64_t red[SCAN_BLOCK];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS;
+    int64_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + (int64_t)k * SCAN_BLOCK + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = SCAN_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
+}
+
+// one block: exclusive scan of `sums` (nb entries) in place; total written to sums[nb]
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_sums(int64_t* sums, int64_t nb)
+{
+    __shared__ int64_t tile[SCAN_BLOCK];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += SCAN_BLOCK) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = (i < nb) ? sums[i] : 0;
+        tile[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < SCAN_BLOCK; off <<= 1) {  // Hillis-Steele inclusive scan
+            int64_t t = 0;
+            if ((int)threadIdx.x >= off) t = tile[threadIdx.x - off];
+            __syncthreads();
+            tile[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int64_t incl = tile[threadIdx.x];
+        const int64_t c = carry;
+        if (i < nb) sums[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == SCAN_BLOCK - 1) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nb] = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply(const int64_t* in, int64_t n, const int64_t* sums,
+                                                         int64_t* out)
+{
+    // each thread owns SCAN_ITEMS CONSECUTIVE elements so the block scan is over thread totals
+    __shared__ int64_t tile[SCAN_BLOCK];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t v[SCAN_ITEMS];
+    int64_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    tile[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        int64_t t = 0;
+        if ((int)threadIdx.x >= off) t = tile[threadIdx.x - off];
+        __syncthreads();
+        tile[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int64_t run = sums[blockIdx.x] + tile[threadIdx.x] - s;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) out[n] = sums[gridDim.x];
+}
+
+__global__ void scan_empty(int64_t* out) { out[0] = 0; }
+
+int64_t exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t n)
+{
+    Context& c = ctx();
+    if (n <= 0) {
+        MI_LAUNCH(scan_empty, dim3(1), dim3(1), c.stream, out);
+        return 0;
+    }
+    const int64_t nb = ceil_div(n, (int64_t)SCAN_BLOCK * SCAN_ITEMS);
+    int64_t* sums = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nb + 1)));
+    MI_LAUNCH(scan_block_sums, dim3((unsigned)nb), dim3(SCAN_BLOCK), c.stream, in, n, sums);
+    MI_LAUNCH(scan_sums, dim3(1), dim3(SCAN_BLOCK), c.stream, sums, nb);
+    MI_LAUNCH(scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), c.stream, in, n, (const int64_t*)sums, out);
+    int64_t total = 0;
+    MI_HIP_CHECK(hipMemcpyAsync(&total, out + n, sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return total;
+}
+
+}  // namespace mi
+
+// ================================================================================================
+// service entry points
+// ================================================================================================
+extern "C" {
+
+mi_sparse_status_t mi_sparse_get_version_string(char* buf, int len)
+{
+    return mi::guarded([&] {
+        if (!buf || len <= 0) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad buffer");
+        int n = 0;
+        char dev[300] = "no HIP device visible";
+        if (hipGetDeviceCount(&n) == hipSuccess && n > 0) {
+            hipDeviceProp_t prop;
+            int d = mi::ctx().device;
+            if (hipGetDeviceProperties(&prop, d) == hipSuccess)
+                snprintf(dev, sizeof(dev), "%d device(s); device %d: %s (%s, %d CUs, %.0f GiB)", n, d, prop.name,
+                         prop.gcnArchName, prop.multiProcessorCount,
+                         (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+        } else {
+            (void)hipGetLastError();
+        }
+#ifdef MI_HIP_EMU
+        snprintf(buf, (size_t)len, "mi_sparse 0.1.0 HOST-EMULATED DEVELOPER BUILD (not a product): %s", dev);
+#else
+        snprintf(buf, (size_t)len, "mi_sparse 0.1.0 (HIP, gfx950 / CDNA4 kernels): %s", dev);
+#endif
+    });
+}
+
+int mi_sparse_get_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+mi_sparse_status_t mi_sparse_set_device(int device)
+{
+    return mi::guarded([&] {
+        mi::Context& c = mi::ctx();
+        if (device < 0) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "negative device");
+        if (c.initialised && c.device != device) {
+            c.sync();
+            c.scratch.release();
+            c.scratch_used = 0;
+            c.initialised = false;
+        }
+        c.device = device;
+        c.ensure();
+    });
+}
+
+mi_sparse_status_t mi_sparse_set_stream(void* hip_stream)
+{
+    return mi::guarded([&] { mi::ctx().stream = static_cast<hipStream_t>(hip_stream); });
+}
+
+mi_sparse_status_t mi_sparse_synchronize(void)
+{
+    return mi::guarded([&] { mi::ctx().sync(); });
+}
+
+const char* mi_sparse_last_error(void) { return mi::get_error(); }
+
+mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
+{
+    return mi::guarded([&] {
+        if (!name) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "NULL option name");
+        mi::Options& o = mi::options();
+        if (!strcmp(name, "spmm_chunk")) {
+            if (value != 128 && value != 256 && value != 512 && value != 1024)
+                mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_chunk must be 128, 256, 512 or 1024");
+            o.spmm_chunk = value;
+        } else if (!strcmp(name, "spmm_force_generic")) {
+            o.spmm_force_generic = value;
+        } else if (!strcmp(name, "spgemm_force_global")) {
+            o.spgemm_force_global = value;
+        } else {
+            mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown option '%s'", name);
+        }
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,535 @@
+// spgemm.hip -- sparse x sparse products:
+//   mi_sparse_spmm      C := A * B            (sparse CSR out)   reference _sparse_sparse.py:35-40
+//   mi_sparse_?_spmmd   C := A * B            (dense out)        reference _sparse_sparse.py:94-101
+//   mi_sparse_syrk      C := triu(A^T A) / triu(A A^T) (sparse)  reference _gram_matrix.py:70-74
+//
+// Two-phase row-wise (Gustavson) SpGEMM with hash accumulators:
+//   0. ub[i]  = sum over nonzeros (i,k) of A of nnz(B[k,:])          (upper bound of row i of C)
+//   1. symbolic: rows binned by ub; every row counts its distinct columns in a hash table
+//      (LDS table per workgroup for ub <= 2048; a global-memory slab per persistent workgroup
+//      for the hub rows of skewed matrices)
+//   2. exclusive scan of the counts -> row pointer of C (int64: nnz(C) may exceed 2^31)
+//   3. numeric: rows re-binned by their exact length; same hash tables now carry values
+//      (LDS float/double atomic adds), then the table is compacted into C.
+// Column order inside a row of C is unspecified (as with mkl_sparse_spmm); mi_sparse_order sorts.
+// Entries that cancel to 0.0 stay (MKL keeps them; scipy prunes -- SURVEY section 8 a3).
+#include "common.hpp"
+
+namespace mi {
+
+constexpr int32_t HASH_EMPTY = -1;
+
+__device__ __forceinline__ uint32_t hash_col(int32_t c, int log2s)
+{
+    return (uint32_t)((uint32_t)c * 2654435761u) >> (32 - log2s);
+}
+
+// ---- phase 0: upper bounds -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_row_ub(int64_t rows, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
+             const int64_t* __restrict__ bptr, int64_t* __restrict__ ub)
+{
+    // 8 lanes per row
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = t >> 3;
+    const int sub = (int)(t & 7);
+    int64_t s = 0;
+    if (row < rows) {
+        for (int64_t p = aptr[row] + sub; p < aptr[row + 1]; p += 8) {
+            const int32_t k = acol[p];
+            s += bptr[k + 1] - bptr[k];
+        }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (row < rows && sub == 0) ub[row] = s;
+}
+
+// ---- binning -------------------------------------------------------------------------------------
+constexpr int NBINS = 4;                       // 0: <=32   1: <=256   2: <=2048   3: larger
+__host__ __device__ inline int bin_of(int64_t c)
+{
+    return c <= 32 ? 0 : c <= 256 ? 1 : c <= 2048 ? 2 : 3;
+}
+
+// counts per bin (rows with c == 0 are skipped); when `lists` != nullptr also scatters the row ids
+__global__ void __launch_bounds__(256)
+    k_bin_rows(int64_t rows, const int64_t* __restrict__ cnt, int64_t* __restrict__ bin_counts,
+               int32_t* const* __restrict__ lists)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const int64_t c = cnt[i];
+    if (c <= 0) return;
+    const int b = bin_of(c);
+    const int64_t d = (int64_t)atomicAdd((unsigned long long*)&bin_counts[b], 1ull);
+    if (lists) lists[b][d] = (int32_t)i;
+}
+
+// ---- LDS hash kernel: one workgroup per row -------------------------------------------------------
+template <typename T, int LOG2S, int THREADS, bool NUMERIC>
+__global__ void __launch_bounds__(THREADS)
+    k_spgemm_lds(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
+                 const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
+                 const int32_t* __restrict__ bcol, const T* __restrict__ bval, int gw, int upper,
+                 int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
+                 T* __restrict__ cval)
+{
+    constexpr int S = 1 << LOG2S;
+    __shared__ int32_t keys[S];
+    __shared__ T vals[NUMERIC ? S : 1];
+    __shared__ int counter;
+    const int tid = threadIdx.x;
+    const int32_t row = row_list[blockIdx.x];
+    for (int k = tid; k < S; k += THREADS) {
+        keys[k] = HASH_EMPTY;
+        if (NUMERIC) vals[k] = vt<T>::zero();
+    }
+    if (tid == 0) counter = 0;
+    __syncthreads();
+
+    const int group = tid / gw, ngroups = THREADS / gw, gl = tid % gw;
+    int local = 0;
+    const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+    for (int64_t p = a0 + group; p < a1; p += ngroups) {
+        const int32_t kk = acol[p];
+        T a = vt<T>::zero();
+        if (NUMERIC) a = aval[p];
+        const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
+        for (int64_t q = b0 + gl; q < b1; q += gw) {
+            const int32_t j = bcol[q];
+            if (upper && j < row) continue;
+            uint32_t h = hash_col(j, LOG2S);
+            for (;;) {
+                const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, j);
+                if (old == HASH_EMPTY || old == j) {
+                    if (NUMERIC) atomic_accum(&vals[h], vt<T>::mul(a, bval[q]));
+                    else if (old == HASH_EMPTY) ++local;
+                    break;
+                }
+                h = (h + 1) & (S - 1);
+            }
+        }
+    }
+    if (!NUMERIC) {
+        if (local) atomicAdd(&counter, local);
+        __syncthreads();
+        if (tid == 0) row_nnz[row] = counter;
+    } else {
+        __syncthreads();
+        const int64_t base = cptr[row];
+        for (int k = tid; k < S; k += THREADS) {
+            const int32_t key = keys[k];
+            if (key != HASH_EMPTY) {
+                const int pos = atomicAdd(&counter, 1);
+                ccol[base + pos] = key;
+                cval[base + pos] = vals[k];
+            }
+        }
+    }
+}
+
+// ---- global-memory hash kernel: persistent workgroups, one slab each ------------------------------
+template <typename T>
+__device__ __forceinline__ T load_l2(const T* p)
+{
+#ifdef MI_HIP_EMU
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+
+template <typename T, bool NUMERIC>
+__global__ void __launch_bounds__(1024)
+    k_spgemm_global(int64_t nbig, const int32_t* __restrict__ row_list, const int64_t* __restrict__ cnt,
+                    int64_t ncols, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
+                    const T* __restrict__ aval, const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol,
+                    const T* __restrict__ bval, int gw, int upper, int32_t* slab_keys, T* slab_vals, int64_t slab,
+                    int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
+                    T* __restrict__ cval)
+{
+    __shared__ int counter;
+    const int tid = threadIdx.x;
+    const int threads = blockDim.x;
+    int32_t* keys = slab_keys + (int64_t)blockIdx.x * slab;
+    T* vals = NUMERIC ? slab_vals + (int64_t)blockIdx.x * slab : nullptr;
+    for (int64_t idx = blockIdx.x; idx < nbig; idx += gridDim.x) {
+        const int32_t row = row_list[idx];
+        int64_t c = cnt[row];
+        if (c > ncols) c = ncols;
+        int log2s = 2;
+        while (((int64_t)1 << log2s) < 2 * c) ++log2s;
+        const int64_t S = (int64_t)1 << log2s;  // <= slab by construction
+        for (int64_t k = tid; k < S; k += threads) {
+            keys[k] = HASH_EMPTY;
+            if (NUMERIC) vals[k] = vt<T>::zero();
+        }
+        if (tid == 0) counter = 0;
+        __syncthreads();
+        const int group = tid / gw, ngroups = threads / gw, gl = tid % gw;
+        int local = 0;
+        const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+        for (int64_t p = a0 + group; p < a1; p += ngroups) {
+            const int32_t kk = acol[p];
+            T a = vt<T>::zero();
+            if (NUMERIC) a = aval[p];
+            const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
+            for (int64_t q = b0 + gl; q < b1; q += gw) {
+                const int32_t j = bcol[q];
+                if (upper && j < row) continue;
+                uint32_t h = hash_col(j, log2s);
+                for (;;) {
+                    const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, j);
+                    if (old == HASH_EMPTY || old == j) {
+                        if (NUMERIC) atomic_accum(&vals[h], vt<T>::mul(a, bval[q]));
+                        else if (old == HASH_EMPTY) ++local;
+                        break;
+                    }
+                    h = (h + 1) & (uint32_t)(S - 1);
+                }
+            }
+        }
+        if (!NUMERIC) {
+            if (local) atomicAdd(&counter, local);
+            __syncthreads();
+            if (tid == 0) row_nnz[row] = counter;
+            __syncthreads();
+        } else {
+            __syncthreads();
+            const int64_t base = cptr[row];
+            for (int64_t k = tid; k < S; k += threads) {
+                // the table was updated by L2 atomics: read it back past the (possibly stale) L1
+                const int32_t key = load_l2(&keys[k]);
+                if (key != HASH_EMPTY) {
+                    const int pos = atomicAdd(&counter, 1);
+                    ccol[base + pos] = key;
+                    T v;
+                    if (vt<T>::is_complex) {
+                        using R = typename vt<T>::real;
+                        const R* pr = reinterpret_cast<const R*>(&vals[k]);
+                        R* vr = reinterpret_cast<R*>(&v);
+                        vr[0] = load_l2(pr);
+                        vr[1] = load_l2(pr + 1);
+                    } else {
+                        using R = typename vt<T>::real;
+                        *reinterpret_cast<R*>(&v) = load_l2(reinterpret_cast<const R*>(&vals[k]));
+                    }
+                    cval[base + pos] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- dense-output variant (spmmd): one wave per row, products scattered with L2 atomics ------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_spmmd(int64_t rows, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
+            const T* __restrict__ aval, const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol,
+            const T* __restrict__ bval, T* __restrict__ C, int64_t c_rs, int64_t c_cs)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (row >= rows) return;
+    T* crow = C + row * c_rs;
+    for (int64_t p = aptr[row]; p < aptr[row + 1]; ++p) {
+        const int32_t kk = acol[p];
+        const T a = aval[p];
+        for (int64_t q = bptr[kk] + lane; q < bptr[kk + 1]; q += WAVE)
+            atomic_accum(crow + (int64_t)bcol[q] * c_cs, vt<T>::mul(a, bval[q]));
+    }
+}
+
+template <typename T>
+__global__ void k_fill_dense(T* C, int64_t r, int64_t cdim, int64_t c_rs, int64_t c_cs, T v)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= r * cdim) return;
+    // consecutive threads -> consecutive memory
+    const bool row_major = (c_cs == 1);
+    const int64_t i = row_major ? t / cdim : t % r;
+    const int64_t j = row_major ? t % cdim : t / r;
+    C[i * c_rs + j * c_cs] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct Bins {
+    int64_t n[NBINS] = {0, 0, 0, 0};
+    int32_t* list[NBINS] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+static Bins make_bins(const int64_t* cnt, int64_t rows)
+{
+    Context& c = ctx();
+    Bins b;
+    int64_t* dcounts = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * NBINS));
+    MI_HIP_CHECK(hipMemsetAsync(dcounts, 0, sizeof(int64_t) * NBINS, c.stream));
+    const dim3 grid((unsigned)ceil_div(rows > 0 ? rows : 1, 256));
+    MI_LAUNCH(k_bin_rows, grid, dim3(256), c.stream, rows, cnt, dcounts, (int32_t* const*)nullptr);
+    MI_HIP_CHECK(hipMemcpyAsync(b.n, dcounts, sizeof(int64_t) * NBINS, hipMemcpyDeviceToHost, c.stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+    int32_t* hl[NBINS];
+    for (int k = 0; k < NBINS; ++k) {
+        b.list[k] = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(b.n[k] + 1)));
+        hl[k] = b.list[k];
+    }
+    int32_t** dl = static_cast<int32_t**>(c.scratch_alloc(sizeof(int32_t*) * NBINS));
+    MI_HIP_CHECK(hipMemcpyAsync(dl, hl, sizeof(hl), hipMemcpyHostToDevice, c.stream));
+    MI_HIP_CHECK(hipMemsetAsync(dcounts, 0, sizeof(int64_t) * NBINS, c.stream));
+    MI_LAUNCH(k_bin_rows, grid, dim3(256), c.stream, rows, cnt, dcounts, (int32_t* const*)dl);
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // hl is on the host stack
+    return b;
+}
+
+static int pick_gw(const Csr& B)
+{
+    const double avg = B.rows > 0 ? (double)B.nnz / (double)B.rows : 1.0;
+    int gw = 4;
+    while (gw < 64 && gw < avg) gw <<= 1;
+    return gw;
+}
+
+template <typename T, bool NUMERIC>
+static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt, int64_t max_cnt, int64_t* row_nnz,
+                      const int64_t* cptr, int32_t* ccol, T* cval)
+{
+    Context& c = ctx();
+    const int gw = pick_gw(B);
+    const int gw64 = gw > 64 ? 64 : gw;
+    Bins b = make_bins(cnt, A.rows);
+    const bool force_global = options().spgemm_force_global != 0;
+#define MI_SPGEMM_ARGS(list)                                                                                       \
+    (const int32_t*)list, (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,   \
+        (const int32_t*)B.col, (const T*)B.val
+    if (!force_global) {
+        if (b.n[0])
+            MI_LAUNCH((k_spgemm_lds<T, 6, 64, NUMERIC>), dim3((unsigned)b.n[0]), dim3(64), c.stream,
+                      MI_SPGEMM_ARGS(b.list[0]), gw64, (int)upper, row_nnz, cptr, ccol, cval);
+        if (b.n[1])
+            MI_LAUNCH((k_spgemm_lds<T, 9, 64, NUMERIC>), dim3((unsigned)b.n[1]), dim3(64), c.stream,
+                      MI_SPGEMM_ARGS(b.list[1]), gw64, (int)upper, row_nnz, cptr, ccol, cval);
+        if (b.n[2])
+            MI_LAUNCH((k_spgemm_lds<T, 12, 256, NUMERIC>), dim3((unsigned)b.n[2]), dim3(256), c.stream,
+                      MI_SPGEMM_ARGS(b.list[2]), gw, (int)upper, row_nnz, cptr, ccol, cval);
+    }
+    for (int k = 0; k < NBINS; ++k) {
+        if (!b.n[k] || (!force_global && k < 3)) continue;
+        // slab = table size of the largest row: next pow2 >= 2 * min(max_cnt, cols)
+        int64_t cap = max_cnt < B.cols ? max_cnt : B.cols;
+        int64_t slab = 4;
+        while (slab < 2 * cap) slab <<= 1;
+        int64_t nblocks = b.n[k] < 512 ? b.n[k] : 512;
+        // keep the slabs under ~4 GiB
+        const size_t per = (size_t)slab * (sizeof(int32_t) + (NUMERIC ? sizeof(T) : 0));
+        while (nblocks > 1 && per * (size_t)nblocks > (size_t(4) << 30)) nblocks >>= 1;
+        DevBuf kbuf, vbuf;
+        kbuf.alloc(sizeof(int32_t) * (size_t)slab * (size_t)nblocks);
+        if (NUMERIC) vbuf.alloc(sizeof(T) * (size_t)slab * (size_t)nblocks);
+        MI_LAUNCH((k_spgemm_global<T, NUMERIC>), dim3((unsigned)nblocks), dim3(1024), c.stream, b.n[k],
+                  (const int32_t*)b.list[k], cnt, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
+                  (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val, gw, (int)upper,
+                  kbuf.as<int32_t>(), vbuf.as<T>(), slab, row_nnz, cptr, ccol, cval);
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // slabs are freed on scope exit
+    }
+#undef MI_SPGEMM_ARGS
+    MI_HIP_CHECK(hipGetLastError());
+}
+
+__global__ void k_max_i64(const int64_t* in, int64_t n, int64_t* out)
+{
+    __shared__ int64_t red[256];
+    int64_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (in[i] > m) m = in[i];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off && red[threadIdx.x + off] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax((long long*)out, (long long)red[0]);
+}
+
+static int64_t device_max(const int64_t* in, int64_t n)
+{
+    Context& c = ctx();
+    int64_t* d = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t)));
+    MI_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(int64_t), c.stream));
+    if (n > 0) {
+        const int64_t blocks = ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024;
+        MI_LAUNCH(k_max_i64, dim3((unsigned)blocks), dim3(256), c.stream, in, n, d);
+    }
+    int64_t h = 0;
+    MI_HIP_CHECK(hipMemcpyAsync(&h, d, sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return h;
+}
+
+// C := A * B (or its upper triangle).  C's storage is allocated here.
+template <typename T>
+static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
+{
+    Context& c = ctx();
+    if (A.cols != B.rows)
+        fail(MI_SPARSE_STATUS_INVALID_VALUE, "dimension mismatch: (%lld x %lld) * (%lld x %lld)", (long long)A.rows,
+             (long long)A.cols, (long long)B.rows, (long long)B.cols);
+    C.rows = A.rows;
+    C.cols = B.cols;
+    C.ptr_own.alloc(sizeof(int64_t) * (size_t)(C.rows + 1));
+    C.ptr = C.ptr_own.as<int64_t>();
+    int64_t* ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
+    int64_t* row_nnz = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
+    MI_HIP_CHECK(hipMemsetAsync(row_nnz, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
+    if (A.rows > 0)
+        MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows,
+                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, ub);
+    const int64_t max_ub = device_max(ub, A.rows);
+    run_phase<T, false>(A, B, upper, ub, max_ub, row_nnz, nullptr, nullptr, nullptr);
+    const int64_t nnz = exclusive_scan_i64(row_nnz, C.ptr, C.rows);
+    C.nnz = nnz;
+    C.col_own.alloc(sizeof(int32_t) * (size_t)nnz);
+    C.val_own.alloc(sizeof(T) * (size_t)nnz);
+    C.col = C.col_own.as<int32_t>();
+    C.val = C.val_own.p;
+    if (nnz > 0) {
+        const int64_t max_nnz = device_max(row_nnz, A.rows);
+        run_phase<T, true>(A, B, upper, row_nnz, max_nnz, nullptr, C.ptr, C.col, static_cast<T*>(C.val));
+    }
+    C.valid = true;
+    C.sorted = false;
+}
+
+void spgemm(char vtype, const Csr& A, const Csr& B, bool upper, Csr& C)
+{
+    by_type(vtype, [&](auto tag) { spgemm_typed<decltype(tag)>(A, B, upper, C); });
+}
+
+template <typename T>
+static int spmmd_generic(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, int layout, T* C, int64_t ldc)
+{
+    return guarded([&] {
+        mi_sparse_matrix* ha = check_handle(A);
+        mi_sparse_matrix* hb = check_handle(B);
+        if (op != MI_SPARSE_OPERATION_NON_TRANSPOSE) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "spmmd supports op = 10 only");
+        if (ha->vtype != type_char<T>::value || hb->vtype != type_char<T>::value)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "value type mismatch between handles and routine");
+        if (layout != MI_SPARSE_LAYOUT_ROW_MAJOR && layout != MI_SPARSE_LAYOUT_COLUMN_MAJOR)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad layout code %d", layout);
+        if (ha->cols != hb->rows)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "dimension mismatch: (%lld x %lld) * (%lld x %lld)",
+                 (long long)ha->rows, (long long)ha->cols, (long long)hb->rows, (long long)hb->cols);
+        const int64_t m = ha->rows, n = hb->cols;
+        if (m == 0 || n == 0) return;
+        if (!C) fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL output array");
+        const bool row_major = layout == MI_SPARSE_LAYOUT_ROW_MAJOR;
+        if (ldc < (row_major ? n : m)) fail(MI_SPARSE_STATUS_INVALID_VALUE, "ldc too small");
+        Context& c = ctx();
+        c.scratch_reset();
+        Csr& a = need_csr(ha);
+        Csr& b = need_csr(hb);
+        const int64_t c_rs = row_major ? ldc : 1, c_cs = row_major ? 1 : ldc;
+        const size_t extent = row_major ? (size_t)((m - 1) * ldc + n) : (size_t)((n - 1) * ldc + m);
+        Staged sc;
+        sc.stage_in(C, sizeof(T) * extent, false);
+        MI_LAUNCH((k_fill_dense<T>), dim3((unsigned)ceil_div(m * n, 256)), dim3(256), c.stream, static_cast<T*>(sc.dev), m,
+                  n, c_rs, c_cs, vt<T>::zero());
+        MI_LAUNCH((k_spmmd<T>), dim3((unsigned)ceil_div(m * WAVE, 256)), dim3(256), c.stream, m, (const int64_t*)a.ptr,
+                  (const int32_t*)a.col, (const T*)a.val, (const int64_t*)b.ptr, (const int32_t*)b.col,
+                  (const T*)b.val, static_cast<T*>(sc.dev), c_rs, c_cs);
+        MI_HIP_CHECK(hipGetLastError());
+        sc.copy_back();
+    });
+}
+
+}  // namespace mi
+
+using mi::cdouble;
+using mi::cfloat;
+
+extern "C" {
+
+mi_sparse_status_t mi_sparse_spmm(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, mi_sparse_matrix_t* C)
+{
+    return mi::guarded([&] {
+        if (!C) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL output handle pointer");
+        *C = nullptr;
+        mi_sparse_matrix* ha = mi::check_handle(A);
+        mi_sparse_matrix* hb = mi::check_handle(B);
+        if (op != MI_SPARSE_OPERATION_NON_TRANSPOSE)
+            mi::fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "spmm supports op = 10 only");
+        if (ha->vtype != hb->vtype) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "operands hold different value types");
+        if (ha->cols != hb->rows)
+            mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "dimension mismatch: (%lld x %lld) * (%lld x %lld)",
+                     (long long)ha->rows, (long long)ha->cols, (long long)hb->rows, (long long)hb->cols);
+        mi::ctx().scratch_reset();
+        mi::Csr& a = mi::need_csr(ha);
+        mi::Csr& b = mi::need_csr(hb);
+        const int ib = ha->index_bytes > hb->index_bytes ? ha->index_bytes : hb->index_bytes;
+        mi_sparse_matrix* r = mi::new_result_handle(ha->vtype, ib, ha->rows, hb->cols);
+        try {
+            mi::spgemm(ha->vtype, a, b, false, r->csr);
+            mi::ctx().sync();
+        } catch (...) {
+            r->magic = 0;
+            delete r;
+            throw;
+        }
+        *C = r;
+    });
+}
+
+mi_sparse_status_t mi_sparse_syrk(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t* C)
+{
+    return mi::guarded([&] {
+        if (!C) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL output handle pointer");
+        *C = nullptr;
+        mi_sparse_matrix* h = mi::check_handle(A);
+        if (op != MI_SPARSE_OPERATION_NON_TRANSPOSE && op != MI_SPARSE_OPERATION_TRANSPOSE &&
+            op != MI_SPARSE_OPERATION_CONJUGATE_TRANSPOSE)
+            mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad operation code %d", op);
+        if (h->vtype == 'c' || h->vtype == 'z')
+            mi::fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "syrk supports real values only (the reference rejects complex gram)");
+        mi::ctx().scratch_reset();
+        mi::Csr& a = mi::need_csr(h);
+        mi::Csr& at = mi::need_csrT(h);
+        const bool aat = (op == MI_SPARSE_OPERATION_NON_TRANSPOSE);
+        const int64_t n = aat ? h->rows : h->cols;
+        mi_sparse_matrix* r = mi::new_result_handle(h->vtype, h->index_bytes, n, n);
+        try {
+            if (aat) mi::spgemm(h->vtype, a, at, true, r->csr);
+            else mi::spgemm(h->vtype, at, a, true, r->csr);
+            mi::ctx().sync();
+        } catch (...) {
+            r->magic = 0;
+            delete r;
+            throw;
+        }
+        *C = r;
+    });
+}
+
+mi_sparse_status_t mi_sparse_s_spmmd(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, int layout, float* C, int64_t ldc)
+{
+    return mi::spmmd_generic<float>(op, A, B, layout, C, ldc);
+}
+mi_sparse_status_t mi_sparse_d_spmmd(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, int layout, double* C, int64_t ldc)
+{
+    return mi::spmmd_generic<double>(op, A, B, layout, C, ldc);
+}
+mi_sparse_status_t mi_sparse_c_spmmd(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, int layout, mi_complex8* C,
+                                     int64_t ldc)
+{
+    return mi::spmmd_generic<cfloat>(op, A, B, layout, (cfloat*)C, ldc);
+}
+mi_sparse_status_t mi_sparse_z_spmmd(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, int layout, mi_complex16* C,
+                                     int64_t ldc)
+{
+    return mi::spmmd_generic<cdouble>(op, A, B, layout, (cdouble*)C, ldc);
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+// spmm.hip -- C := alpha * op(A) * B + beta * C   (CSR x dense), the primary hot path.
+// Replaces mkl_sparse_?_mm / mkl_sparse_?_mv (reference sparse_dot_mkl/_sparse_dense.py:111-123,
+// _sparse_vector.py:87-95).
+//
+// Kernel design (gfx950, 64-lane waves)
+// -------------------------------------
+// Work decomposition is nnz+row balanced ("merge path"): the sequence of all nonzeros with one
+// extra "row end" item after every row has nnz + rows items; wave w takes items
+// [w*CH, (w+1)*CH).  A row is OWNED by the wave that holds its row-end item; the owner writes the
+// output row exactly once with plain stores (no atomics, no pre-zeroing of C: empty rows are
+// just row-end items).  A row cut by a chunk boundary leaves a partial sum ("carry") in a small
+// workspace (one N-vector per wave at most); a second tiny kernel adds the carries of a row, in
+// chunk order, to the owner's output -> results are deterministic run to run.  Skewed (R-MAT)
+// rows of 64 k nonzeros therefore spread over ~250 waves instead of one.
+//
+// Inside a wave the lanes span the DENSE dimension: LPN lanes x V values (16 bytes per lane when
+// the layout allows: one global_load_dwordx4) cover one row of B, so every B-row read is a
+// fully coalesced 16*LPN-byte segment; the 64/LPN lane groups of the wave work on different
+// nonzeros of the same output row and are combined with xor-shuffles at the row end.  The wave's
+// slice of A (column indices, values, row ends) is staged once in LDS with coalesced loads and
+// then broadcast-read; B rows go straight from L2/HBM to registers (there is no intra-workgroup
+// reuse of a B row to stage for -- see DESIGN.md), U independent loads in flight per lane.
+#include "common.hpp"
+
+namespace mi {
+
+template <typename T>
+__device__ __forceinline__ T shfl_xor_val(T v, int mask)
+{
+    return __shfl_xor(v, mask);
+}
+template <typename R>
+__device__ __forceinline__ cx<R> shfl_xor_val(cx<R> v, int mask)
+{
+    return cx<R>{__shfl_xor(v.re, mask), __shfl_xor(v.im, mask)};
+}
+
+// chunk_row[w] = number of rows whose row-end item lies before item w*chunk
+__global__ void k_spmm_plan(const int64_t* ptr, int64_t rows, int64_t chunk, int64_t nchunks, int32_t* chunk_row)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > nchunks) return;
+    const int64_t s = w * chunk;
+    // smallest r in [0, rows] with q(r) = ptr[r+1] + r + 1 > s   (q is strictly increasing)
+    int64_t lo = 0, hi = rows;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ptr[mid + 1] + mid + 1 > s) hi = mid; else lo = mid + 1;
+    }
+    chunk_row[w] = (int32_t)lo;
+}
+
+constexpr int SPMM_WAVES = 4;  // waves per workgroup (independent of each other after staging)
+
+// LDS bytes one wave needs for a chunk of CH items
+template <typename T>
+__host__ __device__ constexpr size_t spmm_wave_lds(int ch)
+{
+    return (size_t)ch * (sizeof(int32_t) + sizeof(T)) + (size_t)(ch + 2) * sizeof(int32_t);
+}
+
+template <typename T, int V, int LPN, int U>
+__global__ void __launch_bounds__(SPMM_WAVES* WAVE)
+    k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
+           const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
+           const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
+           int64_t N, T alpha, T beta, int beta_zero, int32_t* __restrict__ carry_row, T* __restrict__ carry_val)
+{
+    MI_DYN_SMEM(smem);
+    constexpr int NG = WAVE / LPN;  // lane groups per wave, each on its own nonzero
+    const int wave_in_block = threadIdx.x / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    const int64_t w = (int64_t)blockIdx.x * SPMM_WAVES + wave_in_block;
+    const bool active = w < nchunks;
+
+    // carve this wave's LDS: values first (largest alignment), then columns, then row ends
+    const size_t per_wave = (spmm_wave_lds<T>(ch) + 15) & ~size_t(15);
+    char* base = smem + per_wave * wave_in_block;
+    T* s_val = reinterpret_cast<T*>(base);
+    int32_t* s_col = reinterpret_cast<int32_t*>(base + sizeof(T) * (size_t)ch);
+    int32_t* s_end = s_col + ch;
+
+    int64_t r0 = 0, r1 = 0, P0 = 0;
+    int n_owned = 0, has_trail = 0;
+    if (active) {
+        const int64_t total = nnz + rows;
+        const int64_t s = w * ch;
+        const int64_t e = (s + ch < total) ? s + ch : total;
+        r0 = chunk_row[w];
+        r1 = chunk_row[w + 1];
+        n_owned = (int)(r1 - r0);
+        const int64_t p_r0 = ptr[r0 < rows ? r0 : rows];
+        P0 = (s - r0 > p_r0) ? s - r0 : p_r0;
+        int64_t P1;
+        if (r1 < rows) {
+            const int64_t t_begin = (r1 == r0) ? P0 : ptr[r1];
+            int64_t t_end = ptr[r1 + 1];
+            if (e - r1 < t_end) t_end = e - r1;
+            has_trail = (t_end > t_begin) ? 1 : 0;
+            P1 = has_trail ? t_end : t_begin;
+        } else {
+            P1 = nnz;
+        }
+        // row ends relative to P0 (owned rows, then the trailing partial row)
+        const int nproc = n_owned + has_trail;
+        for (int k = lane; k < nproc; k += WAVE) {
+            int64_t en = ptr[r0 + k + 1];
+            if (k == n_owned) en = P1;  // trailing row is cut at the chunk end
+            s_end[k] = (int32_t)(en - P0);
+        }
+        const int len = (int)(P1 - P0);
+        for (int k = lane; k < len; k += WAVE) {
+            s_col[k] = col[P0 + k];
+            const T a = val[P0 + k];
+            s_val[k] = conj_a ? vt<T>::conj(a) : a;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    const int g = lane / LPN;
+    const int li = lane % LPN;
+
+    for (int64_t j0 = 0; j0 < N; j0 += (int64_t)LPN * V) {
+        const int64_t jc = j0 + (int64_t)li * V;  // first column of this lane
+        const bool col_ok = jc < N;               // V divides N on the vector path
+        const T* bcol = B + jc * b_cs;
+        int begin = 0;
+        const int nproc = n_owned + has_trail;
+        for (int k = 0; k < nproc; ++k) {
+            const int end = s_end[k];
+            T acc[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = vt<T>::zero();
+            for (int p = begin + g; p < end; p += NG * U) {
+                vec<T, V> b[U];
+                T a[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int pp = p + u * NG;
+                    ok[u] = pp < end;
+                    const int pc = ok[u] ? pp : end - 1;  // clamp: re-read a valid entry of this row
+                    a[u] = s_val[pc];
+                    const int64_t c = s_col[pc];
+                    if (col_ok) {
+                        if (V > 1) {
+                            b[u] = *reinterpret_cast<const vec<T, V>*>(bcol + c * b_rs);
+                        } else {
+                            b[u].v[0] = bcol[c * b_rs];
+                        }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) b[u].v[v] = vt<T>::zero();
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (ok[u]) {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) acc[v] = vt<T>::fma(a[u], b[u].v[v], acc[v]);
+                    }
+                }
+            }
+            begin = end;
+            // combine the lane groups
+#pragma unroll
+            for (int off = LPN; off < WAVE; off <<= 1) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] = vt<T>::add(acc[v], shfl_xor_val(acc[v], off));
+            }
+            if (g == 0 && col_ok) {
+                if (k < n_owned) {
+                    T* crow = C + (r0 + k) * c_rs + jc * c_cs;
+                    vec<T, V> out;
+                    if (beta_zero) {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) out.v[v] = vt<T>::mul(alpha, acc[v]);
+                    } else {
+                        vec<T, V> old;
+                        if (V > 1) {
+                            old = *reinterpret_cast<const vec<T, V>*>(crow);
+                        } else {
+                            old.v[0] = crow[0];
+                        }
+#pragma unroll
+                        for (int v = 0; v < V; ++v)
+                            out.v[v] = vt<T>::fma(alpha, acc[v], vt<T>::mul(beta, old.v[v]));
+                    }
+                    if (V > 1) {
+                        *reinterpret_cast<vec<T, V>*>(crow) = out;
+                    } else {
+                        crow[0] = out.v[0];
+                    }
+                } else {
+                    // trailing partial row -> carry (raw partial sum; alpha applied by the fix-up)
+                    T* cv = carry_val + w * N + jc;
+                    if (V > 1) {
+                        vec<T, V> out;
+#pragma unroll
+                        for (int v = 0; v < V; ++v) out.v[v] = acc[v];
+                        *reinterpret_cast<vec<T, V>*>(cv) = out;
+                    } else {
+                        cv[0] = acc[0];
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) carry_row[w] = has_trail ? (int32_t)r1 : -1;
+}
+
+// add the carries of every cut row to the row its owner wrote; carries of one row are contiguous
+// chunks, summed in chunk order by the wave of the first one
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_spmm_fixup(int64_t nchunks, const int32_t* __restrict__ carry_row, const T* __restrict__ carry_val, int64_t N,
+                 T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha)
+{
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (w >= nchunks) return;
+    const int32_t row = carry_row[w];
+    if (row < 0) return;
+    if (w > 0 && carry_row[w - 1] == row) return;  // not the head of this row's run
+    int64_t last = w;
+    while (last + 1 < nchunks && carry_row[last + 1] == row) ++last;
+    for (int64_t j = lane; j < N; j += WAVE) {
+        T sum = vt<T>::zero();
+        for (int64_t u = w; u <= last; ++u) sum = vt<T>::add(sum, carry_val[u * N + j]);
+        T* c = C + (int64_t)row * c_rs + j * c_cs;
+        *c = vt<T>::fma(alpha, sum, *c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, int chunk)
+{
+    SpmmPlan& p = transposed ? h->planT : h->plan;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    if (p.chunk == chunk && p.chunk_row.p) return p;
+    Context& c = ctx();
+    const int64_t total = m.nnz + m.rows;
+    p.nchunks = total > 0 ? ceil_div(total, chunk) : 1;
+    p.chunk_row.alloc(sizeof(int32_t) * (size_t)(p.nchunks + 1));
+    MI_LAUNCH(k_spmm_plan, dim3((unsigned)ceil_div(p.nchunks + 1, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
+              m.rows, (int64_t)chunk, p.nchunks, p.chunk_row.as<int32_t>());
+    p.chunk = chunk;
+    return p;
+}
+
+template <typename T, int V, int LPN>
+static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
+                        int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val)
+{
+    Context& c = ctx();
+    constexpr int U = (V > 1) ? 4 : 4;
+    const size_t per_wave = (spmm_wave_lds<T>(p.chunk) + 15) & ~size_t(15);
+    const size_t lds = per_wave * SPMM_WAVES;
+    const unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
+    const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
+    MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz,
+                   (const int64_t*)m.ptr, (const int32_t*)m.col, (const T*)m.val,
+                   (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,
+                   c_cs, N, alpha, beta, beta_zero, carry_row, carry_val);
+}
+
+// Core executor on DEVICE pointers.  m is the CSR of op(A) (rows of m = rows of C).
+template <typename T>
+void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a, T alpha, int layout, const T* B,
+                 int64_t N, int64_t ldb, T beta, T* C, int64_t ldc)
+{
+    Context& c = ctx();
+    if (m.rows == 0 || N == 0) return;
+    const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk);
+    int32_t* carry_row = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)p.nchunks));
+    T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)p.nchunks * (size_t)N));
+    const bool row_major = (layout == MI_SPARSE_LAYOUT_ROW_MAJOR);
+    const int64_t b_rs = row_major ? ldb : 1, b_cs = row_major ? 1 : ldb;
+    const int64_t c_rs = row_major ? ldc : 1, c_cs = row_major ? 1 : ldc;
+    constexpr int V16 = 16 / (int)sizeof(T);
+    const bool vec_ok = row_major && !options().spmm_force_generic && (N % V16 == 0) &&
+                        ((ldb * (int64_t)sizeof(T)) % 16 == 0) && ((ldc * (int64_t)sizeof(T)) % 16 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(B) % 16) == 0) && ((reinterpret_cast<uintptr_t>(C) % 16) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(carry_val) % 16) == 0);
+#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val
+    if (vec_ok) {
+        const int64_t lanes = N / V16;  // 16-byte lanes needed for one row of B
+        if (lanes >= 64) launch_spmm<T, V16, 64>(MI_SPMM_ARGS);
+        else if (lanes > 16) launch_spmm<T, V16, 32>(MI_SPMM_ARGS);
+        else if (lanes > 8) launch_spmm<T, V16, 16>(MI_SPMM_ARGS);
+        else launch_spmm<T, V16, 8>(MI_SPMM_ARGS);
+    } else {
+        if (N > 16) launch_spmm<T, 1, 64>(MI_SPMM_ARGS);
+        else if (N > 4) launch_spmm<T, 1, 16>(MI_SPMM_ARGS);
+        else launch_spmm<T, 1, 4>(MI_SPMM_ARGS);
+    }
+#undef MI_SPMM_ARGS
+    MI_LAUNCH((k_spmm_fixup<T>), dim3((unsigned)ceil_div(p.nchunks * WAVE, 256)), dim3(256), c.stream, p.nchunks,
+              (const int32_t*)carry_row, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+}
+
+template void spmm_device<float>(mi_sparse_matrix*, bool, const Csr&, int, float, int, const float*, int64_t, int64_t,
+                                 float, float*, int64_t);
+template void spmm_device<double>(mi_sparse_matrix*, bool, const Csr&, int, double, int, const double*, int64_t,
+                                  int64_t, double, double*, int64_t);
+template void spmm_device<cfloat>(mi_sparse_matrix*, bool, const Csr&, int, cfloat, int, const cfloat*, int64_t,
+                                  int64_t, cfloat, cfloat*, int64_t);
+template void spmm_device<cdouble>(mi_sparse_matrix*, bool, const Csr&, int, cdouble, int, const cdouble*, int64_t,
+                                   int64_t, cdouble, cdouble*, int64_t);
+
+static size_t dense_extent(int layout, int64_t r, int64_t cdim, int64_t ld)
+{
+    if (r == 0 || cdim == 0) return 0;
+    return (layout == MI_SPARSE_LAYOUT_ROW_MAJOR) ? (size_t)((r - 1) * ld + cdim) : (size_t)((cdim - 1) * ld + r);
+}
+
+template <typename T>
+static int mm_generic(int op, T alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr, int layout, const T* B,
+                      int64_t columns, int64_t ldb, T beta, T* C, int64_t ldc)
+{
+    return guarded([&] {
+        mi_sparse_matrix* h = check_handle(A);
+        if (h->vtype != type_char<T>::value)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "handle holds '%c' values but the '%c' routine was called", h->vtype,
+                 type_char<T>::value);
+        if (descr.type != MI_SPARSE_MATRIX_TYPE_GENERAL)
+            fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "only SPARSE_MATRIX_TYPE_GENERAL descriptors are supported");
+        if (op != MI_SPARSE_OPERATION_NON_TRANSPOSE && op != MI_SPARSE_OPERATION_TRANSPOSE &&
+            op != MI_SPARSE_OPERATION_CONJUGATE_TRANSPOSE)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad operation code %d", op);
+        if (layout != MI_SPARSE_LAYOUT_ROW_MAJOR && layout != MI_SPARSE_LAYOUT_COLUMN_MAJOR)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad layout code %d", layout);
+        if (columns < 0) fail(MI_SPARSE_STATUS_INVALID_VALUE, "negative column count");
+        const bool trans = (op != MI_SPARSE_OPERATION_NON_TRANSPOSE);
+        const int64_t crows = trans ? h->cols : h->rows;
+        const int64_t brows = trans ? h->rows : h->cols;
+        const bool row_major = (layout == MI_SPARSE_LAYOUT_ROW_MAJOR);
+        if (ldb < (row_major ? columns : brows) || ldc < (row_major ? columns : crows))
+            if (columns > 0 && crows > 0 && brows > 0)
+                fail(MI_SPARSE_STATUS_INVALID_VALUE, "leading dimension too small (ldb=%lld ldc=%lld)", (long long)ldb,
+                     (long long)ldc);
+        if (crows == 0 || columns == 0) return;
+        if (!C || (!B && brows > 0)) fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL dense operand");
+        Context& c = ctx();
+        c.scratch_reset();
+        Csr& m = trans ? need_csrT(h) : need_csr(h);
+        const int conj_a = (op == MI_SPARSE_OPERATION_CONJUGATE_TRANSPOSE && vt<T>::is_complex) ? 1 : 0;
+        Staged sb, sc;
+        sb.stage_in(B, sizeof(T) * dense_extent(layout, brows, columns, ldb), true);
+        sc.stage_in(C, sizeof(T) * dense_extent(layout, crows, columns, ldc), !vt<T>::is_zero(beta));
+        spmm_device<T>(h, trans, m, conj_a, alpha, layout, static_cast<const T*>(sb.dev), columns, ldb, beta,
+                       static_cast<T*>(sc.dev), ldc);
+        MI_HIP_CHECK(hipGetLastError());
+        if (sb.host) c.sync();  // staged B is freed when `sb` goes out of scope
+        sc.copy_back();
+    });
+}
+
+}  // namespace mi
+
+using mi::cdouble;
+using mi::cfloat;
+
+static inline cfloat cv(mi_complex8 x) { return cfloat{x.real, x.imag}; }
+static inline cdouble cv(mi_complex16 x) { return cdouble{x.real, x.imag}; }
+
+extern "C" {
+
+mi_sparse_status_t mi_sparse_s_mm(int op, float alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr, int layout,
+                                  const float* B, int64_t columns, int64_t ldb, float beta, float* C, int64_t ldc)
+{
+    return mi::mm_generic<float>(op, alpha, A, descr, layout, B, columns, ldb, beta, C, ldc);
+}
+mi_sparse_status_t mi_sparse_d_mm(int op, double alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr, int layout,
+                                  const double* B, int64_t columns, int64_t ldb, double beta, double* C, int64_t ldc)
+{
+    return mi::mm_generic<double>(op, alpha, A, descr, layout, B, columns, ldb, beta, C, ldc);
+}
+mi_sparse_status_t mi_sparse_c_mm(int op, mi_complex8 alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr,
+                                  int layout, const mi_complex8* B, int64_t columns, int64_t ldb, mi_complex8 beta,
+                                  mi_complex8* C, int64_t ldc)
+{
+    return mi::mm_generic<cfloat>(op, cv(alpha), A, descr, layout, (const cfloat*)B, columns, ldb, cv(beta),
+                                  (cfloat*)C, ldc);
+}
+mi_sparse_status_t mi_sparse_z_mm(int op, mi_complex16 alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr,
+                                  int layout, const mi_complex16* B, int64_t columns, int64_t ldb, mi_complex16 beta,
+                                  mi_complex16* C, int64_t ldc)
+{
+    return mi::mm_generic<cdouble>(op, cv(alpha), A, descr, layout, (const cdouble*)B, columns, ldb, cv(beta),
+                                   (cdouble*)C, ldc);
+}
+
+mi_sparse_status_t mi_sparse_s_mv(int op, float alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr,
+                                  const float* x, float beta, float* y)
+{
+    return mi::mm_generic<float>(op, alpha, A, descr, MI_SPARSE_LAYOUT_ROW_MAJOR, x, 1, 1, beta, y, 1);
+}
+mi_sparse_status_t mi_sparse_d_mv(int op, double alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr,
+                                  const double* x, double beta, double* y)
+{
+    return mi::mm_generic<double>(op, alpha, A, descr, MI_SPARSE_LAYOUT_ROW_MAJOR, x, 1, 1, beta, y, 1);
+}
+mi_sparse_status_t mi_sparse_c_mv(int op, mi_complex8 alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr,
+                                  const mi_complex8* x, mi_complex8 beta, mi_complex8* y)
+{
+    return mi::mm_generic<cfloat>(op, cv(alpha), A, descr, MI_SPARSE_LAYOUT_ROW_MAJOR, (const cfloat*)x, 1, 1,
+                                  cv(beta), (cfloat*)y, 1);
+}
+mi_sparse_status_t mi_sparse_z_mv(int op, mi_complex16 alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr,
+                                  const mi_complex16* x, mi_complex16 beta, mi_complex16* y)
+{
+    return mi::mm_generic<cdouble>(op, cv(alpha), A, descr, MI_SPARSE_LAYOUT_ROW_MAJOR, (const cdouble*)x, 1, 1,
+                                   cv(beta), (cdouble*)y, 1);
+}
+
+}  // extern "C"
