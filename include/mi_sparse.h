@@ -259,9 +259,9 @@ mi_sparse_status_t mi_sparse_z_export_csc_64(mi_sparse_matrix_t A, int *base, in
 mi_sparse_status_t mi_sparse_get_info(mi_sparse_matrix_t A, int64_t *rows, int64_t *cols, int64_t *nnz,
                                       char *value_type, int *index_bytes);
 
-/* DEVICE pointers of the handle's CSR arrays (indptr has rows+1 entries of `index_bytes` bytes),
- * valid until destroy.  Lets HBM-resident callers consume spmm / syrk results without a host
- * round trip. */
+/* DEVICE pointers of the handle's canonical CSR arrays -- indptr: int64_t[rows + 1], col_indx:
+ * int32_t[nnz], values: nnz elements of the handle's value type -- valid until destroy.  Lets
+ * HBM-resident callers consume spmm / syrk results without a host round trip. */
 mi_sparse_status_t mi_sparse_get_device_csr(mi_sparse_matrix_t A, void **indptr, void **col_indx,
                                             void **values);
 
@@ -379,6 +379,11 @@ const char *mi_sparse_last_error(void);
 /* Tuning / diagnostic knob: name -> integer value (e.g. "spmm_chunk"); unknown names return
  * INVALID_VALUE.  Used by bench.py to A/B kernel variants; defaults are the shipped choice. */
 mi_sparse_status_t mi_sparse_set_option(const char *name, int64_t value);
+/* Diagnostic counters of the calling thread.  With option "profile_events" = 1 the SpMM executor
+ * brackets its main kernel with hipEvents on the launch stream and accumulates
+ * "spmm_kernel_ms" (sum of durations) and "spmm_kernel_launches"; "reset" (any value pointer)
+ * zeroes them.  Unknown names return INVALID_VALUE. */
+mi_sparse_status_t mi_sparse_get_counter(const char *name, double *value);
 
 #ifdef __cplusplus
 }

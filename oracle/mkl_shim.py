@@ -1,0 +1,92 @@
+"""
+Minimal ctypes binding of Intel MKL's mkl_sparse_?_mm, used ONLY by bench.py's `cpu_baseline`
+leg to time the arithmetic engine the reference itself calls, on the GPU box's host cores.
+
+TEST / MEASUREMENT INFRASTRUCTURE -- never imported by the product package.  This is the build's
+own shim (the reference's Python does not travel to the GPU box); it binds the three symbols the
+reference's SpMM path uses (reference sparse_dot_mkl/_sparse_dense.py:111-123,
+_mkl_interface/_common.py:310-319, 671-680).  LP64 (32-bit index) interface.
+"""
+import ctypes as _ct
+import ctypes.util as _ctu
+import os as _os
+
+import numpy as _np
+
+
+class _Descr(_ct.Structure):
+    _fields_ = [("type", _ct.c_int), ("mode", _ct.c_int), ("diag", _ct.c_int)]
+
+
+def find_mkl():
+    """Path of a loadable libmkl_rt, or None."""
+    cands = []
+    if _os.environ.get("MKL_RT"):
+        cands.append(_os.environ["MKL_RT"])
+    cands += ["/opt/conda/lib/libmkl_rt.so", "/opt/conda/lib/libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so.2"]
+    found = _ctu.find_library("mkl_rt")
+    if found:
+        cands.append(found)
+    for c in cands:
+        try:
+            _ct.CDLL(c)
+            return c
+        except OSError:
+            continue
+    return None
+
+
+class MklSpmm:
+    """C := A @ B with A CSR (int32 indices), B / C row-major, via mkl_sparse_?_mm."""
+
+    def __init__(self, path=None):
+        path = path or find_mkl()
+        if path is None:
+            raise OSError("libmkl_rt not found")
+        self.path = path
+        self.lib = _ct.CDLL(path)
+        try:
+            self.lib.MKL_Set_Interface_Layer(_ct.c_int(0))  # LP64
+        except AttributeError:
+            pass
+        self.lib.MKL_Get_Max_Threads.restype = _ct.c_int
+
+    def threads(self):
+        return int(self.lib.MKL_Get_Max_Threads())
+
+    def version(self):
+        buf = _ct.create_string_buffer(256)
+        self.lib.MKL_Get_Version_String(buf, 256)
+        return buf.value.decode().strip()
+
+    def make(self, a):
+        dt = _np.dtype(a.dtype)
+        letter = {"float32": "s", "float64": "d"}[dt.name]
+        indptr = _np.ascontiguousarray(a.indptr, dtype=_np.int32)
+        indices = _np.ascontiguousarray(a.indices, dtype=_np.int32)
+        data = _np.ascontiguousarray(a.data)
+        h = _ct.c_void_p()
+        create = getattr(self.lib, "mkl_sparse_%s_create_csr" % letter)
+        create.restype = _ct.c_int
+        st = create(_ct.byref(h), _ct.c_int(0), _ct.c_int(a.shape[0]), _ct.c_int(a.shape[1]),
+                    _ct.c_void_p(indptr.ctypes.data), _ct.c_void_p(indptr.ctypes.data + 4),
+                    _ct.c_void_p(indices.ctypes.data), _ct.c_void_p(data.ctypes.data))
+        if st:
+            raise RuntimeError("mkl_sparse_%s_create_csr returned %d" % (letter, st))
+        return (h, letter, (indptr, indices, data))
+
+    def mm(self, handle, b, out):
+        h, letter, _keep = handle
+        fn = getattr(self.lib, "mkl_sparse_%s_mm" % letter)
+        ct = _ct.c_float if letter == "s" else _ct.c_double
+        fn.restype = _ct.c_int
+        fn.argtypes = [_ct.c_int, ct, _ct.c_void_p, _Descr, _ct.c_int, _ct.c_void_p, _ct.c_int, _ct.c_int, ct,
+                       _ct.c_void_p, _ct.c_int]
+        st = fn(10, 1.0, h, _Descr(20, 0, 0), 101, b.ctypes.data, b.shape[1], b.shape[1], 0.0, out.ctypes.data,
+                out.shape[1])
+        if st:
+            raise RuntimeError("mkl_sparse_%s_mm returned %d" % (letter, st))
+        return out
+
+    def destroy(self, handle):
+        self.lib.mkl_sparse_destroy(handle[0])

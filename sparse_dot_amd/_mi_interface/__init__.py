@@ -45,6 +45,12 @@ def mi_set_option(name, value):
     _check_return_value(MI.call("mi_sparse_set_option", name.encode(), int(value)), "mi_sparse_set_option")
 
 
+def mi_get_counter(name):
+    v = _ct.c_double()
+    _check_return_value(MI.call("mi_sparse_get_counter", name.encode(), _ct.byref(v)), "mi_sparse_get_counter")
+    return v.value
+
+
 def mi_interface_integer_dtype():
     """Index dtype of results built from int32 inputs (int64 inputs / huge results give int64)."""
     return _np.int32

@@ -29,6 +29,32 @@ def _find_library():
     )
 
 
+def _share_torch_hip_runtime():
+    """When PyTorch-ROCm is installed it bundles its own copy of the HIP runtime (libamdhip64).
+    Two copies of that runtime in one process cannot both own the GPU (the second one reports
+    "no devices"), and which copy wins would depend on import order.  So, if a torch install is
+    present, its copy is loaded FIRST (without importing torch); libmi_sparse.so's
+    `NEEDED libamdhip64.so.7` then binds to that same object and torch may be imported before or
+    after this package.  Without torch the system runtime (/opt/rocm) is used.  Opt out with
+    MI_SPARSE_NO_TORCH_HIP=1."""
+    if _os.environ.get("MI_SPARSE_NO_TORCH_HIP"):
+        return None
+    try:
+        import importlib.util as _ilu
+        spec = _ilu.find_spec("torch")
+        if spec is None or not spec.origin:
+            return None
+        cand = _os.path.join(_os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if _os.path.exists(cand):
+            return _ct.CDLL(cand, mode=_ct.RTLD_GLOBAL)
+    except Exception:
+        return None
+    return None
+
+
+_torch_hip = _share_torch_hip_runtime()
+
+
 class _OpaqueMatrix(_ct.Structure):
     pass
 
@@ -115,6 +141,7 @@ def _bind(lib):
     add("mi_sparse_synchronize", [])
     add("mi_sparse_last_error", [], _ct.c_char_p)
     add("mi_sparse_set_option", [_ct.c_char_p, _i64])
+    add("mi_sparse_get_counter", [_ct.c_char_p, _ct.POINTER(_ct.c_double)])
     return table
 
 

@@ -312,8 +312,15 @@ inline void by_type(char vtype, F&& f)
 struct Options {
     int64_t spmm_chunk = 256;      // work items (nnz + row ends) per wave in the SpMM kernel
     int64_t spmm_force_generic = 0;
+    int64_t spmm_unroll = 4;       // 4 or 8 independent B-row loads in flight per lane
     int64_t spgemm_force_global = 0;
+    int64_t profile_events = 0;    // bracket the SpMM main kernel with hipEvents (diagnostics)
 };
+struct Counters {
+    double spmm_kernel_ms = 0.0;
+    double spmm_kernel_launches = 0.0;
+};
+Counters& counters();  // per host thread
 Options& options();
 
 }  // namespace mi

@@ -159,6 +159,12 @@ Options& options()
     return o;
 }
 
+Counters& counters()
+{
+    static thread_local Counters c;
+    return c;
+}
+
 // ---- exclusive scan ----------------------------------------------------------------------------
 // Three-kernel scan: per-block sums -> single-block scan of the sums -> add back.  n is at most a
 // few tens of millions (row counts), so this is never the bottleneck.
@@ -320,7 +326,12 @@ mi_sparse_status_t mi_sparse_set_device(int device)
 
 mi_sparse_status_t mi_sparse_set_stream(void* hip_stream)
 {
-    return mi::guarded([&] { mi::ctx().stream = static_cast<hipStream_t>(hip_stream); });
+    return mi::guarded([&] {
+        mi::Context& c = mi::ctx();
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        if (c.initialised && s != c.stream) c.sync();  // the scratch arena is ordered by ONE stream
+        c.stream = s;
+    });
 }
 
 mi_sparse_status_t mi_sparse_synchronize(void)
@@ -339,13 +350,35 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             if (value != 128 && value != 256 && value != 512 && value != 1024)
                 mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_chunk must be 128, 256, 512 or 1024");
             o.spmm_chunk = value;
+        } else if (!strcmp(name, "spmm_unroll")) {
+            if (value != 4 && value != 8) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_unroll must be 4 or 8");
+            o.spmm_unroll = value;
         } else if (!strcmp(name, "spmm_force_generic")) {
             o.spmm_force_generic = value;
         } else if (!strcmp(name, "spgemm_force_global")) {
             o.spgemm_force_global = value;
+        } else if (!strcmp(name, "profile_events")) {
+            o.profile_events = value;
         } else {
             mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown option '%s'", name);
         }
+    });
+}
+
+mi_sparse_status_t mi_sparse_get_counter(const char* name, double* value)
+{
+    return mi::guarded([&] {
+        if (!name) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "NULL counter name");
+        mi::Counters& k = mi::counters();
+        if (!strcmp(name, "reset")) {
+            k = mi::Counters();
+            if (value) *value = 0.0;
+            return;
+        }
+        if (!value) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL value pointer");
+        if (!strcmp(name, "spmm_kernel_ms")) *value = k.spmm_kernel_ms;
+        else if (!strcmp(name, "spmm_kernel_launches")) *value = k.spmm_kernel_launches;
+        else mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown counter '%s'", name);
     });
 }
 

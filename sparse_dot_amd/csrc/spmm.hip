@@ -52,11 +52,19 @@ __global__ void k_spmm_plan(const int64_t* ptr, int64_t rows, int64_t chunk, int
 
 constexpr int SPMM_WAVES = 4;  // waves per workgroup (independent of each other after staging)
 
+// one staged nonzero of A: column + value side by side so a lane group fetches both with ONE
+// LDS read (ds_read_b64 for float, ds_read_b128 for double / complex float)
+template <typename T>
+struct alignas(sizeof(T) >= 16 ? 16 : (sizeof(T) == 8 ? 8 : 8)) SpEntry {
+    int32_t c;
+    T v;
+};
+
 // LDS bytes one wave needs for a chunk of CH items
 template <typename T>
 __host__ __device__ constexpr size_t spmm_wave_lds(int ch)
 {
-    return (size_t)ch * (sizeof(int32_t) + sizeof(T)) + (size_t)(ch + 2) * sizeof(int32_t);
+    return (size_t)ch * sizeof(SpEntry<T>) + (size_t)(ch + 2) * sizeof(int32_t);
 }
 
 template <typename T, int V, int LPN, int U>
@@ -73,12 +81,11 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
     const int64_t w = (int64_t)blockIdx.x * SPMM_WAVES + wave_in_block;
     const bool active = w < nchunks;
 
-    // carve this wave's LDS: values first (largest alignment), then columns, then row ends
+    // carve this wave's LDS: staged nonzeros first (largest alignment), then the row ends
     const size_t per_wave = (spmm_wave_lds<T>(ch) + 15) & ~size_t(15);
     char* base = smem + per_wave * wave_in_block;
-    T* s_val = reinterpret_cast<T*>(base);
-    int32_t* s_col = reinterpret_cast<int32_t*>(base + sizeof(T) * (size_t)ch);
-    int32_t* s_end = s_col + ch;
+    SpEntry<T>* s_nz = reinterpret_cast<SpEntry<T>*>(base);
+    int32_t* s_end = reinterpret_cast<int32_t*>(base + sizeof(SpEntry<T>) * (size_t)ch);
 
     int64_t r0 = 0, r1 = 0, P0 = 0;
     int n_owned = 0, has_trail = 0;
@@ -110,9 +117,11 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
         }
         const int len = (int)(P1 - P0);
         for (int k = lane; k < len; k += WAVE) {
-            s_col[k] = col[P0 + k];
             const T a = val[P0 + k];
-            s_val[k] = conj_a ? vt<T>::conj(a) : a;
+            SpEntry<T> en;
+            en.c = col[P0 + k];
+            en.v = conj_a ? vt<T>::conj(a) : a;
+            s_nz[k] = en;
         }
     }
     __syncthreads();
@@ -120,45 +129,43 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
 
     const int g = lane / LPN;
     const int li = lane % LPN;
+    const int nproc = n_owned + has_trail;
 
     for (int64_t j0 = 0; j0 < N; j0 += (int64_t)LPN * V) {
         const int64_t jc = j0 + (int64_t)li * V;  // first column of this lane
         const bool col_ok = jc < N;               // V divides N on the vector path
-        const T* bcol = B + jc * b_cs;
+        // idle lanes (jc >= N) still issue loads, from column 0: keeps the loop free of divergence
+        const T* bcol = B + (col_ok ? jc : 0) * b_cs;
         int begin = 0;
-        const int nproc = n_owned + has_trail;
         for (int k = 0; k < nproc; ++k) {
             const int end = s_end[k];
             T acc[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[v] = vt<T>::zero();
             for (int p = begin + g; p < end; p += NG * U) {
+                SpEntry<T> nz[U];
                 vec<T, V> b[U];
-                T a[U];
                 bool ok[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int pp = p + u * NG;
                     ok[u] = pp < end;
-                    const int pc = ok[u] ? pp : end - 1;  // clamp: re-read a valid entry of this row
-                    a[u] = s_val[pc];
-                    const int64_t c = s_col[pc];
-                    if (col_ok) {
-                        if (V > 1) {
-                            b[u] = *reinterpret_cast<const vec<T, V>*>(bcol + c * b_rs);
-                        } else {
-                            b[u].v[0] = bcol[c * b_rs];
-                        }
-                    } else {
+                    nz[u] = s_nz[ok[u] ? pp : end - 1];  // clamp: re-read a valid entry of this row
+                }
 #pragma unroll
-                        for (int v = 0; v < V; ++v) b[u].v[v] = vt<T>::zero();
+                for (int u = 0; u < U; ++u) {
+                    const T* src = bcol + (int64_t)nz[u].c * b_rs;
+                    if (V > 1) {
+                        b[u] = *reinterpret_cast<const vec<T, V>*>(src);
+                    } else {
+                        b[u].v[0] = src[0];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (ok[u]) {
 #pragma unroll
-                        for (int v = 0; v < V; ++v) acc[v] = vt<T>::fma(a[u], b[u].v[v], acc[v]);
+                        for (int v = 0; v < V; ++v) acc[v] = vt<T>::fma(nz[u].v, b[u].v[v], acc[v]);
                     }
                 }
             }
@@ -251,12 +258,11 @@ static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, in
     return p;
 }
 
-template <typename T, int V, int LPN>
-static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
-                        int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val)
+template <typename T, int V, int LPN, int U>
+static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
+                          int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val)
 {
     Context& c = ctx();
-    constexpr int U = (V > 1) ? 4 : 4;
     const size_t per_wave = (spmm_wave_lds<T>(p.chunk) + 15) & ~size_t(15);
     const size_t lds = per_wave * SPMM_WAVES;
     const unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
@@ -265,6 +271,18 @@ static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B,
                    (const int64_t*)m.ptr, (const int32_t*)m.col, (const T*)m.val,
                    (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,
                    c_cs, N, alpha, beta, beta_zero, carry_row, carry_val);
+}
+
+template <typename T, int V, int LPN>
+static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
+                        int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val)
+{
+    // U = independent 16-byte loads in flight per lane.  The deeper variant exists for the 512-byte
+    // row shapes of the headline configs only (keeps the instantiation count down).
+    if (V > 1 && LPN >= 32 && options().spmm_unroll == 8)
+        launch_spmm_u<T, V, LPN, 8>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val);
+    else
+        launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val);
 }
 
 // Core executor on DEVICE pointers.  m is the CSR of op(A) (rows of m = rows of C).
@@ -286,6 +304,15 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
                         ((reinterpret_cast<uintptr_t>(B) % 16) == 0) && ((reinterpret_cast<uintptr_t>(C) % 16) == 0) &&
                         ((reinterpret_cast<uintptr_t>(carry_val) % 16) == 0);
 #define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val
+#ifndef MI_HIP_EMU
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const bool prof = options().profile_events != 0;
+    if (prof) {
+        MI_HIP_CHECK(hipEventCreate(&ev0));
+        MI_HIP_CHECK(hipEventCreate(&ev1));
+        MI_HIP_CHECK(hipEventRecord(ev0, c.stream));
+    }
+#endif
     if (vec_ok) {
         const int64_t lanes = N / V16;  // 16-byte lanes needed for one row of B
         if (lanes >= 64) launch_spmm<T, V16, 64>(MI_SPMM_ARGS);
@@ -298,6 +325,18 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         else launch_spmm<T, 1, 4>(MI_SPMM_ARGS);
     }
 #undef MI_SPMM_ARGS
+#ifndef MI_HIP_EMU
+    if (prof) {
+        MI_HIP_CHECK(hipEventRecord(ev1, c.stream));
+        MI_HIP_CHECK(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        MI_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        counters().spmm_kernel_ms += ms;
+        counters().spmm_kernel_launches += 1.0;
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+    }
+#endif
     MI_LAUNCH((k_spmm_fixup<T>), dim3((unsigned)ceil_div(p.nchunks * WAVE, 256)), dim3(256), c.stream, p.nchunks,
               (const int32_t*)carry_row, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
 }

@@ -1,0 +1,471 @@
+"""GPU: parity of the HIP path against the CPU oracle on seeded inputs that stress the kernels'
+code paths (lane-group widths, chunk boundaries, hub rows, empty rows, hash-table bins, the
+global-memory hash fallback, 64-bit indices, device pointers), plus size-independent properties
+at the BASELINE config-2 scale."""
+import ctypes as ct
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5   # north_star: fp32 within 1e-5 rel
+F64_TOL = 1e-12  # north_star: fp64 within 1e-12 rel
+
+
+def rel_err(got, want):
+    """max |got - want| / (|A| |B|-style scale): elementwise relative to the magnitude of the exact
+    result computed in float64 with positive data (no cancellation), floor 1e-30."""
+    want = np.asarray(want, dtype=np.complex128 if np.iscomplexobj(want) else np.float64)
+    return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-30))) if want.size else 0.0
+
+
+def pos_csr(m, n, density, dtype, seed, fmt="csr"):
+    a = sps.random(m, n, density=density, format="csr", dtype=np.float64, random_state=seed)
+    rng = np.random.default_rng(seed + 1000)
+    a.data[:] = rng.uniform(0.5, 1.5, a.nnz)
+    if np.dtype(dtype).kind == "c":
+        a = a.astype(dtype)
+        a.data += 1j * rng.uniform(0.5, 1.5, a.nnz)
+    return a.astype(dtype).asformat(fmt)
+
+
+def dense(shape, dtype, seed, order="C"):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0.5, 1.5, shape)
+    if np.dtype(dtype).kind == "c":
+        x = x + 1j * rng.uniform(0.5, 1.5, shape)
+    return np.asarray(x.astype(dtype), order=order)
+
+
+def tol(dtype):
+    return F32_TOL if np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64)) else F64_TOL
+
+
+# ---- SpMM -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
+@pytest.mark.parametrize("n", [1, 3, 4, 8, 17, 32, 64, 96, 128, 200, 256, 260, 512, 1000])
+def test_spmm_widths(gpu, oracle, dtype, n):
+    """Every lane-group width of the vector path and the scalar path (N not a multiple of 16 B)."""
+    a = pos_csr(700, 500, 0.03, dtype, 1)
+    b = dense((500, n), dtype, 2)
+    got = gpu.dot_product_mkl(a, b) if n > 1 else gpu.dot_product_mkl(a, b.reshape(500, 1).copy())
+    want = oracle.spmm(a.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64),
+                       b.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64))
+    assert got.dtype == dtype and got.shape == (700, n)
+    assert rel_err(got, want) <= tol(dtype)
+
+
+@pytest.mark.parametrize("chunk", [128, 256, 512, 1024])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spmm_skewed_rows_and_chunks(gpu, oracle, dtype, chunk):
+    """Hub rows spanning many chunks, runs of empty rows (also leading / trailing), 1-nnz rows."""
+    rng = np.random.default_rng(7)
+    lens = rng.integers(0, 40, 3000)
+    lens[:50] = 0
+    lens[-70:] = 0
+    lens[100] = 5000   # spans ~20 chunks of 256
+    lens[101] = 1
+    lens[1500:1600] = 0
+    lens[2000] = 1300
+    ncols = 6000
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(ncols, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.uniform(0.5, 1.5, indices.size).astype(dtype)
+    a = sps.csr_matrix((data, indices, indptr), shape=(3000, ncols))
+    b = dense((ncols, 128 if dtype == np.float32 else 64), dtype, 3)
+    gpu.mi_set_option("spmm_chunk", chunk)
+    try:
+        got = gpu.dot_product_mkl(a, b)
+        out = np.full_like(got, 2.0)
+        got2 = gpu.dot_product_mkl(a, b, out=out, out_scalar=-1.5)
+    finally:
+        gpu.mi_set_option("spmm_chunk", 256)
+    want = oracle.spmm(a.astype(np.float64), b.astype(np.float64))
+    assert rel_err(got, want) <= tol(dtype)
+    assert got2 is out
+    np.testing.assert_allclose(got2, want - 3.0, rtol=10 * tol(dtype), atol=10 * tol(dtype))
+    # empty rows are written (zeros), not skipped
+    assert not got[:50].any() and not got[-70:].any()
+
+
+def test_spmm_determinism(gpu):
+    a = pos_csr(4000, 3000, 0.02, np.float32, 5)
+    b = dense((3000, 128), np.float32, 6)
+    r1 = gpu.dot_product_mkl(a, b)
+    r2 = gpu.dot_product_mkl(a, b)
+    assert np.array_equal(r1, r2)  # no atomics in the SpMM path: bitwise reproducible
+
+
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("fmt", ["csr", "csc", "bsr"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex128])
+def test_spmm_both_sides_layouts_formats(gpu, oracle, dtype, fmt, order):
+    a = pos_csr(120, 90, 0.1, dtype, 11)
+    a_f = a.asformat(fmt) if fmt != "bsr" else a.tobsr(blocksize=(10, 10))
+    b = dense((90, 33), dtype, 12, order)
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    want = a.astype(wide).toarray() @ b.astype(wide)
+    got = gpu.dot_product_mkl(a_f, b)
+    assert got.flags["C_CONTIGUOUS" if order == "C" else "F_CONTIGUOUS"]
+    assert rel_err(got, want) <= tol(dtype)
+    # dense on the left
+    d = dense((33, 120), dtype, 13, order)
+    want = d.astype(wide) @ a.astype(wide).toarray()
+    got = gpu.dot_product_mkl(d, a_f)
+    assert got.shape == (33, 90) and rel_err(got, want) <= tol(dtype)
+    out = np.asarray(np.ones((33, 90), dtype=dtype), order=order)
+    got = gpu.dot_product_mkl(d, a_f, out=out, out_scalar=2.0)
+    assert got is out and rel_err(got, want + 2.0) <= 4 * tol(dtype)
+
+
+def test_spmm_int64_indices_and_unmodified_input(gpu, oracle):
+    a = pos_csr(300, 200, 0.05, np.float64, 21)
+    a64 = a.copy()
+    a64.indices = a64.indices.astype(np.int64)  # (the scipy constructor would narrow them again)
+    a64.indptr = a64.indptr.astype(np.int64)
+    b = dense((200, 16), np.float64, 22)
+    got = gpu.dot_product_mkl(a64, b)
+    assert a64.indices.dtype == np.int64 and a64.indptr.dtype == np.int64  # not cast in place
+    assert rel_err(got, oracle.spmm(a, b)) <= F64_TOL
+
+
+def test_spmv_shapes(gpu, oracle):
+    a = pos_csr(150, 80, 0.1, np.float64, 31)
+    v = dense((80,), np.float64, 32)
+    want = a.toarray() @ v
+    r = gpu.dot_product_mkl(a, v)
+    assert r.shape == (150,) and rel_err(r, want) <= F64_TOL
+    r = gpu.dot_product_mkl(a, v.reshape(80, 1))
+    assert r.shape == (150, 1) and rel_err(r[:, 0], want) <= F64_TOL
+    u = dense((150,), np.float64, 33)
+    r = gpu.dot_product_mkl(u, a)
+    assert r.shape == (80,) and rel_err(r, u @ a.toarray()) <= F64_TOL
+    r = gpu.dot_product_mkl(u.reshape(1, 150), a)
+    assert r.shape == (1, 80) and rel_err(r[0], u @ a.toarray()) <= F64_TOL
+    out = np.ones(150)
+    r = gpu.dot_product_mkl(a, v, out=out, out_scalar=3.0)
+    assert r is out and rel_err(r, want + 3.0) <= 4 * F64_TOL
+
+
+def test_c_abi_with_device_pointers(gpu, oracle):
+    """HBM-resident operands: device pointers (torch) straight into the C ABI, zero copy."""
+    torch = pytest.importorskip("torch")
+    from sparse_dot_amd._mi_interface import MI, matrix_descr, sparse_matrix_t, _check_return_value
+    a = pos_csr(500, 400, 0.04, np.float32, 41)
+    b = dense((400, 128), np.float32, 42)
+    dev = torch.device("cuda", 0)
+    t_ptr = torch.from_numpy(a.indptr.astype(np.int32)).to(dev)
+    t_idx = torch.from_numpy(a.indices.astype(np.int32)).to(dev)
+    t_val = torch.from_numpy(a.data).to(dev)
+    t_b = torch.from_numpy(b).to(dev)
+    t_c = torch.full((500, 128), 5.0, device=dev, dtype=torch.float32)
+    gpu.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        h = sparse_matrix_t()
+        _check_return_value(MI.call("mi_sparse_s_create_csr", ct.byref(h), 0, 500, 400, t_ptr.data_ptr(),
+                                    t_ptr.data_ptr() + 4, t_idx.data_ptr(), t_val.data_ptr()), "create")
+        _check_return_value(MI.call("mi_sparse_s_mm", 10, 2.0, h, matrix_descr(), 101, t_b.data_ptr(), 128, 128,
+                                    0.5, t_c.data_ptr(), 128), "mm")
+        torch.cuda.synchronize()
+        got = t_c.cpu().numpy()
+        _check_return_value(MI.call("mi_sparse_destroy", h), "destroy")
+    finally:
+        gpu.mi_set_stream(0)
+    want = 2.0 * oracle.spmm(a.astype(np.float64), b.astype(np.float64)) + 2.5
+    assert rel_err(got, want) <= F32_TOL
+
+
+def test_c_abi_status_codes(gpu):
+    from sparse_dot_amd._mi_interface import MI, matrix_descr, sparse_matrix_t
+    null = sparse_matrix_t()
+    assert MI.call("mi_sparse_destroy", null) == 1                      # NOT_INITIALIZED
+    assert MI.call("mi_sparse_order", null) == 1
+    out = sparse_matrix_t()
+    assert MI.call("mi_sparse_spmm", 10, null, null, ct.byref(out)) == 1
+    a = pos_csr(10, 7, 0.5, np.float64, 1)
+    b = pos_csr(9, 4, 0.5, np.float64, 2)  # inner dimensions disagree
+    from sparse_dot_amd._mi_interface import SparseHandle
+    with SparseHandle.from_scipy(a) as ha, SparseHandle.from_scipy(b) as hb:
+        assert MI.call("mi_sparse_spmm", 10, ha.ptr, hb.ptr, ct.byref(out)) == 3   # INVALID_VALUE
+        c = np.zeros((10, 3))
+        x = np.zeros((7, 3))
+        assert MI.call("mi_sparse_d_mm", 99, 1.0, ha.ptr, matrix_descr(), 101, x.ctypes.data, 3, 3, 0.0,
+                       c.ctypes.data, 3) == 3
+        assert MI.call("mi_sparse_s_mm", 10, 1.0, ha.ptr, matrix_descr(), 101, x.ctypes.data, 3, 3, 0.0,
+                       c.ctypes.data, 3) == 3    # value type mismatch
+        assert "value" in MI.last_error()
+
+
+# ---- handles: create -> export round trips -----------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_create_export_roundtrip(gpu, dtype, fmt):
+    from sparse_dot_amd._mi_interface import _create_mi_sparse, _export_mi, _destroy_mi_handle, _convert_to_csr
+    a = pos_csr(60, 45, 0.15, dtype, 51, fmt)
+    h, dbl, cplx = _create_mi_sparse(a)
+    back = _export_mi(h, dbl, cplx, fmt + "_matrix")
+    assert back.format == fmt and np.array_equal(back.toarray(), a.toarray())
+    assert np.array_equal(back.indptr, a.indptr) and np.array_equal(back.indices, a.indices)
+    other = "csc" if fmt == "csr" else "csr"
+    conv = _export_mi(h, dbl, cplx, other + "_array")
+    assert conv.format == other and np.array_equal(conv.toarray(), a.toarray()) and conv.has_canonical_format
+    c = _convert_to_csr(h)
+    as_csr = _export_mi(c, dbl, cplx, "csr_matrix")
+    assert np.array_equal(as_csr.toarray(), a.toarray())
+    _destroy_mi_handle(c)
+    _destroy_mi_handle(h)
+    with pytest.raises(ValueError):
+        _destroy_mi_handle(h)  # double destroy is an error, not a crash
+
+
+def test_bsr_handle_and_order(gpu):
+    from sparse_dot_amd._mi_interface import SparseHandle
+    a = pos_csr(40, 60, 0.2, np.float64, 61).tobsr(blocksize=(4, 4))
+    with SparseHandle.from_scipy(a) as h:
+        assert np.array_equal(h.export("csr_matrix").toarray(), a.toarray())
+    # order: shuffled rows (with a duplicate) come back sorted, values follow, caller arrays re-ordered
+    rng = np.random.default_rng(0)
+    b = pos_csr(500, 9000, 0.05, np.float32, 62)   # rows of ~450 entries, some > 512 -> block tier
+    sh = b.copy()
+    for i in range(b.shape[0]):
+        lo, hi = b.indptr[i], b.indptr[i + 1]
+        p = rng.permutation(hi - lo)
+        sh.indices[lo:hi] = b.indices[lo:hi][p]
+        sh.data[lo:hi] = b.data[lo:hi][p]
+    with SparseHandle.from_scipy(sh) as h:
+        h.order()
+        out = h.export("csr_matrix")
+    assert np.array_equal(out.indices, b.indices) and np.array_equal(out.data, b.data)
+    assert np.array_equal(sh.indices, b.indices) and np.array_equal(sh.data, b.data)  # MKL-style in-place order
+
+
+def test_order_huge_row_global_tier(gpu):
+    """A row longer than the LDS sort tiers (8192) goes through the global-memory bitonic sort."""
+    from sparse_dot_amd._mi_interface import SparseHandle
+    rng = np.random.default_rng(3)
+    n = 20000
+    cols0 = rng.permutation(50000)[:n].astype(np.int32)
+    vals0 = rng.uniform(0.5, 1.5, n)
+    small = pos_csr(30, 50000, 0.001, np.float64, 63)
+    a = sps.vstack([sps.csr_matrix((vals0, cols0, [0, n]), shape=(1, 50000)), small]).tocsr()
+    a_unsorted = sps.csr_matrix((np.concatenate([vals0, small.data]), np.concatenate([cols0, small.indices]),
+                                 np.concatenate([[0], small.indptr + n])), shape=a.shape)
+    with SparseHandle.from_scipy(a_unsorted) as h:
+        h.order()
+        out = h.export("csr_matrix")
+    ref = a_unsorted.copy()
+    ref.sort_indices()
+    assert np.array_equal(out.indices, ref.indices) and np.array_equal(out.data, ref.data)
+
+
+# ---- SpGEMM -----------------------------------------------------------------------------------------
+def _check_spgemm(got, want, dtype):
+    g = got.tocsr().copy()
+    g.sort_indices()
+    assert np.array_equal(g.indptr, want.indptr), "indptr"
+    assert np.array_equal(g.indices, want.indices), "indices"
+    assert rel_err(g.data, want.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64).data) <= tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
+def test_spgemm_all_bins(gpu, oracle, dtype):
+    """Rows whose product count falls in every LDS bin (<=32, <=256, <=2048) and beyond (global hash)."""
+    rng = np.random.default_rng(71)
+    k, n = 3000, 5000
+    b = pos_csr(k, n, 0.004, dtype, 72)          # ~20 nnz per row of B
+    lens = np.concatenate([rng.integers(0, 2, 300), rng.integers(2, 12, 300), rng.integers(20, 90, 100),
+                           [400, 900, 1500], rng.integers(0, 3, 50)])
+    m = lens.size
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.uniform(0.5, 1.5, indices.size).astype(dtype)
+    a = sps.csr_matrix((data, indices, indptr), shape=(m, k))
+    want = oracle.spgemm(a, b)
+    got = gpu.dot_product_mkl(a, b)
+    assert isinstance(got, sps.csr_matrix) and got.dtype == dtype and got.shape == (m, n)
+    _check_spgemm(got, want, dtype)
+    got = gpu.dot_product_mkl(a, b, reorder_output=True)
+    assert np.array_equal(got.indices, want.indices)  # already ordered
+    # the global-memory hash path on the same problem
+    gpu.mi_set_option("spgemm_force_global", 1)
+    try:
+        got = gpu.dot_product_mkl(a, b)
+    finally:
+        gpu.mi_set_option("spgemm_force_global", 0)
+    _check_spgemm(got, want, dtype)
+
+
+def test_spgemm_keeps_cancelled_entries_and_sums_duplicates(gpu):
+    a = sps.csr_matrix(np.array([[1.0, -1.0, 0.0], [0.0, 2.0, 0.0]]))
+    b = sps.csr_matrix(np.array([[1.0, 0.0], [1.0, 0.0], [0.0, 3.0]]))
+    c = gpu.dot_product_mkl(a, b, reorder_output=True)
+    assert c.nnz == 2 and c[0, 0] == 0.0 and (0 in c.indices[c.indptr[0]:c.indptr[1]])  # explicit zero kept (MKL)
+    ua = sps.csr_matrix((np.array([1.0, 2.0, 3.0, 4.0, 5.0]), np.array([2, 0, 2, 1, 0]), np.array([0, 3, 5])), shape=(2, 3))
+    ub = sps.csr_matrix((np.array([1.0, 2.0, 3.0, 4.0]), np.array([1, 0, 1, 1]), np.array([0, 2, 3, 4])), shape=(3, 2))
+    c = gpu.dot_product_mkl(ua, ub)
+    np.testing.assert_allclose(c.toarray(), ua.toarray() @ ub.toarray(), rtol=1e-14)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spgemm_dense_output_and_formats(gpu, oracle, dtype):
+    a = pos_csr(130, 170, 0.05, dtype, 81)
+    b = pos_csr(170, 90, 0.05, dtype, 82)
+    want = oracle.spgemm(a, b)
+    d = gpu.dot_product_mkl(a, b, dense=True)
+    assert isinstance(d, np.ndarray) and d.flags.c_contiguous
+    np.testing.assert_allclose(d, want.toarray(), rtol=tol(dtype), atol=tol(dtype))
+    out = np.full((130, 90), 9.0, dtype=dtype)
+    assert gpu.dot_product_mkl(a, b, dense=True, out=out) is out
+    np.testing.assert_allclose(out, want.toarray(), rtol=tol(dtype), atol=tol(dtype))  # overwritten, not added
+    for fa, fb, cls in (("csc", "csc", sps.csc_matrix), ("csr", "csc", sps.csr_matrix), ("csc", "csr", sps.csc_matrix)):
+        r = gpu.dot_product_mkl(a.asformat(fa), b.asformat(fb))
+        assert isinstance(r, cls)
+        np.testing.assert_allclose(r.toarray(), want.toarray(), rtol=tol(dtype), atol=tol(dtype))
+    r = gpu.dot_product_mkl(sps.csr_array(a), sps.csr_array(b))
+    assert isinstance(r, sps.csr_array)
+    ab, bb = a.tobsr(blocksize=(10, 10)), b.tobsr(blocksize=(10, 10))
+    r = gpu.dot_product_mkl(ab, bb)
+    assert r.format == "bsr" and r.blocksize == (10, 10)
+    np.testing.assert_allclose(r.toarray(), want.toarray(), rtol=tol(dtype), atol=tol(dtype))
+
+
+def test_spgemm_low_density_and_full_density(gpu, oracle):
+    for m, k, n, d in ((2000, 3000, 1000, 5e-4), (2000, 3000, 1000, 5e-6), (10, 50, 20, 1.0)):
+        a = pos_csr(m, k, d, np.float64, 91)
+        b = pos_csr(k, n, d, np.float64, 92)
+        got = gpu.dot_product_mkl(a, b)
+        if a.nnz == 0 or b.nnz == 0:
+            assert got.nnz == 0 and got.shape == (m, n)
+            continue
+        _check_spgemm(got, oracle.spgemm(a, b), np.float64)
+
+
+# ---- gram ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_gram_paths(gpu, oracle, dtype, transpose):
+    a = pos_csr(400, 150, 0.05, dtype, 101)
+    ad = a.astype(np.float64).toarray()
+    full = ad @ ad.T if transpose else ad.T @ ad
+    want = np.triu(full)
+    t = 10 * tol(dtype) if dtype == np.float32 else tol(dtype)  # reference tests use decimal=5 for fp32 gram
+    s = gpu.gram_matrix_mkl(a, transpose=transpose)
+    assert isinstance(s, sps.csr_matrix)
+    np.testing.assert_allclose(s.toarray(), want, rtol=t, atol=t)
+    so = oracle.syrk_sparse(a, aat=transpose)
+    g = s.copy()
+    g.sort_indices()
+    assert np.array_equal(g.indptr, so.indptr) and np.array_equal(g.indices, so.indices)
+    assert _rows_sorted(gpu.gram_matrix_mkl(a, transpose=transpose, reorder_output=True))
+    d = gpu.gram_matrix_mkl(a, transpose=transpose, dense=True)
+    np.testing.assert_allclose(d, want, rtol=t, atol=t)            # strict lower triangle is zero
+    out = np.ones_like(d)
+    r = gpu.gram_matrix_mkl(a, transpose=transpose, dense=True, out=out, out_scalar=2.0)
+    assert r is out
+    iu = np.triu_indices(out.shape[0])
+    np.testing.assert_allclose(out[iu], (want + 2.0)[iu], rtol=t, atol=t)
+    assert (np.tril(out, -1) == np.tril(np.ones_like(out), -1)).all()  # lower triangle untouched
+    for order in ("C", "F"):
+        dd = gpu.gram_matrix_mkl(np.asarray(a.toarray(), order=order), transpose=transpose)
+        iu = np.triu_indices(dd.shape[0])
+        np.testing.assert_allclose(dd[iu], want[iu], rtol=t, atol=t)
+    c = gpu.gram_matrix_mkl(a.tocsc(), transpose=transpose, cast=True, dense=True)
+    np.testing.assert_allclose(c, want, rtol=t, atol=t)
+
+
+def _rows_sorted(m):
+    return all(np.all(np.diff(m.indices[m.indptr[i]:m.indptr[i + 1]]) > 0) for i in range(m.shape[0]))
+
+
+# ---- dense fallback (MFMA) -------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (5, 7, 3), (64, 64, 64), (65, 130, 33), (200, 17, 300)])
+def test_dense_gemm(gpu, dtype, shape):
+    m, k, n = shape
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    for oa in ("C", "F"):
+        for ob in ("C", "F"):
+            a, b = dense((m, k), dtype, 111, oa), dense((k, n), dtype, 112, ob)
+            got = gpu.dot_product_mkl(a, b)
+            want = a.astype(wide) @ b.astype(wide)
+            assert got.dtype == dtype and got.flags["C_CONTIGUOUS" if oa == "C" else "F_CONTIGUOUS"]
+            assert rel_err(got, want) <= tol(dtype) * 4
+    a, b = dense((m, k), dtype, 113), dense((k, n), dtype, 114)
+    out = np.ones((m, n), dtype=dtype)
+    got = gpu.dot_product_mkl(a, b, out=out, out_scalar=3.0)
+    assert got is out and rel_err(got, a.astype(wide) @ b.astype(wide) + 3.0) <= tol(dtype) * 4
+
+
+def test_dense_gemm_is_transpose_detecting(gpu):
+    """Asymmetric operands: A = I must return B exactly (catches swapped MFMA row/col maps)."""
+    for dtype in (np.float32, np.float64):
+        b = np.arange(70 * 90, dtype=dtype).reshape(70, 90)
+        got = gpu.dot_product_mkl(np.eye(70, dtype=dtype), b)
+        assert np.array_equal(got, b)
+
+
+# ---- properties at BASELINE config-2 scale ------------------------------------------------------------------
+def test_config2_scale_properties(gpu):
+    """R-MAT 2^20 x 2^20 (~31 M nnz) x dense 2^20 x 128 fp32, all device resident:
+    (1) A @ ones = row sums of A;  (2) linearity A(B1 + B2) = A B1 + A B2;  (3) a row sample equals
+    an fp64 evaluation.  Size-independent checks -- the oracle would take minutes here."""
+    torch = pytest.importorskip("torch")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    from sparse_dot_amd._mi_interface import MI, matrix_descr, sparse_matrix_t, _check_return_value
+    dev = torch.device("cuda", 0)
+    indptr, indices, vals, n = bench.rmat_csr(torch, 20, 32, 7, dev)
+    nnz = indices.numel()
+    assert 30_000_000 < nnz < 33_000_000
+    N = 128
+    gpu.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+    h = sparse_matrix_t()
+    try:
+        _check_return_value(MI.call("mi_sparse_s_create_csr", ct.byref(h), 0, n, n, indptr.data_ptr(),
+                                    indptr.data_ptr() + 4, indices.data_ptr(), vals.data_ptr()), "create")
+
+        def mm(b, c, alpha=1.0, beta=0.0):
+            _check_return_value(MI.call("mi_sparse_s_mm", 10, alpha, h, matrix_descr(), 101, b.data_ptr(), N, N, beta,
+                                        c.data_ptr(), N), "mm")
+        ones = torch.ones((n, N), device=dev)
+        c1 = torch.empty((n, N), device=dev)
+        mm(ones, c1)
+        torch.cuda.synchronize()
+        ip = indptr.to(torch.int64)
+        rowsum = torch.zeros(n, device=dev, dtype=torch.float64)
+        rowsum.index_add_(0, torch.repeat_interleave(torch.arange(n, device=dev), ip[1:] - ip[:-1]), vals.double())
+        err = ((c1[:, 0].double() - rowsum).abs() / rowsum.clamp(min=1e-30))[rowsum > 0].max().item()
+        assert err <= F32_TOL, err
+        assert (c1[rowsum == 0] == 0).all()          # empty rows are zero
+        assert torch.equal(c1[:, :1].expand(-1, N), c1)  # every column identical
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        b1 = torch.rand((n, N), generator=g, device=dev) + 0.5
+        b2 = torch.rand((n, N), generator=g, device=dev) + 0.5
+        r1, r2, r12 = (torch.empty((n, N), device=dev) for _ in range(3))
+        mm(b1, r1)
+        mm(b2, r2)
+        mm(b1 + b2, r12)
+        torch.cuda.synchronize()
+        lin = ((r12 - (r1 + r2)).abs() / r12.abs().clamp(min=1e-30)).max().item()
+        assert lin <= 4 * F32_TOL, lin
+        # beta path: C := A b1 + 1.0 * C(=r2)  == r1 + r2
+        acc = r2.clone()
+        mm(b1, acc, 1.0, 1.0)
+        torch.cuda.synchronize()
+        assert ((acc - (r1 + r2)).abs() / acc.abs().clamp(min=1e-30)).max().item() <= 4 * F32_TOL
+        sel = torch.cat([torch.argmax(ip[1:] - ip[:-1]).reshape(1), torch.randint(0, n, (40,), device=dev)])
+        for r in sel.tolist():
+            lo, hi = int(ip[r]), int(ip[r + 1])
+            if hi == lo:
+                continue
+            want = (vals[lo:hi].double()[:, None] * b1[indices[lo:hi].long()].double()).sum(0)
+            assert ((r1[r].double() - want).abs() / want.abs()).max().item() <= F32_TOL
+    finally:
+        if h:
+            MI.call("mi_sparse_destroy", h)
+        gpu.mi_set_stream(0)
