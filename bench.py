@@ -156,14 +156,44 @@ def main():
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo": dry run of the N > 1 control flow on one GPU
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
-    sda.mi_set_device(local_rank)
+    def bcast(t, src=0):
+        if backend == "nccl":
+            dist.broadcast(t, src=src)
+        else:  # gloo dry run: stage through the host
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
+
+    def allreduce(t, op):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        return h.to(t.device)
+
+    def allgather_rows(dst, src_block):
+        if backend == "nccl":
+            dist.all_gather_into_tensor(dst, src_block)
+        else:
+            parts = [torch.empty_like(src_block, device="cpu") for _ in range(world)]
+            dist.all_gather(parts, src_block.cpu())
+            dst.copy_(torch.cat(parts, 0))
+
+    sda.mi_set_device(dev_index)
     stream = torch.cuda.current_stream()
     sda.mi_set_stream(stream.cuda_stream)
     if args.chunk:
@@ -182,7 +212,7 @@ def main():
     gb.manual_seed(9)
     B = torch.rand((n, N), generator=gb, device=dev, dtype=torch.float32)
     if world > 1:
-        dist.broadcast(B, src=0)  # replicate B (set-up; cost reported under "collectives")
+        bcast(B)  # replicate B (set-up; cost reported under "collectives")
     C = torch.empty((n, N), device=dev, dtype=torch.float32)
     torch.cuda.synchronize()
 
@@ -214,11 +244,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = allreduce(torch.tensor([elapsed], device=dev, dtype=torch.float64), dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tn = torch.tensor([float(nnz)], device=dev, dtype=torch.float64)
-        dist.all_reduce(tn, op=dist.ReduceOp.SUM)
+        tn = allreduce(torch.tensor([float(nnz)], device=dev, dtype=torch.float64), dist.ReduceOp.SUM)
         total_nnz = float(tn.item())
     else:
         total_nnz = float(nnz)
@@ -260,8 +288,9 @@ def main():
             return (time.perf_counter() - t1) / reps * 1e3
         gathered = torch.empty((world * n, N), device=dev, dtype=torch.float32)
         collectives = {
-            "broadcast_B_ms": round(timed(lambda: dist.broadcast(B, src=0)), 3),
-            "allgather_C_ms": round(timed(lambda: dist.all_gather_into_tensor(gathered, C)), 3),
+            "broadcast_B_ms": round(timed(lambda: bcast(B)), 3),
+            "allgather_C_ms": round(timed(lambda: allgather_rows(gathered, C)), 3),
+            "backend": backend,
             "note": "RCCL over xGMI; not part of the timed step (weak scaling, outputs stay row-distributed)",
         }
         del gathered

@@ -67,8 +67,11 @@ __host__ __device__ constexpr size_t spmm_wave_lds(int ch)
     return (size_t)ch * sizeof(SpEntry<T>) + (size_t)(ch + 2) * sizeof(int32_t);
 }
 
+#ifndef MI_SPMM_MIN_WAVES
+#define MI_SPMM_MIN_WAVES 8
+#endif
 template <typename T, int V, int LPN, int U>
-__global__ void __launch_bounds__(SPMM_WAVES* WAVE)
+__global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ? MI_SPMM_MIN_WAVES : 1)
     k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
            const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
            const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
@@ -218,26 +221,80 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
 }
 
 // add the carries of every cut row to the row its owner wrote; carries of one row are contiguous
-// chunks, summed in chunk order by the wave of the first one
-template <typename T>
+// chunks, summed in chunk order by the lane group of the first one.  LPN lanes x V values per
+// chunk (same shapes as the main kernel), so one 16-byte load + one 16-byte read-modify-write of
+// C per lane in the common single-carry case.
+template <typename T, int V, int LPN>
 __global__ void __launch_bounds__(256)
     k_spmm_fixup(int64_t nchunks, const int32_t* __restrict__ carry_row, const T* __restrict__ carry_val, int64_t N,
                  T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha)
 {
-    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x % WAVE;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t w = t / LPN;
+    const int li = (int)(t % LPN);
     if (w >= nchunks) return;
     const int32_t row = carry_row[w];
-    if (row < 0) return;
-    if (w > 0 && carry_row[w - 1] == row) return;  // not the head of this row's run
+    const int32_t prev = (w > 0) ? carry_row[w - 1] : -1;
+    if (row < 0 || prev == row) return;  // no carry, or not the head of this row's run
     int64_t last = w;
     while (last + 1 < nchunks && carry_row[last + 1] == row) ++last;
-    for (int64_t j = lane; j < N; j += WAVE) {
-        T sum = vt<T>::zero();
-        for (int64_t u = w; u <= last; ++u) sum = vt<T>::add(sum, carry_val[u * N + j]);
-        T* c = C + (int64_t)row * c_rs + j * c_cs;
-        *c = vt<T>::fma(alpha, sum, *c);
+    for (int64_t jc = (int64_t)li * V; jc < N; jc += (int64_t)LPN * V) {
+        T sum[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) sum[v] = vt<T>::zero();
+        for (int64_t u = w; u <= last; ++u) {
+            vec<T, V> cvv;
+            if (V > 1) cvv = *reinterpret_cast<const vec<T, V>*>(carry_val + u * N + jc);
+            else cvv.v[0] = carry_val[u * N + jc];
+#pragma unroll
+            for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], cvv.v[v]);
+        }
+        T* c = C + (int64_t)row * c_rs + jc * c_cs;
+        if (V > 1) {
+            vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(c);
+#pragma unroll
+            for (int v = 0; v < V; ++v) old.v[v] = vt<T>::fma(alpha, sum[v], old.v[v]);
+            *reinterpret_cast<vec<T, V>*>(c) = old;
+        } else {
+            *c = vt<T>::fma(alpha, sum[0], *c);
+        }
     }
+}
+
+// dense layout conversion through a 32 x 32 LDS tile: element (i, j) moves from
+// src[i * s_rs + j * s_cs] to dst[i * d_rs + j * d_cs]; reads and writes are both coalesced along
+// whichever index is contiguous on that side.  Used to run column-major operands through the
+// row-major (fully coalesced) SpMM kernel.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_convert_layout(int64_t rows, int64_t cols, const T* __restrict__ src, int64_t s_rs, int64_t s_cs,
+                     T* __restrict__ dst, int64_t d_rs, int64_t d_cs)
+{
+    __shared__ T tile[32][33];  // [j local][i local]
+    const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;  // 32 x 8
+    const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+    for (int k = 0; k < 4; ++k) {
+        const int a = tx, b = ty + 8 * k;
+        const int il = (s_rs == 1) ? a : b, jl = (s_rs == 1) ? b : a;
+        const int64_t i = i0 + il, j = j0 + jl;
+        if (i < rows && j < cols) tile[jl][il] = src[i * s_rs + j * s_cs];
+    }
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const int a = tx, b = ty + 8 * k;
+        const int jl = (d_cs == 1) ? a : b, il = (d_cs == 1) ? b : a;
+        const int64_t i = i0 + il, j = j0 + jl;
+        if (i < rows && j < cols) dst[i * d_rs + j * d_cs] = tile[jl][il];
+    }
+}
+
+template <typename T>
+static void convert_layout(int64_t rows, int64_t cols, const T* src, int64_t s_rs, int64_t s_cs, T* dst, int64_t d_rs,
+                           int64_t d_cs)
+{
+    if (rows == 0 || cols == 0) return;
+    MI_LAUNCH((k_convert_layout<T>), dim3((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32)), dim3(256),
+              ctx().stream, rows, cols, src, s_rs, s_cs, dst, d_rs, d_cs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -279,10 +336,14 @@ static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B,
 {
     // U = independent 16-byte loads in flight per lane.  The deeper variant exists for the 512-byte
     // row shapes of the headline configs only (keeps the instantiation count down).
-    if (V > 1 && LPN >= 32 && options().spmm_unroll == 8)
-        launch_spmm_u<T, V, LPN, 8>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val);
-    else
-        launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val);
+    if constexpr (V > 1 && LPN >= 32) {
+        if (options().spmm_unroll == 8) {
+            launch_spmm_u<T, V, LPN, 8>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row,
+                                        carry_val);
+            return;
+        }
+    }
+    launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val);
 }
 
 // Core executor on DEVICE pointers.  m is the CSR of op(A) (rows of m = rows of C).
@@ -292,6 +353,21 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
 {
     Context& c = ctx();
     if (m.rows == 0 || N == 0) return;
+    if (layout == MI_SPARSE_LAYOUT_COLUMN_MAJOR && N > 1 && !options().spmm_force_generic) {
+        // Column-major operands: a gather of B "rows" would touch one element per cache line.
+        // Re-lay B (and C when beta != 0) as row-major scratch copies with a 16-byte-aligned
+        // leading dimension, run the coalesced kernel, and write C back column-major: two extra
+        // streaming passes over the dense operands instead of an N-fold amplified gather.
+        constexpr int64_t A16 = 16 / (int64_t)sizeof(T);
+        const int64_t ldt = ceil_div(N, A16) * A16;
+        T* bt = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)m.cols * (size_t)ldt));
+        T* ct = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)m.rows * (size_t)ldt));
+        convert_layout<T>(m.cols, N, B, 1, ldb, bt, ldt, 1);
+        if (!vt<T>::is_zero(beta)) convert_layout<T>(m.rows, N, C, 1, ldc, ct, ldt, 1);
+        spmm_device<T>(h, transposed, m, conj_a, alpha, MI_SPARSE_LAYOUT_ROW_MAJOR, bt, N, ldt, beta, ct, ldt);
+        convert_layout<T>(m.rows, N, ct, ldt, 1, C, 1, ldc);
+        return;
+    }
     const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk);
     int32_t* carry_row = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)p.nchunks));
     T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)p.nchunks * (size_t)N));
@@ -337,8 +413,17 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         (void)hipEventDestroy(ev1);
     }
 #endif
-    MI_LAUNCH((k_spmm_fixup<T>), dim3((unsigned)ceil_div(p.nchunks * WAVE, 256)), dim3(256), c.stream, p.nchunks,
-              (const int32_t*)carry_row, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+    if (vec_ok) {
+        if (N / V16 > 16)
+            MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)ceil_div(p.nchunks * 32, 256)), dim3(256), c.stream,
+                      p.nchunks, (const int32_t*)carry_row, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+        else
+            MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)ceil_div(p.nchunks * 8, 256)), dim3(256), c.stream,
+                      p.nchunks, (const int32_t*)carry_row, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+    } else {
+        MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(p.nchunks * 16, 256)), dim3(256), c.stream,
+                  p.nchunks, (const int32_t*)carry_row, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+    }
 }
 
 template void spmm_device<float>(mi_sparse_matrix*, bool, const Csr&, int, float, int, const float*, int64_t, int64_t,

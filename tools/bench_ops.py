@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""
+Secondary measurements (not the driver's bench contract): SpGEMM and gram at BASELINE-config scale
+on one MI355X, device-resident operands through the C ABI, each followed by size-independent
+parity checks (the oracle would take minutes to hours at these sizes).
+
+    python tools/bench_ops.py spgemm [--scale 20 --per-row 16 --kind uniform|rmat]
+    python tools/bench_ops.py gram   [--rows-log2 20 --cols 16384 --per-row 64 --dense]
+
+Prints one JSON line per run.
+SpGEMM checks:  C 1 == A (B 1)   (row sums, via SpMV on the same library, fp64 1e-12 rel);
+                nnz(C) <= sum of per-row product counts;  no duplicate column inside a row after ordering.
+Gram checks:    triu(C) 1-weighted sums:  sum_ij C_ij (j >= i)  and  diag(C) = column sums of A.^2.
+"""
+import argparse
+import ctypes as ct
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("op", choices=["spgemm", "gram"])
+    ap.add_argument("--scale", type=int, default=20)
+    ap.add_argument("--per-row", type=int, default=None)
+    ap.add_argument("--kind", default="uniform", choices=["uniform", "rmat"])
+    ap.add_argument("--rows-log2", type=int, default=20)
+    ap.add_argument("--cols", type=int, default=16384)
+    ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import bench
+    import sparse_dot_amd as sda
+    from sparse_dot_amd._mi_interface import MI, matrix_descr, sparse_matrix_t, _check_return_value
+
+    dev = torch.device("cuda", 0)
+    sda.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def make(kind, n_rows_log2, ncols, per_row, seed, dtype):
+        if kind == "rmat":
+            ip, idx, v, n = bench.rmat_csr(torch, n_rows_log2, per_row, seed, dev)
+            return ip, idx, v.to(dtype), n, n
+        n = 1 << n_rows_log2
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        rows = torch.arange(n, device=dev, dtype=torch.int64).repeat_interleave(per_row)
+        cols = torch.randint(0, ncols, (n * per_row,), generator=g, device=dev, dtype=torch.int64)
+        key = torch.unique(rows * ncols + cols)
+        r = key // ncols
+        idx = (key % ncols).to(torch.int32)
+        counts = torch.bincount(r, minlength=n)
+        ip = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        ip[1:] = torch.cumsum(counts, 0)
+        v = (torch.rand(idx.numel(), generator=g, device=dev, dtype=torch.float64) + 0.5).to(dtype)
+        return ip.to(torch.int32), idx, v, n, ncols
+
+    def handle(letter, ip, idx, v, m, k):
+        h = sparse_matrix_t()
+        _check_return_value(MI.call("mi_sparse_%s_create_csr" % letter, ct.byref(h), 0, m, k, ip.data_ptr(),
+                                    ip.data_ptr() + 4, idx.data_ptr(), v.data_ptr()), "create")
+        return h
+
+    def dev_csr(h, dtype):
+        rows, cols, nnz = ct.c_int64(), ct.c_int64(), ct.c_int64()
+        _check_return_value(MI.call("mi_sparse_get_info", h, ct.byref(rows), ct.byref(cols), ct.byref(nnz), None, None), "info")
+        p, c, v = ct.c_void_p(), ct.c_void_p(), ct.c_void_p()
+        _check_return_value(MI.call("mi_sparse_get_device_csr", h, ct.byref(p), ct.byref(c), ct.byref(v)), "devcsr")
+        return rows.value, cols.value, nnz.value, p.value, c.value, v.value
+
+    def spmv(letter, h, x, y):
+        _check_return_value(MI.call("mi_sparse_%s_mv" % letter, 10, 1.0, h, matrix_descr(), x.data_ptr(), 0.0,
+                                    y.data_ptr()), "mv")
+
+    out = {"op": args.op}
+    if args.op == "spgemm":
+        per_row = args.per_row or 16
+        dt = torch.float64
+        a = make(args.kind, args.scale, 1 << args.scale, per_row, 21 if args.kind == "rmat" else 1, dt)
+        b = make(args.kind, args.scale, 1 << args.scale, per_row, 23 if args.kind == "rmat" else 2, dt)
+        ha = handle("d", *a[:3], a[3], a[4])
+        hb = handle("d", *b[:3], b[3], b[4])
+        times = []
+        hc = None
+        for rep in range(args.reps + 1):
+            if hc is not None:
+                MI.call("mi_sparse_destroy", hc)
+            hc = sparse_matrix_t()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _check_return_value(MI.call("mi_sparse_spmm", 10, ha, hb, ct.byref(hc)), "spmm")
+            torch.cuda.synchronize()
+            if rep:
+                times.append(time.perf_counter() - t0)
+        t = sorted(times)[len(times) // 2]
+        m, n, nnzc, _, _, _ = dev_csr(hc, dt)
+        # products = sum_k colnnz_A(k) * rownnz_B(k)
+        colnnz_a = torch.bincount(a[1].long(), minlength=a[4]).double()
+        rownnz_b = (b[0][1:] - b[0][:-1]).double()
+        products = float((colnnz_a * rownnz_b).sum())
+        # parity: C 1 == A (B 1)
+        ones = torch.ones(n, device=dev, dtype=dt)
+        b1 = torch.empty(b[3], device=dev, dtype=dt)
+        ab1 = torch.empty(m, device=dev, dtype=dt)
+        c1 = torch.empty(m, device=dev, dtype=dt)
+        spmv("d", hb, ones, b1)
+        spmv("d", ha, b1, ab1)
+        spmv("d", hc, ones, c1)
+        torch.cuda.synchronize()
+        rel = float(((c1 - ab1).abs() / ab1.abs().clamp(min=1e-300)).max())
+        t0 = time.perf_counter()
+        _check_return_value(MI.call("mi_sparse_order", hc), "order")
+        torch.cuda.synchronize()
+        t_order = time.perf_counter() - t0
+        nbytes = (a[1].numel() + b[1].numel() + nnzc) * 12 + 3 * (m + 1) * 8
+        out.update({"config": "%s 2^%d x 2^%d, %d/row fp64 x same" % (args.kind, args.scale, args.scale, per_row),
+                    "nnzA": int(a[1].numel()), "nnzB": int(b[1].numel()), "nnzC": int(nnzc), "products": products,
+                    "ms": t * 1e3, "gflops": 2 * products / t / 1e9, "algorithmic_GBps": nbytes / t / 1e9,
+                    "order_ms": t_order * 1e3, "rowsum_max_rel_err": rel,
+                    "checks": {"rowsum_1e-12": rel <= 1e-12, "nnzC_le_products": nnzc <= products}})
+        for h in (ha, hb, hc):
+            MI.call("mi_sparse_destroy", h)
+    else:
+        per_row = args.per_row or 64
+        dt = torch.float32
+        a = make("uniform", args.rows_log2, args.cols, per_row, 3, dt)
+        ha = handle("s", *a[:3], a[3], a[4])
+        n = args.cols
+        colsq = torch.zeros(n, device=dev, dtype=torch.float64)
+        colsq.index_add_(0, a[1].long(), a[2].double() ** 2)
+        lens = (a[0][1:] - a[0][:-1]).double()
+        flops = float((lens * (lens + 1)).sum())  # 2 * sum r(r+1)/2
+        if args.dense:
+            C = torch.zeros((n, n), device=dev, dtype=dt)
+            times = []
+            for rep in range(args.reps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _check_return_value(MI.call("mi_sparse_s_syrkd", 11, ha, 1.0, 0.0, C.data_ptr(), 101, n), "syrkd")
+                torch.cuda.synchronize()
+                if rep:
+                    times.append(time.perf_counter() - t0)
+            t = sorted(times)[len(times) // 2]
+            diag_err = float(((torch.diagonal(C).double() - colsq).abs() / colsq.clamp(min=1e-30)).max())
+            lower_zero = bool((torch.tril(C[:2048, :2048], -1) == 0).all())
+            # total: sum of upper triangle == sum over rows of (sum_{p<=q} v_p v_q)
+            out.update({"config": "uniform 2^%d x %d, %d/row fp32, dense out" % (args.rows_log2, n, per_row),
+                        "nnzA": int(a[1].numel()), "ms": t * 1e3, "gflops": flops / t / 1e9,
+                        "algorithmic_GBps": (a[1].numel() * 8 + n * n * 4 / 2) / t / 1e9,
+                        "diag_max_rel_err": diag_err, "checks": {"diag_1e-5": diag_err <= 1e-5, "lower_zero": lower_zero}})
+        else:
+            times = []
+            hc = None
+            for rep in range(args.reps + 1):
+                if hc is not None:
+                    MI.call("mi_sparse_destroy", hc)
+                hc = sparse_matrix_t()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _check_return_value(MI.call("mi_sparse_syrk", 11, ha, ct.byref(hc)), "syrk")
+                torch.cuda.synchronize()
+                if rep:
+                    times.append(time.perf_counter() - t0)
+            t = sorted(times)[len(times) // 2]
+            m, _, nnzc, _, _, _ = dev_csr(hc, dt)
+            out.update({"config": "uniform 2^%d x %d, %d/row fp32, sparse out" % (args.rows_log2, n, per_row),
+                        "nnzA": int(a[1].numel()), "nnzC": int(nnzc), "ms": t * 1e3, "gflops": flops / t / 1e9})
+            MI.call("mi_sparse_destroy", hc)
+        MI.call("mi_sparse_destroy", ha)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
