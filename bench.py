@@ -136,8 +136,10 @@ def main():
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--ncols", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the uniform-random secondary measurement")
     ap.add_argument("--chunk", type=int, default=0, help="override the SpMM work-item chunk (tuning)")
     ap.add_argument("--unroll", type=int, default=0, help="override the SpMM load unroll 4|8 (tuning)")
+    ap.add_argument("--hot-kb", type=int, default=-1, help="override the hot-set budget in KiB, 0 = no tagging (tuning)")
     args = ap.parse_args()
 
     import numpy as np
@@ -200,6 +202,8 @@ def main():
         sda.mi_set_option("spmm_chunk", args.chunk)
     if args.unroll:
         sda.mi_set_option("spmm_unroll", args.unroll)
+    if args.hot_kb >= 0:
+        sda.mi_set_option("spmm_hot_kb", args.hot_kb)
 
     # ---- synthetic inputs, generated on the device ------------------------------------------------
     N = args.ncols
@@ -270,8 +274,11 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    tagged = bool(sda.mi_get_counter("spmm_last_tagged"))
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_spmm<float,4,32,4>",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "k_spmm<float,4,%d,%d,%s>" % (32 if N == 128 else 64 if N >= 256 else 16, args.unroll or 4,
+                                                        "true" if tagged else "false"),
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes}
 
     # ---- collectives the row-partitioned path needs around the kernel (reported, not timed above) --
@@ -294,6 +301,36 @@ def main():
             "note": "RCCL over xGMI; not part of the timed step (weak scaling, outputs stay row-distributed)",
         }
         del gathered
+
+    # ---- secondary workload the north_star asks to report alongside: uniform-random CSR, same shape ----
+    secondary = None
+    if not args.no_secondary and args.workload == "rmat" and world == 1 and not args.no_cpu:
+        u_ptr, u_idx, u_val, _ = uniform_csr(torch, n, 32, 11, dev)
+        uref = sparse_matrix_t()
+        _check_return_value(MI.call("mi_sparse_s_create_csr", ct.byref(uref), 0, n, n, u_ptr.data_ptr(),
+                                    u_ptr.data_ptr() + 4, u_idx.data_ptr(), u_val.data_ptr()), "mi_sparse_s_create_csr")
+        C2 = torch.empty_like(C)
+
+        def ustep():
+            r = MI.call("mi_sparse_s_mm", 10, 1.0, uref, matrix_descr(), 101, B.data_ptr(), N, N, 0.0, C2.data_ptr(), N)
+            if r:
+                _check_return_value(r, "mi_sparse_s_mm")
+        for _ in range(args.warmup):
+            ustep()
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        for _ in range(args.steps):
+            ustep()
+        torch.cuda.synchronize()
+        tu = (time.perf_counter() - tu) / args.steps
+        u_nnz = int(u_idx.numel())
+        u_bytes = u_nnz * 8 + (n + 1) * 8 + 2 * n * N * 4
+        secondary = {"workload": "uniform-random CSR %dx%d, 32/row (%d nnz) x dense %dx%d fp32" % (n, n, u_nnz, n, N),
+                     "value": round(2.0 * u_nnz * N / tu / 1e9, 2), "unit": "GFLOP/s", "ms_per_step": round(tu * 1e3, 4),
+                     "algorithmic_GBps": round(u_bytes / tu / 1e9, 1),
+                     "hot_cold_tagged_gather": bool(sda.mi_get_counter("spmm_last_tagged"))}
+        MI.call("mi_sparse_destroy", uref)
+        del C2, u_ptr, u_idx, u_val
 
     # ---- parity spot check of the timed configuration (a row sample vs fp64 on the GPU) -----------
     cpu = None
@@ -320,11 +357,15 @@ def main():
                                    % ("R-MAT(.57,.19,.19,.05) scale %d, 32 edges/row, dedup" % args.scale
                                       if args.workload == "rmat" else "uniform 32/row", n, n, nnz, n, N),
                        "partition": "1-D row blocks, one block per GPU" if world > 1 else "single GPU",
-                       "spmm_chunk": args.chunk or 256},
+                       "spmm_chunk": args.chunk or 256,
+                       "hot_cold_tagged_gather": bool(sda.mi_get_counter("spmm_last_tagged")),
+                       "hot_column_coverage": round(sda.mi_get_counter("spmm_hot_coverage"), 4)},
             "roofline": roofline, "cpu_baseline": cpu, "parity_max_rel_err_sample": worst,
         }
         if collectives:
             line["collectives"] = collectives
+        if secondary:
+            line["secondary"] = secondary
         print(json.dumps(line), flush=True)
     handle.destroy()
     if dist:

@@ -69,7 +69,11 @@ struct vt {  // real types
     static __host__ __device__ __forceinline__ T one() { return T(1); }
     static __host__ __device__ __forceinline__ T mul(T a, T b) { return a * b; }
     static __host__ __device__ __forceinline__ T add(T a, T b) { return a + b; }
-    static __host__ __device__ __forceinline__ T fma(T a, T b, T c) { return a * b + c; }
+    // explicit fused multiply-add: one rounding, independent of how a given instantiation is
+    // scheduled, so every kernel variant produces the same bits
+    static __host__ __device__ __forceinline__ T fma(T a, T b, T c) { return fma_(a, b, c); }
+    static __host__ __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __host__ __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __host__ __device__ __forceinline__ T conj(T a) { return a; }
     static __host__ __device__ __forceinline__ bool is_zero(T a) { return a == T(0); }
 };
@@ -82,12 +86,13 @@ struct vt<cx<R>> {
     static __host__ __device__ __forceinline__ T one() { return T{R(1), R(0)}; }
     static __host__ __device__ __forceinline__ T mul(T a, T b)
     {
-        return T{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+        return T{vt<R>::fma(a.re, b.re, -(a.im * b.im)), vt<R>::fma(a.re, b.im, a.im * b.re)};
     }
     static __host__ __device__ __forceinline__ T add(T a, T b) { return T{a.re + b.re, a.im + b.im}; }
     static __host__ __device__ __forceinline__ T fma(T a, T b, T c)
     {
-        return T{c.re + a.re * b.re - a.im * b.im, c.im + a.re * b.im + a.im * b.re};
+        return T{vt<R>::fma(-a.im, b.im, vt<R>::fma(a.re, b.re, c.re)),
+                 vt<R>::fma(a.im, b.re, vt<R>::fma(a.re, b.im, c.im))};
     }
     static __host__ __device__ __forceinline__ T conj(T a) { return T{a.re, -a.im}; }
     static __host__ __device__ __forceinline__ bool is_zero(T a) { return a.re == R(0) && a.im == R(0); }
@@ -260,6 +265,12 @@ struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.h
     int chunk = 0;
     int64_t nchunks = 0;
     DevBuf chunk_row;  // int32[nchunks + 1]
+    // hot / cold column tagging (see spmm.hip): copy of the column indices with bit 31 set on
+    // entries whose column is NOT in the hot set that is meant to stay L2 resident
+    int64_t hot_rows_budget = -1;  // the budget (in B rows) the tags were computed for; -1 = never
+    bool tagged = false;           // false: matrix has no useful hot set (or tagging disabled)
+    double hot_coverage = 0.0;     // fraction of nonzeros that fall on hot columns
+    DevBuf col_tagged;             // int32[nnz]
 };
 
 }  // namespace mi
@@ -313,12 +324,16 @@ struct Options {
     int64_t spmm_chunk = 256;      // work items (nnz + row ends) per wave in the SpMM kernel
     int64_t spmm_force_generic = 0;
     int64_t spmm_unroll = 4;       // 4 or 8 independent B-row loads in flight per lane
+    int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
+    int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;
     int64_t profile_events = 0;    // bracket the SpMM main kernel with hipEvents (diagnostics)
 };
 struct Counters {
     double spmm_kernel_ms = 0.0;
     double spmm_kernel_launches = 0.0;
+    double spmm_last_tagged = 0.0;    // 1 when the last SpMM used the hot / cold tagged gather
+    double spmm_hot_coverage = 0.0;   // share of nonzeros on hot columns in the last SpMM's plan
 };
 Counters& counters();  // per host thread
 Options& options();

@@ -6,45 +6,96 @@
 //
 // Row-owned formulation (no inter-workgroup races): with X = A (op 11) or X = A^T (op 10),
 // C = X^T X and output row i is  sum over nonzeros (r, i) of X of  X[r, i] * X[r, i:].
-// The CSR of X^T (cached on the handle) lists those nonzeros; one wave owns output row i, walks
-// them in order and lets its lanes span the entries of X's row r.  The scatter into the dense
-// row uses L2 float/double atomics (entries of different r collide on the same column); all
-// traffic to one output row comes from one wave, so the row stays in that XCD's L2.
+// The CSR of X^T (cached on the handle) lists those nonzeros; a workgroup owns (row i, a 64 KiB
+// column tile), its waves walk those nonzeros and let their lanes span the entries of X's row r.
 #include "common.hpp"
 
 namespace mi {
 
+// One workgroup per (output row i, column tile): the tile of the dense row lives in LDS, products are
+// accumulated with LDS float / double atomics (entries of different source rows r collide on the
+// same column), and the finished tile is written to HBM exactly once, coalesced, with beta applied
+// on the way -- no global atomics, no separate scaling pass.  Tiles start at the diagonal (only
+// col >= row is produced).
 template <typename T>
-__global__ void __launch_bounds__(256)
-    k_scale_upper(T* C, int64_t n, int64_t c_rs, int64_t c_cs, T beta, int beta_zero)
+__device__ __forceinline__ T shfl_bcast(T v, int src)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * n) return;
-    const bool row_major = (c_cs == 1);
-    const int64_t i = row_major ? t / n : t % n;
-    const int64_t j = row_major ? t % n : t / n;
-    if (j < i) return;
-    T* c = C + i * c_rs + j * c_cs;
-    *c = beta_zero ? vt<T>::zero() : vt<T>::mul(beta, *c);
+    return __shfl(v, src);
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256)
-    k_syrkd(int64_t n, const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol,
-            const T* __restrict__ tval, const int64_t* __restrict__ xptr, const int32_t* __restrict__ xcol,
-            const T* __restrict__ xval, T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha)
+constexpr int syrkd_tile() { return (int)(65536 / sizeof(T)); }  // 64 KiB of LDS per workgroup
+
+template <typename T>
+__global__ void __launch_bounds__(512)
+    k_syrkd_lds(int64_t n, int64_t tiles_per_row, const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol,
+                const T* __restrict__ tval, const int64_t* __restrict__ xptr, const int32_t* __restrict__ xcol,
+                const T* __restrict__ xval, T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta,
+                int beta_zero)
 {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x % WAVE;
-    if (i >= n) return;
-    T* crow = C + i * c_rs;
-    for (int64_t p = tptr[i]; p < tptr[i + 1]; ++p) {
-        const int32_t r = tcol[p];
-        const T a = vt<T>::mul(alpha, tval[p]);
-        for (int64_t q = xptr[r] + lane; q < xptr[r + 1]; q += WAVE) {
-            const int32_t j = xcol[q];
-            if (j >= i) atomic_accum(crow + (int64_t)j * c_cs, vt<T>::mul(a, xval[q]));
+    constexpr int TILE = syrkd_tile<T>();
+    __shared__ T acc[TILE];
+    const int64_t i = (int64_t)blockIdx.x / tiles_per_row;
+    const int64_t t = (int64_t)blockIdx.x % tiles_per_row;
+    const int64_t j_lo = i + t * TILE;
+    if (j_lo >= n) return;  // uniform for the whole workgroup
+    const int64_t j_hi = (j_lo + TILE < n) ? j_lo + TILE : n;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    for (int k = tid; k < (int)(j_hi - j_lo); k += nthreads) acc[k] = vt<T>::zero();
+    __syncthreads();
+    const int wave = tid / WAVE, lane = tid % WAVE, nwaves = nthreads / WAVE;
+    // Each wave takes 64 nonzeros (r, X[r,i]) of column i at a time: lane l fetches entry l and the
+    // extent of X's row r (coalesced + one gather), then the wave walks those 64 rows with the
+    // per-row scalars broadcast by readlane -- one dependent memory latency per row instead of
+    // three, and four rows' loads in flight together.
+    const int64_t t0 = tptr[i], t1 = tptr[i + 1];
+    for (int64_t base = t0 + (int64_t)wave * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {
+        const int64_t p = base + lane;
+        const bool valid = p < t1;
+        const int32_t r = valid ? tcol[p] : 0;
+        const T a = valid ? vt<T>::mul(alpha, tval[p]) : vt<T>::zero();
+        const int64_t q0 = valid ? xptr[r] : 0;
+        const int64_t q1 = valid ? xptr[r + 1] : 0;
+        const int cnt = (t1 - base < WAVE) ? (int)(t1 - base) : WAVE;
+        for (int e0 = 0; e0 < cnt; e0 += 4) {
+            int64_t qs[4], qe[4];
+            T ae[4];
+            int32_t jj[4];
+            T xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = (e0 + u < cnt) ? e0 + u : e0;  // clamp: duplicates are masked out below
+                qs[u] = shfl_bcast(q0, e);
+                qe[u] = (e0 + u < cnt) ? shfl_bcast(q1, e) : qs[u];
+                ae[u] = shfl_bcast(a, e);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // first 64 entries of each of the four rows: loads issued together
+                const int64_t q = qs[u] + lane;
+                const bool ok = q < qe[u];
+                jj[u] = ok ? xcol[q] : -1;
+                xv[u] = ok ? xval[q] : vt<T>::zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = jj[u];
+                if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(ae[u], xv[u]));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // rows longer than one wave
+                for (int64_t q = qs[u] + WAVE + lane; q < qe[u]; q += WAVE) {
+                    const int64_t j = xcol[q];
+                    if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(ae[u], xval[q]));
+                }
+            }
         }
+    }
+    __syncthreads();
+    T* crow = C + i * c_rs;
+    for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
+        T* c = crow + j * c_cs;
+        const T v = acc[j - j_lo];
+        *c = beta_zero ? v : vt<T>::fma(beta, *c, v);
     }
 }
 
@@ -77,11 +128,11 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
         sc.stage_in(C, sizeof(T) * (size_t)((n - 1) * ldc + n), true);  // lower triangle must survive the round trip
         T* dC = static_cast<T*>(sc.dev);
-        MI_LAUNCH((k_scale_upper<T>), dim3((unsigned)ceil_div(n * n, 256)), dim3(256), c.stream, dC, n, c_rs, c_cs, beta,
-                  beta_zero);
-        MI_LAUNCH((k_syrkd<T>), dim3((unsigned)ceil_div(n * WAVE, 256)), dim3(256), c.stream, n, (const int64_t*)t.ptr,
-                  (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, (const int32_t*)x.col,
-                  (const T*)x.val, dC, c_rs, c_cs, alpha);
+        const int64_t tiles_per_row = ceil_div(n, (int64_t)syrkd_tile<T>());
+        if (n * tiles_per_row > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "gram output too large for one launch");
+        MI_LAUNCH((k_syrkd_lds<T>), dim3((unsigned)(n * tiles_per_row)), dim3(512), c.stream, n, tiles_per_row,
+                  (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
+                  (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero);
         MI_HIP_CHECK(hipGetLastError());
         sc.copy_back();
     });

@@ -353,6 +353,11 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
         } else if (!strcmp(name, "spmm_unroll")) {
             if (value != 4 && value != 8) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_unroll must be 4 or 8");
             o.spmm_unroll = value;
+        } else if (!strcmp(name, "spmm_hot_kb")) {
+            if (value < 0) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_hot_kb must be >= 0");
+            o.spmm_hot_kb = value;
+        } else if (!strcmp(name, "spmm_hot_force")) {
+            o.spmm_hot_force = value;
         } else if (!strcmp(name, "spmm_force_generic")) {
             o.spmm_force_generic = value;
         } else if (!strcmp(name, "spgemm_force_global")) {
@@ -378,6 +383,8 @@ mi_sparse_status_t mi_sparse_get_counter(const char* name, double* value)
         if (!value) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL value pointer");
         if (!strcmp(name, "spmm_kernel_ms")) *value = k.spmm_kernel_ms;
         else if (!strcmp(name, "spmm_kernel_launches")) *value = k.spmm_kernel_launches;
+        else if (!strcmp(name, "spmm_last_tagged")) *value = k.spmm_last_tagged;
+        else if (!strcmp(name, "spmm_hot_coverage")) *value = k.spmm_hot_coverage;
         else mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown counter '%s'", name);
     });
 }

@@ -6,7 +6,7 @@
 // Two-phase row-wise (Gustavson) SpGEMM with hash accumulators:
 //   0. ub[i]  = sum over nonzeros (i,k) of A of nnz(B[k,:])          (upper bound of row i of C)
 //   1. symbolic: rows binned by ub; every row counts its distinct columns in a hash table
-//      (LDS table per workgroup for ub <= 2048; a global-memory slab per persistent workgroup
+//      (LDS tables of 64 / 256 / 1024 / 4096 slots per workgroup for ub <= 32 / 128 / 512 / 2048; a global-memory slab per persistent workgroup
 //      for the hub rows of skewed matrices)
 //   2. exclusive scan of the counts -> row pointer of C (int64: nnz(C) may exceed 2^31)
 //   3. numeric: rows re-binned by their exact length; same hash tables now carry values
@@ -47,24 +47,37 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---- binning -------------------------------------------------------------------------------------
-constexpr int NBINS = 4;                       // 0: <=32   1: <=256   2: <=2048   3: larger
+constexpr int NBINS = 5;                       // 0: <=32  1: <=128  2: <=512  3: <=2048  4: larger (global)
 __host__ __device__ inline int bin_of(int64_t c)
 {
-    return c <= 32 ? 0 : c <= 256 ? 1 : c <= 2048 ? 2 : 3;
+    return c <= 32 ? 0 : c <= 128 ? 1 : c <= 512 ? 2 : c <= 2048 ? 3 : 4;
 }
 
-// counts per bin (rows with c == 0 are skipped); when `lists` != nullptr also scatters the row ids
+// counts per bin (rows with c == 0 are skipped); when `lists` != nullptr also scatters the row ids.
+// One global atomic per (workgroup, bin): positions inside the workgroup come from LDS counters.
 __global__ void __launch_bounds__(256)
     k_bin_rows(int64_t rows, const int64_t* __restrict__ cnt, int64_t* __restrict__ bin_counts,
                int32_t* const* __restrict__ lists)
 {
+    __shared__ int local_n[NBINS];
+    __shared__ int64_t base[NBINS];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    const int64_t c = cnt[i];
-    if (c <= 0) return;
-    const int b = bin_of(c);
-    const int64_t d = (int64_t)atomicAdd((unsigned long long*)&bin_counts[b], 1ull);
-    if (lists) lists[b][d] = (int32_t)i;
+    if (threadIdx.x < NBINS) local_n[threadIdx.x] = 0;
+    __syncthreads();
+    int b = -1, pos = 0;
+    if (i < rows) {
+        const int64_t c = cnt[i];
+        if (c > 0) {
+            b = bin_of(c);
+            pos = atomicAdd(&local_n[b], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NBINS && local_n[threadIdx.x] > 0)
+        base[threadIdx.x] = (int64_t)atomicAdd((unsigned long long*)&bin_counts[threadIdx.x],
+                                               (unsigned long long)local_n[threadIdx.x]);
+    __syncthreads();
+    if (b >= 0 && lists) lists[b][base[b] + pos] = (int32_t)i;
 }
 
 // ---- LDS hash kernel: one workgroup per row -------------------------------------------------------
@@ -259,8 +272,8 @@ __global__ void k_fill_dense(T* C, int64_t r, int64_t cdim, int64_t c_rs, int64_
 // host side
 // ------------------------------------------------------------------------------------------------
 struct Bins {
-    int64_t n[NBINS] = {0, 0, 0, 0};
-    int32_t* list[NBINS] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t n[NBINS] = {0, 0, 0, 0, 0};
+    int32_t* list[NBINS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static Bins make_bins(const int64_t* cnt, int64_t rows)
@@ -311,14 +324,17 @@ static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt
             MI_LAUNCH((k_spgemm_lds<T, 6, 64, NUMERIC>), dim3((unsigned)b.n[0]), dim3(64), c.stream,
                       MI_SPGEMM_ARGS(b.list[0]), gw64, (int)upper, row_nnz, cptr, ccol, cval);
         if (b.n[1])
-            MI_LAUNCH((k_spgemm_lds<T, 9, 64, NUMERIC>), dim3((unsigned)b.n[1]), dim3(64), c.stream,
+            MI_LAUNCH((k_spgemm_lds<T, 8, 64, NUMERIC>), dim3((unsigned)b.n[1]), dim3(64), c.stream,
                       MI_SPGEMM_ARGS(b.list[1]), gw64, (int)upper, row_nnz, cptr, ccol, cval);
         if (b.n[2])
-            MI_LAUNCH((k_spgemm_lds<T, 12, 256, NUMERIC>), dim3((unsigned)b.n[2]), dim3(256), c.stream,
-                      MI_SPGEMM_ARGS(b.list[2]), gw, (int)upper, row_nnz, cptr, ccol, cval);
+            MI_LAUNCH((k_spgemm_lds<T, 10, 128, NUMERIC>), dim3((unsigned)b.n[2]), dim3(128), c.stream,
+                      MI_SPGEMM_ARGS(b.list[2]), gw64, (int)upper, row_nnz, cptr, ccol, cval);
+        if (b.n[3])
+            MI_LAUNCH((k_spgemm_lds<T, 12, 256, NUMERIC>), dim3((unsigned)b.n[3]), dim3(256), c.stream,
+                      MI_SPGEMM_ARGS(b.list[3]), gw, (int)upper, row_nnz, cptr, ccol, cval);
     }
     for (int k = 0; k < NBINS; ++k) {
-        if (!b.n[k] || (!force_global && k < 3)) continue;
+        if (!b.n[k] || (!force_global && k < NBINS - 1)) continue;
         // slab = table size of the largest row: next pow2 >= 2 * min(max_cnt, cols)
         int64_t cap = max_cnt < B.cols ? max_cnt : B.cols;
         int64_t slab = 4;

@@ -20,6 +20,8 @@
 // slice of A (column indices, values, row ends) is staged once in LDS with coalesced loads and
 // then broadcast-read; B rows go straight from L2/HBM to registers (there is no intra-workgroup
 // reuse of a B row to stage for -- see DESIGN.md), U independent loads in flight per lane.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace mi {
@@ -35,22 +37,32 @@ __device__ __forceinline__ cx<R> shfl_xor_val(cx<R> v, int mask)
     return cx<R>{__shfl_xor(v.re, mask), __shfl_xor(v.im, mask)};
 }
 
-// chunk_row[w] = number of rows whose row-end item lies before item w*chunk
-__global__ void k_spmm_plan(const int64_t* ptr, int64_t rows, int64_t chunk, int64_t nchunks, int32_t* chunk_row)
+// chunk_row[w] = the row that contains work item w*chunk (items of row r are
+// [ptr[r] + r, ptr[r+1] + r]: its nonzeros, then its row-end item); `rows` past the last item
+__global__ void k_spmm_plan(const int64_t* ptr, int64_t rows, int64_t nnz, int64_t chunk, int64_t nchunks,
+                            int32_t* chunk_row)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w > nchunks) return;
     const int64_t s = w * chunk;
-    // smallest r in [0, rows] with q(r) = ptr[r+1] + r + 1 > s   (q is strictly increasing)
+    if (s >= nnz + rows) {
+        chunk_row[w] = (int32_t)rows;
+        return;
+    }
+    // smallest r in [0, rows] with start(r) = ptr[r] + r > s   (start is strictly increasing), minus one
     int64_t lo = 0, hi = rows;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (ptr[mid + 1] + mid + 1 > s) hi = mid; else lo = mid + 1;
+        if (ptr[mid] + mid > s) hi = mid; else lo = mid + 1;
     }
-    chunk_row[w] = (int32_t)lo;
+    chunk_row[w] = (int32_t)(lo - 1);
 }
 
 constexpr int SPMM_WAVES = 4;  // waves per workgroup (independent of each other after staging)
+// Rows of at most SPMM_SPLIT items are never cut: the wave that holds a short row's FIRST item
+// processes the whole row (reading up to SPMM_SPLIT entries past its chunk) and the next wave skips
+// it.  Only longer rows are cut at chunk boundaries and go through the carry / fix-up path.
+constexpr int SPMM_SPLIT = 128;
 
 // one staged nonzero of A: column + value side by side so a lane group fetches both with ONE
 // LDS read (ds_read_b64 for float, ds_read_b128 for double / complex float)
@@ -64,13 +76,18 @@ struct alignas(sizeof(T) >= 16 ? 16 : (sizeof(T) == 8 ? 8 : 8)) SpEntry {
 template <typename T>
 __host__ __device__ constexpr size_t spmm_wave_lds(int ch)
 {
-    return (size_t)ch * sizeof(SpEntry<T>) + (size_t)(ch + 2) * sizeof(int32_t);
+    return (size_t)(ch + SPMM_SPLIT) * sizeof(SpEntry<T>) + (size_t)(ch + 2) * sizeof(int32_t);
 }
 
 #ifndef MI_SPMM_MIN_WAVES
 #define MI_SPMM_MIN_WAVES 8
 #endif
-template <typename T, int V, int LPN, int U>
+// TAG: the staged column indices carry a "cold" flag in bit 31 (plan.col_tagged).  Hot rows of B are
+// fetched with the default cache policy, cold rows with the non-temporal one (`buffer_load ... nt`:
+// the cache policy is an immediate of the instruction, so the two flavours are two instructions
+// selected per lane group), which keeps the streaming majority of the gather from evicting the few
+// MB of B rows that power-law matrices hit over and over.  Needs B below 4 GiB (32-bit buffer offsets).
+template <typename T, int V, int LPN, int U, bool TAG>
 __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ? MI_SPMM_MIN_WAVES : 1)
     k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
            const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
@@ -88,34 +105,52 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     const size_t per_wave = (spmm_wave_lds<T>(ch) + 15) & ~size_t(15);
     char* base = smem + per_wave * wave_in_block;
     SpEntry<T>* s_nz = reinterpret_cast<SpEntry<T>*>(base);
-    int32_t* s_end = reinterpret_cast<int32_t*>(base + sizeof(SpEntry<T>) * (size_t)ch);
+    int32_t* s_end = reinterpret_cast<int32_t*>(base + sizeof(SpEntry<T>) * (size_t)(ch + SPMM_SPLIT));
 
-    int64_t r0 = 0, r1 = 0, P0 = 0;
+    int64_t r0 = 0, P0 = 0;
     int n_owned = 0, has_trail = 0;
     if (active) {
         const int64_t total = nnz + rows;
         const int64_t s = w * ch;
         const int64_t e = (s + ch < total) ? s + ch : total;
-        r0 = chunk_row[w];
-        r1 = chunk_row[w + 1];
-        n_owned = (int)(r1 - r0);
-        const int64_t p_r0 = ptr[r0 < rows ? r0 : rows];
-        P0 = (s - r0 > p_r0) ? s - r0 : p_r0;
-        int64_t P1;
-        if (r1 < rows) {
-            const int64_t t_begin = (r1 == r0) ? P0 : ptr[r1];
-            int64_t t_end = ptr[r1 + 1];
-            if (e - r1 < t_end) t_end = e - r1;
-            has_trail = (t_end > t_begin) ? 1 : 0;
-            P1 = has_trail ? t_end : t_begin;
-        } else {
-            P1 = nnz;
+        const int64_t ra = chunk_row[w];      // row holding item s
+        const int64_t rb = chunk_row[w + 1];  // row holding item e (== rows after the last item)
+        // first row: a short row that began in the previous chunk was finished there; a long one
+        // is continued from item s
+        {
+            const int64_t pa = ptr[ra], pa1 = ptr[ra + 1];
+            const bool before = (pa + ra) < s;
+            const bool is_long = (pa1 - pa + 1) > SPMM_SPLIT;
+            if (before && !is_long) {
+                r0 = ra + 1;
+                P0 = pa1;
+            } else {
+                r0 = ra;
+                P0 = before ? s - ra : pa;
+            }
         }
-        // row ends relative to P0 (owned rows, then the trailing partial row)
-        const int nproc = n_owned + has_trail;
+        // last row: the row holding item e, if it starts inside this chunk, is finished here when
+        // short and cut (-> carry) when long
+        int64_t r_stop, P1;
+        if (rb < rows && (ptr[rb] + rb) < e) {
+            const int64_t pb = ptr[rb], pb1 = ptr[rb + 1];
+            r_stop = rb + 1;
+            if ((pb1 - pb + 1) > SPMM_SPLIT) {
+                P1 = (e - rb < pb1) ? e - rb : pb1;
+                has_trail = 1;
+            } else {
+                P1 = pb1;
+            }
+        } else {
+            r_stop = rb;
+            P1 = (rb < rows) ? ptr[rb] : nnz;
+        }
+        if (r_stop < r0) r_stop = r0;
+        const int nproc = (int)(r_stop - r0);
+        n_owned = nproc - has_trail;
         for (int k = lane; k < nproc; k += WAVE) {
             int64_t en = ptr[r0 + k + 1];
-            if (k == n_owned) en = P1;  // trailing row is cut at the chunk end
+            if (k == nproc - 1) en = P1;  // a cut row ends at the chunk end
             s_end[k] = (int32_t)(en - P0);
         }
         const int len = (int)(P1 - P0);
@@ -133,6 +168,10 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     const int g = lane / LPN;
     const int li = lane % LPN;
     const int nproc = n_owned + has_trail;
+#ifndef MI_HIP_EMU
+    __amdgpu_buffer_rsrc_t b_rsrc;
+    if constexpr (TAG) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+#endif
 
     for (int64_t j0 = 0; j0 < N; j0 += (int64_t)LPN * V) {
         const int64_t jc = j0 + (int64_t)li * V;  // first column of this lane
@@ -157,11 +196,25 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const T* src = bcol + (int64_t)nz[u].c * b_rs;
-                    if (V > 1) {
-                        b[u] = *reinterpret_cast<const vec<T, V>*>(src);
+                    if constexpr (TAG) {
+                        const int32_t cidx = nz[u].c & 0x7fffffff;
+#ifndef MI_HIP_EMU
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const unsigned voff = (unsigned)(((int64_t)cidx * b_rs + (col_ok ? jc : 0)) * (int64_t)sizeof(T));
+                        u32x4 r;
+                        if (nz[u].c < 0) r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 2);  // nt
+                        else r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 0);
+                        b[u] = __builtin_bit_cast(vec<T, V>, r);
+#else
+                        b[u] = *reinterpret_cast<const vec<T, V>*>(bcol + (int64_t)cidx * b_rs);
+#endif
                     } else {
-                        b[u].v[0] = src[0];
+                        const T* src = bcol + (int64_t)nz[u].c * b_rs;
+                        if (V > 1) {
+                            b[u] = *reinterpret_cast<const vec<T, V>*>(src);
+                        } else {
+                            b[u].v[0] = src[0];
+                        }
                     }
                 }
 #pragma unroll
@@ -217,7 +270,7 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
             }
         }
     }
-    if (lane == 0) carry_row[w] = has_trail ? (int32_t)r1 : -1;
+    if (lane == 0) carry_row[w] = has_trail ? (int32_t)(r0 + n_owned) : -1;
 }
 
 // add the carries of every cut row to the row its owner wrote; carries of one row are contiguous
@@ -300,31 +353,95 @@ static void convert_layout(int64_t rows, int64_t cols, const T* src, int64_t s_r
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, int chunk)
+__global__ void k_count_cols(const int32_t* __restrict__ col, int64_t nnz, unsigned* __restrict__ counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nnz) atomicAdd(&counts[col[i]], 1u);
+}
+
+__global__ void k_tag_cols(const int32_t* __restrict__ col, int64_t nnz, const unsigned* __restrict__ counts,
+                           unsigned threshold, int32_t* __restrict__ tagged)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nnz) {
+        const int32_t c = col[i];
+        tagged[i] = counts[c] >= threshold ? c : (int32_t)((unsigned)c | 0x80000000u);
+    }
+}
+
+// Decide whether the matrix has a hot column set worth protecting and, if so, build the tagged
+// column array.  hot_rows = how many rows of B fit the L2 budget for this call's row width.
+static void plan_hot_cold(SpmmPlan& p, const Csr& m, int64_t hot_rows)
+{
+    p.hot_rows_budget = hot_rows;
+    p.tagged = false;
+    p.hot_coverage = 0.0;
+    const bool force = options().spmm_hot_force != 0;
+    if (hot_rows <= 0 || m.nnz == 0) return;
+    if (hot_rows > m.cols) hot_rows = m.cols;
+    if (!force && (m.nnz < (int64_t)1 << 20 || m.cols <= 4 * hot_rows)) return;  // small / everything fits
+    Context& c = ctx();
+    unsigned* counts = static_cast<unsigned*>(c.scratch_alloc(sizeof(unsigned) * (size_t)m.cols));
+    MI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned) * (size_t)m.cols, c.stream));
+    MI_LAUNCH(k_count_cols, dim3((unsigned)ceil_div(m.nnz, 256)), dim3(256), c.stream, (const int32_t*)m.col, m.nnz,
+              counts);
+    std::vector<unsigned> hc((size_t)m.cols);
+    MI_HIP_CHECK(hipMemcpyAsync(hc.data(), counts, sizeof(unsigned) * (size_t)m.cols, hipMemcpyDeviceToHost, c.stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+    // threshold = count of the hot_rows-th most referenced column
+    std::vector<unsigned> sel(hc);
+    std::nth_element(sel.begin(), sel.begin() + (hot_rows - 1), sel.end(), [](unsigned a, unsigned b) { return a > b; });
+    const unsigned thr = sel[(size_t)(hot_rows - 1)];
+    if (thr < 2 && !force) return;
+    int64_t covered = 0, nhot = 0;
+    for (unsigned v : hc)
+        if (v >= thr) { covered += v; ++nhot; }
+    p.hot_coverage = (double)covered / (double)m.nnz;
+    // worth it only when a small set takes a real share of the gather and ties did not blow the set up
+    if (!force && (p.hot_coverage < 0.10 || nhot > 2 * hot_rows)) return;
+    p.col_tagged.alloc(sizeof(int32_t) * (size_t)m.nnz);
+    MI_LAUNCH(k_tag_cols, dim3((unsigned)ceil_div(m.nnz, 256)), dim3(256), c.stream, (const int32_t*)m.col, m.nnz,
+              (const unsigned*)counts, thr, p.col_tagged.as<int32_t>());
+    p.tagged = true;
+}
+
+static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, int chunk, int64_t hot_rows)
 {
     SpmmPlan& p = transposed ? h->planT : h->plan;
     std::lock_guard<std::mutex> lk(h->mtx);
-    if (p.chunk == chunk && p.chunk_row.p) return p;
     Context& c = ctx();
-    const int64_t total = m.nnz + m.rows;
-    p.nchunks = total > 0 ? ceil_div(total, chunk) : 1;
-    p.chunk_row.alloc(sizeof(int32_t) * (size_t)(p.nchunks + 1));
-    MI_LAUNCH(k_spmm_plan, dim3((unsigned)ceil_div(p.nchunks + 1, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
-              m.rows, (int64_t)chunk, p.nchunks, p.chunk_row.as<int32_t>());
-    p.chunk = chunk;
+    if (!(p.chunk == chunk && p.chunk_row.p)) {
+        const int64_t total = m.nnz + m.rows;
+        p.nchunks = total > 0 ? ceil_div(total, chunk) : 1;
+        p.chunk_row.alloc(sizeof(int32_t) * (size_t)(p.nchunks + 1));
+        MI_LAUNCH(k_spmm_plan, dim3((unsigned)ceil_div(p.nchunks + 1, 256)), dim3(256), c.stream,
+                  (const int64_t*)m.ptr, m.rows, m.nnz, (int64_t)chunk, p.nchunks, p.chunk_row.as<int32_t>());
+        p.chunk = chunk;
+    }
+    if (p.hot_rows_budget != hot_rows) plan_hot_cold(p, m, hot_rows);
     return p;
 }
 
 template <typename T, int V, int LPN, int U>
 static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
-                          int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val)
+                          int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val,
+                          bool use_tags)
 {
     Context& c = ctx();
     const size_t per_wave = (spmm_wave_lds<T>(p.chunk) + 15) & ~size_t(15);
     const size_t lds = per_wave * SPMM_WAVES;
     const unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
-    MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz,
+    if constexpr (V * sizeof(T) == 16 && LPN >= 32) {
+        if (use_tags) {
+            MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, true>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows,
+                           m.nnz, (const int64_t*)m.ptr, (const int32_t*)p.col_tagged.as<int32_t>(), (const T*)m.val,
+                           (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C,
+                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_row, carry_val);
+            return;
+        }
+    }
+    MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, false>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz,
                    (const int64_t*)m.ptr, (const int32_t*)m.col, (const T*)m.val,
                    (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,
                    c_cs, N, alpha, beta, beta_zero, carry_row, carry_val);
@@ -332,18 +449,25 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
 
 template <typename T, int V, int LPN>
 static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
-                        int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val)
+                        int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val,
+                        bool use_tags)
 {
     // U = independent 16-byte loads in flight per lane.  The deeper variant exists for the 512-byte
     // row shapes of the headline configs only (keeps the instantiation count down).
     if constexpr (V > 1 && LPN >= 32) {
         if (options().spmm_unroll == 8) {
             launch_spmm_u<T, V, LPN, 8>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row,
-                                        carry_val);
+                                        carry_val, use_tags);
             return;
         }
     }
-    launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val);
+    launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val,
+                                use_tags);
+}
+
+static inline bool dense_bytes_below_4g(int64_t rows, int64_t ld, size_t elem)
+{
+    return (double)rows * (double)ld * (double)elem < 4294967296.0 * 0.99;
 }
 
 // Core executor on DEVICE pointers.  m is the CSR of op(A) (rows of m = rows of C).
@@ -368,7 +492,12 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         convert_layout<T>(m.rows, N, ct, ldt, 1, C, 1, ldc);
         return;
     }
-    const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk);
+    // hot-set budget in rows of B for this call's row width (row-major operands only)
+    int64_t hot_rows = 0;
+    if (layout == MI_SPARSE_LAYOUT_ROW_MAJOR && options().spmm_hot_kb > 0 &&
+        (N * (int64_t)sizeof(T) >= 512 || options().spmm_hot_force))
+        hot_rows = options().spmm_hot_kb * 1024 / (N * (int64_t)sizeof(T));
+    const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk, hot_rows);
     int32_t* carry_row = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)p.nchunks));
     T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)p.nchunks * (size_t)N));
     const bool row_major = (layout == MI_SPARSE_LAYOUT_ROW_MAJOR);
@@ -379,7 +508,11 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
                         ((ldb * (int64_t)sizeof(T)) % 16 == 0) && ((ldc * (int64_t)sizeof(T)) % 16 == 0) &&
                         ((reinterpret_cast<uintptr_t>(B) % 16) == 0) && ((reinterpret_cast<uintptr_t>(C) % 16) == 0) &&
                         ((reinterpret_cast<uintptr_t>(carry_val) % 16) == 0);
-#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val
+    // tagged (hot / cold) gather: needs 32-bit byte offsets into B
+    const bool use_tags = p.tagged && vec_ok && dense_bytes_below_4g(m.cols, ldb, sizeof(T));
+    counters().spmm_last_tagged = use_tags ? 1.0 : 0.0;
+    counters().spmm_hot_coverage = p.hot_coverage;
+#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val, use_tags
 #ifndef MI_HIP_EMU
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool prof = options().profile_events != 0;

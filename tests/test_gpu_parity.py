@@ -90,6 +90,39 @@ def test_spmm_skewed_rows_and_chunks(gpu, oracle, dtype, chunk):
     assert not got[:50].any() and not got[-70:].any()
 
 
+@pytest.mark.parametrize("dtype,n", [(np.float32, 128), (np.float32, 256), (np.float64, 64), (np.float64, 128),
+                                     (np.complex64, 64), (np.complex128, 32)])
+def test_spmm_hot_cold_tagged_gather(gpu, oracle, dtype, n):
+    """The hot / cold tagged gather (buffer loads, nt policy on cold columns) on a power-law column
+    distribution; forced on for a test-sized matrix.  Same values as the untagged path, bit for bit."""
+    rng = np.random.default_rng(17)
+    m, k = 3000, 4000
+    lens = rng.integers(0, 60, m)
+    p = 1.0 / np.arange(1, k + 1) ** 1.1
+    p /= p.sum()
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False, p=p)) for l in lens]).astype(np.int32)
+    data = rng.uniform(0.5, 1.5, indices.size)
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    if np.dtype(dtype).kind == "c":
+        data = data + 1j * rng.uniform(0.5, 1.5, indices.size)
+    a = sps.csr_matrix((data.astype(dtype), indices, indptr), shape=(m, k))
+    b = dense((k, n), dtype, 18)
+    plain = gpu.dot_product_mkl(a, b)
+    assert gpu.mi_get_counter("spmm_last_tagged") == 0.0
+    gpu.mi_set_option("spmm_hot_force", 1)
+    gpu.mi_set_option("spmm_hot_kb", 64)
+    try:
+        tagged = gpu.dot_product_mkl(a, b)
+        assert gpu.mi_get_counter("spmm_last_tagged") == 1.0
+        assert 0.0 < gpu.mi_get_counter("spmm_hot_coverage") < 1.0
+    finally:
+        gpu.mi_set_option("spmm_hot_force", 0)
+        gpu.mi_set_option("spmm_hot_kb", 8192)
+    assert np.array_equal(tagged, plain)  # cache policy must not change a single bit
+    assert rel_err(tagged, oracle.spmm(a.astype(wide), b.astype(wide))) <= tol(dtype)
+
+
 def test_spmm_determinism(gpu):
     a = pos_csr(4000, 3000, 0.02, np.float32, 5)
     b = dense((3000, 128), np.float32, 6)

@@ -5,7 +5,8 @@ import os
 import sys
 import traceback
 
-os.environ.setdefault("MI_SPARSE_RT", "/tmp/libmi_sparse_emu.so")
+if not os.environ.get("CHECK_GOLDEN_REAL"):  # default: the emulation build; CHECK_GOLDEN_REAL=1 replays on the real GPU library
+    os.environ.setdefault("MI_SPARSE_RT", "/tmp/libmi_sparse_emu.so")
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,7 +17,8 @@ import scipy.sparse as sps
 import golden_util as G
 import sparse_dot_amd as sda
 
-assert "EMULATED" in sda.mi_get_version_string(), sda.mi_get_version_string()
+print(sda.mi_get_version_string())
+assert os.environ.get("CHECK_GOLDEN_REAL") or "EMULATED" in sda.mi_get_version_string()
 prefix = sys.argv[1] if len(sys.argv) > 1 else None
 bad = n = 0
 for c in G.cases(prefix=prefix):
@@ -66,6 +68,10 @@ for c in G.cases(prefix=prefix):
             ok = got is out
     if not ok:
         print("MISMATCH", c["name"], type(got), getattr(got, "shape", None), getattr(got, "dtype", None))
+        if isinstance(got, np.ndarray) and isinstance(exp, np.ndarray) and got.shape == exp.shape:
+            d = np.abs(got - exp)
+            bad_idx = np.argwhere(d > 1e-4 * np.maximum(np.abs(exp), 1))
+            print("   max abs diff", d.max(), "n bad", len(bad_idx), "first bad", bad_idx[:6].tolist())
         bad += 1
 print("%d cases, %d bad" % (n, bad))
 sys.exit(1 if bad else 0)

@@ -146,8 +146,23 @@ inline T __shfl_xor(T v, int mask)
     return r;
 }
 
+template <typename T>
+inline T __shfl(T v, int src)
+{
+    static_assert(sizeof(T) <= 16, "shuffle payload too large");
+    hip_emu::WaveState& w = hip_emu::st().waves[hip_emu::t_tid / 64];
+    const int lane = hip_emu::t_tid % 64;
+    std::memcpy(w.slot[lane], &v, sizeof(T));
+    w.bar.arrive_and_wait();
+    T r = v;
+    if (src >= 0 && src < 64) std::memcpy(&r, w.slot[src], sizeof(T));
+    w.bar.arrive_and_wait();
+    return r;
+}
+
 // ---- atomics -------------------------------------------------------------------------------------
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 template <typename F>
 inline F emu_atomic_fadd(F* p, F v)
