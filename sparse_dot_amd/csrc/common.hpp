@@ -265,6 +265,10 @@ struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.h
     int chunk = 0;
     int64_t nchunks = 0;
     DevBuf chunk_row;  // int32[nchunks + 1]
+    // static fix-up schedule: one task per long row that is cut across chunks -- (row, first chunk,
+    // last chunk) whose carries are added, in chunk order, to the row its owner wrote
+    int64_t n_tasks = 0;
+    DevBuf tasks;  // int32[3 * n_tasks]
     // hot / cold column tagging (see spmm.hip): copy of the column indices with bit 31 set on
     // entries whose column is NOT in the hot set that is meant to stay L2 resident
     int64_t hot_rows_budget = -1;  // the budget (in B rows) the tags were computed for; -1 = never

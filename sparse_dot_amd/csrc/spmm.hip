@@ -64,6 +64,39 @@ constexpr int SPMM_WAVES = 4;  // waves per workgroup (independent of each other
 // it.  Only longer rows are cut at chunk boundaries and go through the carry / fix-up path.
 constexpr int SPMM_SPLIT = 128;
 
+// The long row (more than SPMM_SPLIT items) that chunk w cuts at its end and leaves a carry for, or
+// -1.  Must agree with the staging logic of k_spmm.
+__device__ __forceinline__ int32_t spmm_trail_row(const int64_t* ptr, const int32_t* chunk_row, int64_t rows,
+                                                  int64_t nnz, int64_t ch, int64_t w)
+{
+    const int64_t total = nnz + rows;
+    const int64_t s = w * ch;
+    const int64_t e = (s + ch < total) ? s + ch : total;
+    const int64_t rb = chunk_row[w + 1];
+    if (rb < rows && (ptr[rb] + rb) < e && (ptr[rb + 1] - ptr[rb] + 1) > SPMM_SPLIT) return (int32_t)rb;
+    return -1;
+}
+
+// one thread per chunk: the first chunk of every run of chunks that carry into the same row emits
+// the fix-up task (row, first chunk, last chunk)
+__global__ void k_spmm_plan_tasks(const int64_t* ptr, const int32_t* chunk_row, int64_t rows, int64_t nnz, int64_t ch,
+                                  int64_t nchunks, int32_t* tasks, unsigned long long* n_tasks)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nchunks) return;
+    const int32_t row = spmm_trail_row(ptr, chunk_row, rows, nnz, ch, w);
+    if (row < 0) return;
+    if (w > 0 && spmm_trail_row(ptr, chunk_row, rows, nnz, ch, w - 1) == row) return;
+    int64_t last = w;
+    while (last + 1 < nchunks && spmm_trail_row(ptr, chunk_row, rows, nnz, ch, last + 1) == row) ++last;
+    const unsigned long long t = atomicAdd(n_tasks, 1ull);
+    if (tasks) {
+        tasks[3 * t + 0] = row;
+        tasks[3 * t + 1] = (int32_t)w;
+        tasks[3 * t + 2] = (int32_t)last;
+    }
+}
+
 // one staged nonzero of A: column + value side by side so a lane group fetches both with ONE
 // LDS read (ds_read_b64 for float, ds_read_b128 for double / complex float)
 template <typename T>
@@ -92,7 +125,7 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
            const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
            const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
-           int64_t N, T alpha, T beta, int beta_zero, int32_t* __restrict__ carry_row, T* __restrict__ carry_val)
+           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val)
 {
     MI_DYN_SMEM(smem);
     constexpr int NG = WAVE / LPN;  // lane groups per wave, each on its own nonzero
@@ -270,39 +303,34 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
             }
         }
     }
-    if (lane == 0) carry_row[w] = has_trail ? (int32_t)(r0 + n_owned) : -1;
 }
 
-// add the carries of every cut row to the row its owner wrote; carries of one row are contiguous
-// chunks, summed in chunk order by the lane group of the first one.  LPN lanes x V values per
-// chunk (same shapes as the main kernel), so one 16-byte load + one 16-byte read-modify-write of
-// C per lane in the common single-carry case.
+// add the carries of every cut row to the row its owner wrote.  The schedule (which chunks carry
+// into which row) depends only on A and the chunk size, so it is precomputed in the plan: one lane
+// group per task sums that row's carries in chunk order (deterministic) and does one
+// read-modify-write of C.  LPN lanes x V values, the shapes of the main kernel.
 template <typename T, int V, int LPN>
 __global__ void __launch_bounds__(256)
-    k_spmm_fixup(int64_t nchunks, const int32_t* __restrict__ carry_row, const T* __restrict__ carry_val, int64_t N,
+    k_spmm_fixup(int64_t n_tasks, const int32_t* __restrict__ tasks, const T* __restrict__ carry_val, int64_t N,
                  T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t w = t / LPN;
+    const int64_t task = t / LPN;
     const int li = (int)(t % LPN);
-    if (w >= nchunks) return;
-    const int32_t row = carry_row[w];
-    const int32_t prev = (w > 0) ? carry_row[w - 1] : -1;
-    if (row < 0 || prev == row) return;  // no carry, or not the head of this row's run
-    int64_t last = w;
-    while (last + 1 < nchunks && carry_row[last + 1] == row) ++last;
+    if (task >= n_tasks) return;
+    const int64_t row = tasks[3 * task], first = tasks[3 * task + 1], last = tasks[3 * task + 2];
     for (int64_t jc = (int64_t)li * V; jc < N; jc += (int64_t)LPN * V) {
         T sum[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) sum[v] = vt<T>::zero();
-        for (int64_t u = w; u <= last; ++u) {
+        for (int64_t u = first; u <= last; ++u) {
             vec<T, V> cvv;
             if (V > 1) cvv = *reinterpret_cast<const vec<T, V>*>(carry_val + u * N + jc);
             else cvv.v[0] = carry_val[u * N + jc];
 #pragma unroll
             for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], cvv.v[v]);
         }
-        T* c = C + (int64_t)row * c_rs + jc * c_cs;
+        T* c = C + row * c_rs + jc * c_cs;
         if (V > 1) {
             vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(c);
 #pragma unroll
@@ -417,6 +445,24 @@ static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, in
         MI_LAUNCH(k_spmm_plan, dim3((unsigned)ceil_div(p.nchunks + 1, 256)), dim3(256), c.stream,
                   (const int64_t*)m.ptr, m.rows, m.nnz, (int64_t)chunk, p.nchunks, p.chunk_row.as<int32_t>());
         p.chunk = chunk;
+        // fix-up schedule: count, then fill
+        unsigned long long* d_n = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long)));
+        const dim3 tgrid((unsigned)ceil_div(p.nchunks, 256));
+        MI_HIP_CHECK(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c.stream));
+        MI_LAUNCH(k_spmm_plan_tasks, tgrid, dim3(256), c.stream, (const int64_t*)m.ptr,
+                  (const int32_t*)p.chunk_row.as<int32_t>(), m.rows, m.nnz, (int64_t)chunk, p.nchunks,
+                  (int32_t*)nullptr, d_n);
+        unsigned long long h_n = 0;
+        MI_HIP_CHECK(hipMemcpyAsync(&h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, c.stream));
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+        p.n_tasks = (int64_t)h_n;
+        p.tasks.alloc(sizeof(int32_t) * 3 * (size_t)(p.n_tasks + 1));
+        if (p.n_tasks) {
+            MI_HIP_CHECK(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c.stream));
+            MI_LAUNCH(k_spmm_plan_tasks, tgrid, dim3(256), c.stream, (const int64_t*)m.ptr,
+                      (const int32_t*)p.chunk_row.as<int32_t>(), m.rows, m.nnz, (int64_t)chunk, p.nchunks,
+                      p.tasks.as<int32_t>(), d_n);
+        }
     }
     if (p.hot_rows_budget != hot_rows) plan_hot_cold(p, m, hot_rows);
     return p;
@@ -424,7 +470,7 @@ static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, in
 
 template <typename T, int V, int LPN, int U>
 static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
-                          int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val,
+                          int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
                           bool use_tags)
 {
     Context& c = ctx();
@@ -437,32 +483,31 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
             MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, true>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows,
                            m.nnz, (const int64_t*)m.ptr, (const int32_t*)p.col_tagged.as<int32_t>(), (const T*)m.val,
                            (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C,
-                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_row, carry_val);
+                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_val);
             return;
         }
     }
     MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, false>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz,
                    (const int64_t*)m.ptr, (const int32_t*)m.col, (const T*)m.val,
                    (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,
-                   c_cs, N, alpha, beta, beta_zero, carry_row, carry_val);
+                   c_cs, N, alpha, beta, beta_zero, carry_val);
 }
 
 template <typename T, int V, int LPN>
 static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
-                        int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, int32_t* carry_row, T* carry_val,
+                        int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
                         bool use_tags)
 {
     // U = independent 16-byte loads in flight per lane.  The deeper variant exists for the 512-byte
     // row shapes of the headline configs only (keeps the instantiation count down).
     if constexpr (V > 1 && LPN >= 32) {
         if (options().spmm_unroll == 8) {
-            launch_spmm_u<T, V, LPN, 8>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row,
-                                        carry_val, use_tags);
+            launch_spmm_u<T, V, LPN, 8>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val,
+                                        use_tags);
             return;
         }
     }
-    launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val,
-                                use_tags);
+    launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, use_tags);
 }
 
 static inline bool dense_bytes_below_4g(int64_t rows, int64_t ld, size_t elem)
@@ -498,7 +543,6 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         (N * (int64_t)sizeof(T) >= 512 || options().spmm_hot_force))
         hot_rows = options().spmm_hot_kb * 1024 / (N * (int64_t)sizeof(T));
     const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk, hot_rows);
-    int32_t* carry_row = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)p.nchunks));
     T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)p.nchunks * (size_t)N));
     const bool row_major = (layout == MI_SPARSE_LAYOUT_ROW_MAJOR);
     const int64_t b_rs = row_major ? ldb : 1, b_cs = row_major ? 1 : ldb;
@@ -512,7 +556,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     const bool use_tags = p.tagged && vec_ok && dense_bytes_below_4g(m.cols, ldb, sizeof(T));
     counters().spmm_last_tagged = use_tags ? 1.0 : 0.0;
     counters().spmm_hot_coverage = p.hot_coverage;
-#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_row, carry_val, use_tags
+#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, use_tags
 #ifndef MI_HIP_EMU
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool prof = options().profile_events != 0;
@@ -546,16 +590,19 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         (void)hipEventDestroy(ev1);
     }
 #endif
-    if (vec_ok) {
-        if (N / V16 > 16)
-            MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)ceil_div(p.nchunks * 32, 256)), dim3(256), c.stream,
-                      p.nchunks, (const int32_t*)carry_row, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
-        else
-            MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)ceil_div(p.nchunks * 8, 256)), dim3(256), c.stream,
-                      p.nchunks, (const int32_t*)carry_row, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
-    } else {
-        MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(p.nchunks * 16, 256)), dim3(256), c.stream,
-                  p.nchunks, (const int32_t*)carry_row, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+    if (p.n_tasks) {
+        const int32_t* tk = p.tasks.as<int32_t>();
+        if (vec_ok) {
+            if (N / V16 > 16)
+                MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)ceil_div(p.n_tasks * 32, 256)), dim3(256), c.stream,
+                          p.n_tasks, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+            else
+                MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)ceil_div(p.n_tasks * 8, 256)), dim3(256), c.stream,
+                          p.n_tasks, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+        } else {
+            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(p.n_tasks * 16, 256)), dim3(256), c.stream,
+                      p.n_tasks, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+        }
     }
 }
 
