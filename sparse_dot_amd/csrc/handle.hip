@@ -244,6 +244,17 @@ __global__ void k_sort_classify(const int64_t* ptr, int64_t rows, int64_t* n_med
     }
 }
 
+__global__ void k_big_row_sizes(const int64_t* ptr, const int64_t* rows_list, int64_t n, int64_t* sizes)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = rows_list[i];
+    const int64_t len = ptr[r + 1] - ptr[r];
+    int64_t p2 = 2;
+    while (p2 < len) p2 <<= 1;
+    sizes[i] = p2;
+}
+
 template <typename T>
 __global__ void k_gather_vals(const T* in, const int64_t* perm, int64_t nnz, T* out)
 {
@@ -315,28 +326,15 @@ void sort_csr(char vtype, Csr& a)
             MI_LAUNCH(k_sort_block, dim3((unsigned)n_med), dim3(256), c.stream, (const int64_t*)a.ptr, a.col,
                       (const int64_t*)med_rows, perm);
         if (n_big) {
-            // slab offsets computed on the host (few rows)
-            std::vector<int64_t> hrows((size_t)n_big), hptr((size_t)a.rows + 1);
-            MI_HIP_CHECK(hipMemcpyAsync(hrows.data(), big_rows, sizeof(int64_t) * (size_t)n_big,
-                                        hipMemcpyDeviceToHost, c.stream));
-            MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-            std::vector<int64_t> off((size_t)n_big);
-            int64_t total = 0;
-            for (int64_t k = 0; k < n_big; ++k) {
-                int64_t pr[2];
-                MI_HIP_CHECK(hipMemcpy(pr, a.ptr + hrows[(size_t)k], sizeof(pr), hipMemcpyDeviceToHost));
-                int64_t n = 2;
-                while (n < pr[1] - pr[0]) n <<= 1;
-                off[(size_t)k] = total;
-                total += n;
-            }
-            int64_t* doff = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)n_big));
+            // slab sizes (pow2-padded row lengths) and their offsets, computed on the device
+            int64_t* sizes = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
+            int64_t* doff = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
+            MI_LAUNCH(k_big_row_sizes, grid1d(n_big, 256), dim3(256), c.stream, (const int64_t*)a.ptr,
+                      (const int64_t*)big_rows, n_big, sizes);
+            const int64_t total = exclusive_scan_i64(sizes, doff, n_big);
             uint64_t* slabs = static_cast<uint64_t*>(c.scratch_alloc(sizeof(uint64_t) * (size_t)total));
-            MI_HIP_CHECK(hipMemcpyAsync(doff, off.data(), sizeof(int64_t) * (size_t)n_big, hipMemcpyHostToDevice,
-                                        c.stream));
             MI_LAUNCH(k_sort_global, dim3((unsigned)n_big), dim3(1024), c.stream, (const int64_t*)a.ptr, a.col,
                       (const int64_t*)big_rows, (const int64_t*)doff, slabs, perm);
-            MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // `off` / staging buffers go out of scope
         }
     }
     // permute values through a temporary

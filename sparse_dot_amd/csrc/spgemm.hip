@@ -47,13 +47,27 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---- binning -------------------------------------------------------------------------------------
-constexpr int NBINS = 5;                       // 0: <=32  1: <=128  2: <=512  3: <=2048  4: larger (global)
+// bins 0-3: LDS tables (<=32, <=128, <=512, <=2048).  Bins 4..NBINS-1: rows for the global-memory
+// hash, classed by ceil(log2(count)) (4: <=4096, 5: <=8192, ... last: everything larger) so the
+// persistent kernel can take them largest first (longest-processing-time-first scheduling).
+constexpr int NLDSBINS = 4;
+constexpr int NBINS = 18;
 __host__ __device__ inline int bin_of(int64_t c)
 {
-    return c <= 32 ? 0 : c <= 128 ? 1 : c <= 512 ? 2 : c <= 2048 ? 3 : 4;
+    if (c <= 32) return 0;
+    if (c <= 128) return 1;
+    if (c <= 512) return 2;
+    if (c <= 2048) return 3;
+    int b = 4;
+    int64_t lim = 4096;
+    while (c > lim && b < NBINS - 1) {
+        lim <<= 1;
+        ++b;
+    }
+    return b;
 }
 
-// counts per bin (rows with c == 0 are skipped); when `lists` != nullptr also scatters the row ids.
+// counts per bin (rows with c == 0 are skipped; NBINS <= blockDim); when `lists` != nullptr also scatters the row ids.
 // One global atomic per (workgroup, bin): positions inside the workgroup come from LDS counters.
 __global__ void __launch_bounds__(256)
     k_bin_rows(int64_t rows, const int64_t* __restrict__ cnt, int64_t* __restrict__ bin_counts,
@@ -161,14 +175,21 @@ __global__ void __launch_bounds__(1024)
                     const T* __restrict__ aval, const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol,
                     const T* __restrict__ bval, int gw, int upper, int32_t* slab_keys, T* slab_vals, int64_t slab,
                     int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
-                    T* __restrict__ cval)
+                    T* __restrict__ cval, unsigned long long* work_counter)
 {
     __shared__ int counter;
+    __shared__ long long next_idx;
     const int tid = threadIdx.x;
     const int threads = blockDim.x;
     int32_t* keys = slab_keys + (int64_t)blockIdx.x * slab;
     T* vals = NUMERIC ? slab_vals + (int64_t)blockIdx.x * slab : nullptr;
-    for (int64_t idx = blockIdx.x; idx < nbig; idx += gridDim.x) {
+    for (;;) {
+        // rows are listed largest class first; workgroups pull the next one when they are free
+        __syncthreads();
+        if (tid == 0) next_idx = (long long)atomicAdd(work_counter, 1ull);
+        __syncthreads();
+        const int64_t idx = next_idx;
+        if (idx >= nbig) break;
         const int32_t row = row_list[idx];
         int64_t c = cnt[row];
         if (c > ncols) c = ncols;
@@ -272,8 +293,8 @@ __global__ void k_fill_dense(T* C, int64_t r, int64_t cdim, int64_t c_rs, int64_
 // host side
 // ------------------------------------------------------------------------------------------------
 struct Bins {
-    int64_t n[NBINS] = {0, 0, 0, 0, 0};
-    int32_t* list[NBINS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t n[NBINS] = {};
+    int32_t* list[NBINS] = {};
 };
 
 static Bins make_bins(const int64_t* cnt, int64_t rows)
@@ -332,25 +353,53 @@ static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt
         if (b.n[3])
             MI_LAUNCH((k_spgemm_lds<T, 12, 256, NUMERIC>), dim3((unsigned)b.n[3]), dim3(256), c.stream,
                       MI_SPGEMM_ARGS(b.list[3]), gw, (int)upper, row_nnz, cptr, ccol, cval);
+        // class 4 (<= 4096): 8192-slot table -- 32 KiB of keys + up to 64 KiB of values
+        if constexpr (!NUMERIC || sizeof(T) <= 8) {
+            if (b.n[4]) {
+                MI_LAUNCH((k_spgemm_lds<T, 13, 1024, NUMERIC>), dim3((unsigned)b.n[4]), dim3(1024), c.stream,
+                          MI_SPGEMM_ARGS(b.list[4]), gw, (int)upper, row_nnz, cptr, ccol, cval);
+                b.n[4] = 0;
+            }
+        }
+        // class 5 (<= 8192): keys only fit (symbolic phase): 16384-slot table = 64 KiB
+        if constexpr (!NUMERIC) {
+            if (b.n[5]) {
+                MI_LAUNCH((k_spgemm_lds<T, 14, 1024, NUMERIC>), dim3((unsigned)b.n[5]), dim3(1024), c.stream,
+                          MI_SPGEMM_ARGS(b.list[5]), gw, (int)upper, row_nnz, cptr, ccol, cval);
+                b.n[5] = 0;
+            }
+        }
     }
-    for (int k = 0; k < NBINS; ++k) {
-        if (!b.n[k] || (!force_global && k < NBINS - 1)) continue;
-        // slab = table size of the largest row: next pow2 >= 2 * min(max_cnt, cols)
-        int64_t cap = max_cnt < B.cols ? max_cnt : B.cols;
-        int64_t slab = 4;
-        while (slab < 2 * cap) slab <<= 1;
-        int64_t nblocks = b.n[k] < 512 ? b.n[k] : 512;
-        // keep the slabs under ~4 GiB
-        const size_t per = (size_t)slab * (sizeof(int32_t) + (NUMERIC ? sizeof(T) : 0));
-        while (nblocks > 1 && per * (size_t)nblocks > (size_t(4) << 30)) nblocks >>= 1;
-        DevBuf kbuf, vbuf;
-        kbuf.alloc(sizeof(int32_t) * (size_t)slab * (size_t)nblocks);
-        if (NUMERIC) vbuf.alloc(sizeof(T) * (size_t)slab * (size_t)nblocks);
-        MI_LAUNCH((k_spgemm_global<T, NUMERIC>), dim3((unsigned)nblocks), dim3(1024), c.stream, b.n[k],
-                  (const int32_t*)b.list[k], cnt, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
-                  (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val, gw, (int)upper,
-                  kbuf.as<int32_t>(), vbuf.as<T>(), slab, row_nnz, cptr, ccol, cval);
-        MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // slabs are freed on scope exit
+    // global-memory hash: every class that did not go to an LDS bin, largest class first.  One launch
+    // per size class so that tables (cleared and compacted per row) and workgroups are sized for
+    // the class: many small workgroups for the mid-size rows, few large ones for the hub rows.
+    {
+        const int first = force_global ? 0 : NLDSBINS;
+        static const int64_t lds_limits[NLDSBINS] = {32, 128, 512, 2048};
+        for (int k = NBINS - 1; k >= first; --k) {
+            if (!b.n[k]) continue;
+            int64_t limit = (k < NLDSBINS) ? lds_limits[k] : ((int64_t)4096 << (k - NLDSBINS));
+            if (k == NBINS - 1 || limit > max_cnt) limit = max_cnt;
+            const int64_t cap = limit < B.cols ? limit : B.cols;
+            int64_t slab = 4;
+            while (slab < 2 * cap) slab <<= 1;
+            const int threads = cap <= 16384 ? 256 : cap <= 131072 ? 512 : 1024;
+            int64_t nblocks = (int64_t)256 * (2048 / threads);
+            if (nblocks > b.n[k]) nblocks = b.n[k];
+            const size_t per = (size_t)slab * (sizeof(int32_t) + (NUMERIC ? sizeof(T) : 0));
+            while (nblocks > 1 && per * (size_t)nblocks > (size_t(4) << 30)) nblocks >>= 1;  // <= 4 GiB of slabs
+            unsigned long long* work = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long)));
+            MI_HIP_CHECK(hipMemsetAsync(work, 0, sizeof(unsigned long long), c.stream));
+            DevBuf kbuf, vbuf;
+            kbuf.alloc(sizeof(int32_t) * (size_t)slab * (size_t)nblocks);
+            if (NUMERIC) vbuf.alloc(sizeof(T) * (size_t)slab * (size_t)nblocks);
+            MI_LAUNCH((k_spgemm_global<T, NUMERIC>), dim3((unsigned)nblocks), dim3(threads), c.stream, b.n[k],
+                      (const int32_t*)b.list[k], cnt, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
+                      (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val,
+                      gw > threads ? threads : gw, (int)upper, kbuf.as<int32_t>(), vbuf.as<T>(), slab, row_nnz, cptr,
+                      ccol, cval, work);
+            MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // slabs are freed on scope exit
+        }
     }
 #undef MI_SPGEMM_ARGS
     MI_HIP_CHECK(hipGetLastError());

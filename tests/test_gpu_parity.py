@@ -309,7 +309,7 @@ def test_spgemm_all_bins(gpu, oracle, dtype):
     k, n = 3000, 5000
     b = pos_csr(k, n, 0.004, dtype, 72)          # ~20 nnz per row of B
     lens = np.concatenate([rng.integers(0, 2, 300), rng.integers(2, 12, 300), rng.integers(20, 90, 100),
-                           [400, 900, 1500], rng.integers(0, 3, 50)])
+                           [150, 170, 300, 330, 400, 900, 1500], rng.integers(0, 3, 50)])
     m = lens.size
     indptr = np.concatenate([[0], np.cumsum(lens)])
     indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
@@ -437,6 +437,22 @@ def test_dense_gemm_is_transpose_detecting(gpu):
         b = np.arange(70 * 90, dtype=dtype).reshape(70, 90)
         got = gpu.dot_product_mkl(np.eye(70, dtype=dtype), b)
         assert np.array_equal(got, b)
+
+
+def test_config1_reference_cpu_case(gpu, oracle):
+    """BASELINE configs[0]: scipy.sparse.random CSR 10k x 10k density 0.01 fp64 x dense 10k x 64 through
+    the public API with host arrays (the reference's own CPU-runnable case), fp64 within 1e-12 of the
+    oracle and of scipy."""
+    a = sps.random(10000, 10000, density=0.01, format="csr", dtype=np.float64, random_state=0)
+    b = np.random.default_rng(1).random((10000, 64))
+    got = gpu.dot_product_mkl(a, b)
+    want = oracle.spmm(a, b)
+    assert got.shape == (10000, 64) and got.dtype == np.float64 and got.flags.c_contiguous
+    assert rel_err(got, want) <= F64_TOL
+    assert rel_err(got, a @ b) <= F64_TOL
+    out = np.ones_like(got)
+    assert gpu.dot_product_mkl(a, b, out=out, out_scalar=0.5) is out
+    assert rel_err(out, want + 0.5) <= F64_TOL
 
 
 # ---- properties at BASELINE config-2 scale ------------------------------------------------------------------

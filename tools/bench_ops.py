@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--cols", type=int, default=16384)
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--force-global", action="store_true", help="SpGEMM: send every row through the global-memory hash")
     args = ap.parse_args()
 
     import torch
@@ -42,6 +43,8 @@ def main():
 
     dev = torch.device("cuda", 0)
     sda.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.force_global:
+        sda.mi_set_option("spgemm_force_global", 1)
 
     def make(kind, n_rows_log2, ncols, per_row, seed, dtype):
         if kind == "rmat":
