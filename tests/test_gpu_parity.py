@@ -518,3 +518,113 @@ def test_config2_scale_properties(gpu):
         if h:
             MI.call("mi_sparse_destroy", h)
         gpu.mi_set_stream(0)
+
+
+def _uniform_csr_torch(torch, dev, n_rows, n_cols, per_row, seed, dtype):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rows = torch.arange(n_rows, device=dev, dtype=torch.int64).repeat_interleave(per_row)
+    cols = torch.randint(0, n_cols, (n_rows * per_row,), generator=g, device=dev, dtype=torch.int64)
+    key = torch.unique(rows * n_cols + cols)
+    idx = (key % n_cols).to(torch.int32)
+    ip = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    ip[1:] = torch.cumsum(torch.bincount(key // n_cols, minlength=n_rows), 0)
+    val = (torch.rand(idx.numel(), generator=g, device=dev, dtype=torch.float64) + 0.5).to(dtype)
+    return ip.to(torch.int32), idx, val
+
+
+def test_config3_scale_properties(gpu):
+    """BASELINE configs[2] shape (uniform variant): two CSR 2^20 x 2^20, 16 nnz/row, fp64, device resident.
+    Size-independent checks: C 1 = A (B 1) to 1e-12; nnz(C) <= #products; after mi_sparse_order every row
+    of the exported C is strictly increasing (no duplicate columns) and every value is positive."""
+    torch = pytest.importorskip("torch")
+    from sparse_dot_amd._mi_interface import MI, SparseHandle, matrix_descr, sparse_matrix_t, _check_return_value
+    dev = torch.device("cuda", 0)
+    n = 1 << 20
+    a = _uniform_csr_torch(torch, dev, n, n, 16, 1, torch.float64)
+    b = _uniform_csr_torch(torch, dev, n, n, 16, 2, torch.float64)
+    gpu.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+    handles = []
+    try:
+        def mk(t):
+            h = sparse_matrix_t()
+            _check_return_value(MI.call("mi_sparse_d_create_csr", ct.byref(h), 0, n, n, t[0].data_ptr(), t[0].data_ptr() + 4,
+                                        t[1].data_ptr(), t[2].data_ptr()), "create")
+            handles.append(h)
+            return h
+        ha, hb = mk(a), mk(b)
+        hc = sparse_matrix_t()
+        _check_return_value(MI.call("mi_sparse_spmm", 10, ha, hb, ct.byref(hc)), "spmm")
+        handles.append(hc)
+
+        def mv(h, x, y):
+            _check_return_value(MI.call("mi_sparse_d_mv", 10, 1.0, h, matrix_descr(), x.data_ptr(), 0.0, y.data_ptr()), "mv")
+        ones = torch.ones(n, device=dev, dtype=torch.float64)
+        b1, ab1, c1 = (torch.empty(n, device=dev, dtype=torch.float64) for _ in range(3))
+        mv(hb, ones, b1)
+        mv(ha, b1, ab1)
+        mv(hc, ones, c1)
+        torch.cuda.synchronize()
+        assert float(((c1 - ab1).abs() / ab1.abs().clamp(min=1e-300)).max()) <= F64_TOL
+        products = float((torch.bincount(a[1].long(), minlength=n).double() * (b[0][1:] - b[0][:-1]).double()).sum())
+        wrapped = SparseHandle(hc, "d")
+        handles.remove(hc)
+        rows, cols, nnz, letter, _ = wrapped.info()
+        assert (rows, cols, letter) == (n, n, "d") and 0 < nnz <= products
+        assert nnz > 2.6e8  # ~2.68e8 for these seeds: almost no collisions at this density
+        wrapped.order()
+        c = wrapped.export("csr_matrix")
+        wrapped.destroy()
+        assert c.nnz == nnz and c.indptr[0] == 0 and c.indptr[-1] == nnz and np.all(np.diff(c.indptr) >= 0)
+        d = np.diff(c.indices.astype(np.int64))
+        row_starts = c.indptr[1:-1]
+        row_starts = row_starts[(row_starts > 0) & (row_starts < nnz)]
+        inside = np.ones(nnz - 1, dtype=bool)
+        inside[row_starts - 1] = False          # pairs that straddle a row boundary
+        assert np.all(d[inside] > 0), "columns inside a row must be strictly increasing after order()"
+        assert c.data.min() > 0.0
+    finally:
+        for h in handles:
+            MI.call("mi_sparse_destroy", h)
+        gpu.mi_set_stream(0)
+
+
+def test_config4_scaled_gram_properties(gpu):
+    """BASELINE configs[3], scaled (the literal 4 M x 256 k dense output is 262 GB): uniform 2^20 x 16384,
+    64 nnz/row, fp32, dense=True on device.  Checks: diag(C) = column sums of A.^2; sampled entries equal
+    the dot product of the two columns (float64 reference); strict lower triangle untouched; and the same
+    call through beta = 1 doubles the upper triangle."""
+    torch = pytest.importorskip("torch")
+    from sparse_dot_amd._mi_interface import MI, sparse_matrix_t, _check_return_value
+    dev = torch.device("cuda", 0)
+    m, n = 1 << 20, 16384
+    ip, idx, val = _uniform_csr_torch(torch, dev, m, n, 64, 3, torch.float32)
+    gpu.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+    h = sparse_matrix_t()
+    try:
+        _check_return_value(MI.call("mi_sparse_s_create_csr", ct.byref(h), 0, m, n, ip.data_ptr(), ip.data_ptr() + 4,
+                                    idx.data_ptr(), val.data_ptr()), "create")
+        C = torch.full((n, n), -7.0, device=dev, dtype=torch.float32)
+        _check_return_value(MI.call("mi_sparse_s_syrkd", 11, h, 1.0, 0.0, C.data_ptr(), 101, n), "syrkd")
+        torch.cuda.synchronize()
+        colsq = torch.zeros(n, device=dev, dtype=torch.float64)
+        colsq.index_add_(0, idx.long(), val.double() ** 2)
+        assert float(((torch.diagonal(C).double() - colsq).abs() / colsq).max()) <= F32_TOL
+        assert bool((torch.tril(C, -1) == torch.tril(torch.full_like(C, -7.0), -1)).all())  # never touched
+        # sampled off-diagonal entries against float64 column dot products (scipy on the host)
+        a_host = sps.csr_matrix((val.cpu().numpy().astype(np.float64), idx.cpu().numpy(), ip.cpu().numpy()), shape=(m, n)).tocsc()
+        rng = np.random.default_rng(0)
+        for _ in range(40):
+            i, j = sorted(rng.integers(0, n, 2).tolist())
+            want = float(a_host[:, [i]].multiply(a_host[:, [j]]).sum())
+            got = float(C[i, j])
+            assert abs(got - want) <= F32_TOL * max(abs(want), 1e-30) + 1e-30 or (want == 0 and got == 0), (i, j, got, want)
+        upper = torch.triu(C).clone()
+        _check_return_value(MI.call("mi_sparse_s_syrkd", 11, h, 1.0, 1.0, C.data_ptr(), 101, n), "syrkd")
+        torch.cuda.synchronize()
+        rel = ((torch.triu(C) - 2 * upper).abs() / (2 * upper).abs().clamp(min=1e-30)).max()
+        assert float(rel) <= 4 * F32_TOL
+    finally:
+        if h:
+            MI.call("mi_sparse_destroy", h)
+        gpu.mi_set_stream(0)
