@@ -331,6 +331,7 @@ struct Options {
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;
+    int64_t spgemm_global_mode = 0;  // 0: one workgroup per row, L2-local atomics; 1: cooperative, agent-scope atomics
     int64_t profile_events = 0;    // bracket the SpMM main kernel with hipEvents (diagnostics)
 };
 struct Counters {

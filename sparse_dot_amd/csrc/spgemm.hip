@@ -168,6 +168,41 @@ __device__ __forceinline__ T load_l2(const T* p)
 #endif
 }
 
+// Atomics on a table that only ONE workgroup touches while it is live: workgroup scope is formally
+// sufficient and lets the operation complete in the XCD's L2; the default (agent scope) atomics
+// are performed at the memory side of the fabric so that all eight XCDs agree, which is an order
+// of magnitude slower.  The table is cleared before / read back after with L1-bypassing accesses.
+__device__ __forceinline__ int32_t cas_wg(int32_t* p, int32_t expected, int32_t desired)
+{
+#ifdef MI_HIP_EMU
+    return atomicCAS(p, expected, desired);
+#else
+    __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+    return expected;
+#endif
+}
+template <typename R>
+__device__ __forceinline__ void add_wg(R* p, R x)
+{
+#ifdef MI_HIP_EMU
+    atomicAdd(p, x);
+#else
+    __hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void accum_wg(T* p, T x)
+{
+    add_wg(p, x);
+}
+template <typename R>
+__device__ __forceinline__ void accum_wg(cx<R>* p, cx<R> x)
+{
+    add_wg(&p->re, x.re);
+    add_wg(&p->im, x.im);
+}
+
 template <typename T, bool NUMERIC>
 __global__ void __launch_bounds__(1024)
     k_spgemm_global(int64_t nbig, const int32_t* __restrict__ row_list, const int64_t* __restrict__ cnt,
@@ -215,9 +250,9 @@ __global__ void __launch_bounds__(1024)
                 if (upper && j < row) continue;
                 uint32_t h = hash_col(j, log2s);
                 for (;;) {
-                    const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, j);
+                    const int32_t old = cas_wg(&keys[h], HASH_EMPTY, j);
                     if (old == HASH_EMPTY || old == j) {
-                        if (NUMERIC) atomic_accum(&vals[h], vt<T>::mul(a, bval[q]));
+                        if (NUMERIC) accum_wg(&vals[h], vt<T>::mul(a, bval[q]));
                         else if (old == HASH_EMPTY) ++local;
                         break;
                     }
@@ -254,6 +289,128 @@ __global__ void __launch_bounds__(1024)
                 }
             }
             __syncthreads();
+        }
+    }
+}
+
+// Global-memory hash for the rows beyond the LDS bins, cooperative form: the tables of a whole batch
+// of rows (one 2^log2s-slot table per row, cleared with memsets) live in a workspace, and the work
+// is split by (row, slice of 64 A-nonzeros), so the hub rows of power-law matrices are spread over
+// hundreds of workgroups instead of serialising on one.  L2 atomics make concurrent insertion into
+// one table safe.  Symbolic: first insertions are counted per workgroup and added to row_nnz.
+constexpr int GINS_THREADS = 256;
+constexpr int GINS_ENTRIES = 64;  // A-nonzeros per workgroup
+
+template <typename T, bool NUMERIC>
+__global__ void __launch_bounds__(GINS_THREADS)
+    k_spgemm_ginsert(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
+                     const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
+                     const int32_t* __restrict__ bcol, const T* __restrict__ bval, int gw, int upper, int32_t* keys_all,
+                     T* vals_all, int log2s, unsigned long long* __restrict__ row_nnz,
+                     const int64_t* __restrict__ item_off, int64_t nb)
+{
+    __shared__ int found;
+    const int tid = threadIdx.x;
+    // work item -> (row of the batch, slice of its A-nonzeros): item_off is the exclusive scan of the
+    // rows' slice counts
+    const int64_t item = blockIdx.x;
+    int64_t lo = 0, hi = nb;  // largest t with item_off[t] <= item
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (item_off[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int64_t t = lo;
+    const int32_t row = row_list[t];
+    const int64_t e0 = aptr[row] + (item - item_off[t]) * GINS_ENTRIES;
+    int64_t e1 = aptr[row + 1];
+    if (e0 + GINS_ENTRIES < e1) e1 = e0 + GINS_ENTRIES;
+    if (!NUMERIC) {
+        if (tid == 0) found = 0;
+        __syncthreads();
+    }
+    const int64_t S = (int64_t)1 << log2s;
+    int32_t* keys = keys_all + t * S;
+    T* vals = NUMERIC ? vals_all + t * S : nullptr;
+    const int group = tid / gw, ngroups = GINS_THREADS / gw, gl = tid % gw;
+    int local = 0;
+    for (int64_t p = e0 + group; p < e1; p += ngroups) {
+        const int32_t kk = acol[p];
+        T a = vt<T>::zero();
+        if (NUMERIC) a = aval[p];
+        const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
+        for (int64_t q = b0 + gl; q < b1; q += gw) {
+            const int32_t j = bcol[q];
+            if (upper && j < row) continue;
+            uint32_t h = hash_col(j, log2s);
+            for (;;) {
+                const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, j);
+                if (old == HASH_EMPTY || old == j) {
+                    if (NUMERIC) atomic_accum(&vals[h], vt<T>::mul(a, bval[q]));
+                    else if (old == HASH_EMPTY) ++local;
+                    break;
+                }
+                h = (h + 1) & (uint32_t)(S - 1);
+            }
+        }
+    }
+    if (!NUMERIC) {
+        if (local) atomicAdd(&found, local);
+        __syncthreads();
+        if (tid == 0 && found) atomicAdd(&row_nnz[row], (unsigned long long)found);
+    }
+}
+
+__global__ void k_gins_items(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr, int64_t nb,
+                             int64_t* __restrict__ items)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb) return;
+    const int32_t row = row_list[t];
+    items[t] = (aptr[row + 1] - aptr[row] + GINS_ENTRIES - 1) / GINS_ENTRIES;
+}
+
+// compaction of a batch of tables into C: workgroup (slice of 4096 slots, row); positions inside a row
+// come from a per-row cursor (one atomic per workgroup), so the column order is arbitrary
+constexpr int GCOMP_SLOTS = 4096;
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_spgemm_gcompact(const int32_t* __restrict__ row_list, const int32_t* keys_all, const T* vals_all, int log2s,
+                      unsigned long long* __restrict__ cursor, const int64_t* __restrict__ cptr,
+                      int32_t* __restrict__ ccol, T* __restrict__ cval)
+{
+    __shared__ int count;
+    __shared__ long long base;
+    const int tid = threadIdx.x;
+    const int64_t t = blockIdx.y;
+    const int64_t S = (int64_t)1 << log2s;
+    const int64_t k0 = (int64_t)blockIdx.x * GCOMP_SLOTS;
+    if (k0 >= S) return;
+    const int32_t* keys = keys_all + t * S;
+    const T* vals = vals_all + t * S;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    constexpr int PER = GCOMP_SLOTS / 256;
+    int32_t key[PER];
+    int pos[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t k = k0 + tid + (int64_t)u * 256;
+        key[u] = (k < S) ? keys[k] : HASH_EMPTY;  // written by an earlier kernel: plain loads are safe
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) pos[u] = (key[u] != HASH_EMPTY) ? atomicAdd(&count, 1) : -1;
+    __syncthreads();
+    if (tid == 0 && count) base = (long long)atomicAdd(&cursor[t], (unsigned long long)count);
+    __syncthreads();
+    if (!count) return;
+    const int32_t row = row_list[t];
+    const int64_t out0 = cptr[row] + base;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (pos[u] >= 0) {
+            const int64_t k = k0 + tid + (int64_t)u * 256;
+            ccol[out0 + pos[u]] = key[u];
+            cval[out0 + pos[u]] = vals[k];
         }
     }
 }
@@ -328,6 +485,51 @@ static int pick_gw(const Csr& B)
     return gw;
 }
 
+__global__ void k_max_i64(const int64_t* in, int64_t n, int64_t* out)
+{
+    __shared__ int64_t red[256];
+    int64_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (in[i] > m) m = in[i];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off && red[threadIdx.x + off] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax((long long*)out, (long long)red[0]);
+}
+
+static int64_t device_max(const int64_t* in, int64_t n)
+{
+    Context& c = ctx();
+    int64_t* d = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t)));
+    MI_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(int64_t), c.stream));
+    if (n > 0) {
+        const int64_t blocks = ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024;
+        MI_LAUNCH(k_max_i64, dim3((unsigned)blocks), dim3(256), c.stream, in, n, d);
+    }
+    int64_t h = 0;
+    MI_HIP_CHECK(hipMemcpyAsync(&h, d, sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return h;
+}
+
+__global__ void k_row_len(const int64_t* ptr, int64_t rows, int64_t* len)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) len[i] = ptr[i + 1] - ptr[i];
+}
+
+static int64_t device_max_row_len(const Csr& A)
+{
+    if (A.rows == 0) return 0;
+    Context& c = ctx();
+    int64_t* len = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)A.rows));
+    MI_LAUNCH(k_row_len, dim3((unsigned)ceil_div(A.rows, 256)), dim3(256), c.stream, (const int64_t*)A.ptr, A.rows, len);
+    return device_max(len, A.rows);
+}
+
 template <typename T, bool NUMERIC>
 static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt, int64_t max_cnt, int64_t* row_nnz,
                       const int64_t* cptr, int32_t* ccol, T* cval)
@@ -370,69 +572,100 @@ static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt
             }
         }
     }
-    // global-memory hash: every class that did not go to an LDS bin, largest class first.  One launch
-    // per size class so that tables (cleared and compacted per row) and workgroups are sized for
-    // the class: many small workgroups for the mid-size rows, few large ones for the hub rows.
-    {
-        const int first = force_global ? 0 : NLDSBINS;
-        static const int64_t lds_limits[NLDSBINS] = {32, 128, 512, 2048};
-        for (int k = NBINS - 1; k >= first; --k) {
-            if (!b.n[k]) continue;
-            int64_t limit = (k < NLDSBINS) ? lds_limits[k] : ((int64_t)4096 << (k - NLDSBINS));
-            if (k == NBINS - 1 || limit > max_cnt) limit = max_cnt;
-            const int64_t cap = limit < B.cols ? limit : B.cols;
-            int64_t slab = 4;
-            while (slab < 2 * cap) slab <<= 1;
-            const int threads = cap <= 16384 ? 256 : cap <= 131072 ? 512 : 1024;
-            int64_t nblocks = (int64_t)256 * (2048 / threads);
-            if (nblocks > b.n[k]) nblocks = b.n[k];
-            const size_t per = (size_t)slab * (sizeof(int32_t) + (NUMERIC ? sizeof(T) : 0));
-            while (nblocks > 1 && per * (size_t)nblocks > (size_t(4) << 30)) nblocks >>= 1;  // <= 4 GiB of slabs
-            unsigned long long* work = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long)));
-            MI_HIP_CHECK(hipMemsetAsync(work, 0, sizeof(unsigned long long), c.stream));
-            DevBuf kbuf, vbuf;
-            kbuf.alloc(sizeof(int32_t) * (size_t)slab * (size_t)nblocks);
-            if (NUMERIC) vbuf.alloc(sizeof(T) * (size_t)slab * (size_t)nblocks);
-            MI_LAUNCH((k_spgemm_global<T, NUMERIC>), dim3((unsigned)nblocks), dim3(threads), c.stream, b.n[k],
-                      (const int32_t*)b.list[k], cnt, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
-                      (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val,
-                      gw > threads ? threads : gw, (int)upper, kbuf.as<int32_t>(), vbuf.as<T>(), slab, row_nnz, cptr,
-                      ccol, cval, work);
-            MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // slabs are freed on scope exit
+    // Rows beyond the LDS bins.  Two forms of the global-memory hash:
+    //   * one persistent workgroup per row with a PRIVATE table and workgroup-scope (L2-local) atomics
+    //     -- classes up to SPGEMM_COOP_MIN entries;
+    //   * cooperative: many workgroups per row on one table with agent-scope atomics -- the hub
+    //     classes above that, where a single workgroup per row would serialise.
+    if (options().spgemm_global_mode == 0) {
+        // global-memory hash: every class that did not go to an LDS bin, largest class first.  One launch
+        // per size class so that tables (cleared and compacted per row) and workgroups are sized for
+        // the class: many small workgroups for the mid-size rows, few large ones for the hub rows.
+        {
+            const int first = force_global ? 0 : NLDSBINS;
+            static const int64_t lds_limits[NLDSBINS] = {32, 128, 512, 2048};
+            for (int k = NBINS - 1; k >= first; --k) {
+                if (!b.n[k]) continue;
+                int64_t limit = (k < NLDSBINS) ? lds_limits[k] : ((int64_t)4096 << (k - NLDSBINS));
+                if (k == NBINS - 1 || limit > max_cnt) limit = max_cnt;
+                const int64_t cap = limit < B.cols ? limit : B.cols;
+                int64_t slab = 4;
+                while (slab < 2 * cap) slab <<= 1;
+                const int threads = cap <= 16384 ? 256 : cap <= 131072 ? 512 : 1024;
+                int64_t nblocks = (int64_t)256 * (2048 / threads);
+                if (nblocks > b.n[k]) nblocks = b.n[k];
+                const size_t per = (size_t)slab * (sizeof(int32_t) + (NUMERIC ? sizeof(T) : 0));
+                while (nblocks > 1 && per * (size_t)nblocks > (size_t(4) << 30)) nblocks >>= 1;  // <= 4 GiB of slabs
+                unsigned long long* work = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long)));
+                MI_HIP_CHECK(hipMemsetAsync(work, 0, sizeof(unsigned long long), c.stream));
+                DevBuf kbuf, vbuf;
+                kbuf.alloc(sizeof(int32_t) * (size_t)slab * (size_t)nblocks);
+                if (NUMERIC) vbuf.alloc(sizeof(T) * (size_t)slab * (size_t)nblocks);
+                MI_LAUNCH((k_spgemm_global<T, NUMERIC>), dim3((unsigned)nblocks), dim3(threads), c.stream, b.n[k],
+                          (const int32_t*)b.list[k], cnt, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
+                          (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val,
+                          gw > threads ? threads : gw, (int)upper, kbuf.as<int32_t>(), vbuf.as<T>(), slab, row_nnz, cptr,
+                          ccol, cval, work);
+                MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // slabs are freed on scope exit
+            }
+        }
+    } else {
+        // global-memory hash: every class that did not go to an LDS bin, largest first.  All rows of a
+        // class use one table size; they are processed in batches whose tables fit a 4 GiB workspace.
+        {
+            const int first = force_global ? 0 : NLDSBINS;
+            static const int64_t lds_limits[NLDSBINS] = {32, 128, 512, 2048};
+            for (int k = NBINS - 1; k >= first; --k) {
+                if (!b.n[k]) continue;
+                int64_t limit = (k < NLDSBINS) ? lds_limits[k] : ((int64_t)4096 << (k - NLDSBINS));
+                if (k == NBINS - 1 || limit > max_cnt) limit = max_cnt;
+                const int64_t cap = limit < B.cols ? limit : B.cols;
+                int log2s = 2;
+                while (((int64_t)1 << log2s) < 2 * cap) ++log2s;
+                const int64_t S = (int64_t)1 << log2s;
+                const size_t per = (size_t)S * (sizeof(int32_t) + (NUMERIC ? sizeof(T) : 0));
+                int64_t batch = (int64_t)((size_t(4) << 30) / per);
+                if (batch < 1) batch = 1;
+                if (batch > 65535) batch = 65535;
+                if (batch > b.n[k]) batch = b.n[k];
+                DevBuf kbuf, vbuf, cur;
+                kbuf.alloc(sizeof(int32_t) * (size_t)S * (size_t)batch);
+                if (NUMERIC) {
+                    vbuf.alloc(sizeof(T) * (size_t)S * (size_t)batch);
+                    cur.alloc(sizeof(unsigned long long) * (size_t)batch);
+                }
+                const int gwg = gw > GINS_THREADS ? GINS_THREADS : gw;
+                for (int64_t r0 = 0; r0 < b.n[k]; r0 += batch) {
+                    const int64_t nb = (b.n[k] - r0 < batch) ? b.n[k] - r0 : batch;
+                    MI_HIP_CHECK(hipMemsetAsync(kbuf.p, 0xFF, sizeof(int32_t) * (size_t)S * (size_t)nb, c.stream));
+                    if (NUMERIC) {
+                        MI_HIP_CHECK(hipMemsetAsync(vbuf.p, 0, sizeof(T) * (size_t)S * (size_t)nb, c.stream));
+                        MI_HIP_CHECK(hipMemsetAsync(cur.p, 0, sizeof(unsigned long long) * (size_t)nb, c.stream));
+                    }
+                    // work items of this batch: one per slice of GINS_ENTRIES A-nonzeros
+                    int64_t* items = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nb + 1)));
+                    int64_t* item_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nb + 1)));
+                    MI_LAUNCH(k_gins_items, dim3((unsigned)ceil_div(nb, 256)), dim3(256), c.stream,
+                              (const int32_t*)(b.list[k] + r0), (const int64_t*)A.ptr, nb, items);
+                    const int64_t n_items = exclusive_scan_i64(items, item_off, nb);
+                    if (n_items > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "SpGEMM batch too large for one launch");
+                    if (n_items > 0)
+                        MI_LAUNCH((k_spgemm_ginsert<T, NUMERIC>), dim3((unsigned)n_items), dim3(GINS_THREADS), c.stream,
+                                  (const int32_t*)(b.list[k] + r0), (const int64_t*)A.ptr, (const int32_t*)A.col,
+                                  (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val, gwg,
+                                  (int)upper, kbuf.as<int32_t>(), vbuf.as<T>(), log2s, (unsigned long long*)row_nnz,
+                                  (const int64_t*)item_off, nb);
+                    if (NUMERIC)
+                        MI_LAUNCH((k_spgemm_gcompact<T>), dim3((unsigned)ceil_div(S, GCOMP_SLOTS), (unsigned)nb), dim3(256),
+                                  c.stream, (const int32_t*)(b.list[k] + r0), (const int32_t*)kbuf.as<int32_t>(),
+                                  (const T*)vbuf.as<T>(), log2s, cur.as<unsigned long long>(), cptr, ccol, cval);
+                }
+                MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // workspaces are freed on scope exit
+            }
         }
     }
 #undef MI_SPGEMM_ARGS
     MI_HIP_CHECK(hipGetLastError());
-}
-
-__global__ void k_max_i64(const int64_t* in, int64_t n, int64_t* out)
-{
-    __shared__ int64_t red[256];
-    int64_t m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        if (in[i] > m) m = in[i];
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off && red[threadIdx.x + off] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) atomicMax((long long*)out, (long long)red[0]);
-}
-
-static int64_t device_max(const int64_t* in, int64_t n)
-{
-    Context& c = ctx();
-    int64_t* d = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t)));
-    MI_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(int64_t), c.stream));
-    if (n > 0) {
-        const int64_t blocks = ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024;
-        MI_LAUNCH(k_max_i64, dim3((unsigned)blocks), dim3(256), c.stream, in, n, d);
-    }
-    int64_t h = 0;
-    MI_HIP_CHECK(hipMemcpyAsync(&h, d, sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
-    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-    return h;
 }
 
 // C := A * B (or its upper triangle).  C's storage is allocated here.

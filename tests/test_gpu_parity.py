@@ -321,13 +321,16 @@ def test_spgemm_all_bins(gpu, oracle, dtype):
     _check_spgemm(got, want, dtype)
     got = gpu.dot_product_mkl(a, b, reorder_output=True)
     assert np.array_equal(got.indices, want.indices)  # already ordered
-    # the global-memory hash path on the same problem
-    gpu.mi_set_option("spgemm_force_global", 1)
-    try:
-        got = gpu.dot_product_mkl(a, b)
-    finally:
-        gpu.mi_set_option("spgemm_force_global", 0)
-    _check_spgemm(got, want, dtype)
+    # both forms of the global-memory hash path on the same problem
+    for mode in (0, 1):
+        gpu.mi_set_option("spgemm_force_global", 1)
+        gpu.mi_set_option("spgemm_global_mode", mode)
+        try:
+            got = gpu.dot_product_mkl(a, b)
+        finally:
+            gpu.mi_set_option("spgemm_force_global", 0)
+            gpu.mi_set_option("spgemm_global_mode", 0)
+        _check_spgemm(got, want, dtype)
 
 
 def test_spgemm_keeps_cancelled_entries_and_sums_duplicates(gpu):

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--cols", type=int, default=16384)
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--global-mode", type=int, default=-1)
+    ap.add_argument("--no-order", action="store_true", help="SpGEMM: skip the mi_sparse_order timing (needs 2 extra nnz-sized buffers)")
     ap.add_argument("--force-global", action="store_true", help="SpGEMM: send every row through the global-memory hash")
     args = ap.parse_args()
 
@@ -45,6 +47,8 @@ def main():
     sda.mi_set_stream(torch.cuda.current_stream().cuda_stream)
     if args.force_global:
         sda.mi_set_option("spgemm_force_global", 1)
+    if args.global_mode >= 0:
+        sda.mi_set_option("spgemm_global_mode", args.global_mode)
 
     def make(kind, n_rows_log2, ncols, per_row, seed, dtype):
         if kind == "rmat":
@@ -118,7 +122,8 @@ def main():
         torch.cuda.synchronize()
         rel = float(((c1 - ab1).abs() / ab1.abs().clamp(min=1e-300)).max())
         t0 = time.perf_counter()
-        _check_return_value(MI.call("mi_sparse_order", hc), "order")
+        if not args.no_order:
+            _check_return_value(MI.call("mi_sparse_order", hc), "order")
         torch.cuda.synchronize()
         t_order = time.perf_counter() - t0
         nbytes = (a[1].numel() + b[1].numel() + nnzc) * 12 + 3 * (m + 1) * 8
