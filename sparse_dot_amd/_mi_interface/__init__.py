@@ -14,6 +14,7 @@ from ._checks import (  # noqa: F401
 )
 from ._handles import (  # noqa: F401
     SparseHandle, _create_mi_sparse, _export_mi, _destroy_mi_handle, _order_mi_handle, _convert_to_csr,
+    DeviceMatrix, to_device,
 )
 
 

@@ -134,6 +134,8 @@ def _empty_output_check(matrix_a, matrix_b):
     for m in (matrix_a, matrix_b):
         if _sps.issparse(m) and min(m.data.size, m.indices.size) == 0:
             return True
+        if getattr(m, "nnz", None) == 0 and not _sps.issparse(m) and not isinstance(m, _np.ndarray):
+            return True  # an empty DeviceMatrix
     return False
 
 

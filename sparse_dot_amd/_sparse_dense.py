@@ -9,7 +9,7 @@ trivially-empty cases and turns dense x sparse into (B^T A^T)^T.
 import numpy as _np
 from scipy import sparse as _sps
 
-from ._mi_interface import (MI, LAYOUT_CODE_C, LAYOUT_CODE_F, SparseHandle, _check_return_value,
+from ._mi_interface import (MI, LAYOUT_CODE_C, LAYOUT_CODE_F, DeviceMatrix, SparseHandle, _check_return_value,
                             _empty_output_check, _get_numpy_layout, _is_double, _mi_scalar, _out_matrix,
                             _output_dtypes, _sanity_check, _type_check, _type_letters, debug_print, matrix_descr)
 
@@ -26,11 +26,18 @@ def _sparse_dense_matmul(matrix_a, matrix_b, scalar=1.0, transpose=False, out=No
     output_arr = _out_matrix(out_shape, _output_dtypes[(dbl, cplx)], order, out_arr=out, out_t=out_t)
     _, ld_out = _get_numpy_layout(output_arr, second_arr=matrix_b)
     name = "mi_sparse_%s_mm" % _type_letters[(dbl, cplx)]
-    with SparseHandle.from_scipy(matrix_a) as handle:
+
+    def run(handle):
         ret = MI.call(name, 11 if transpose else 10, _mi_scalar(scalar, cplx, dbl), handle.ptr, matrix_descr(),
                       layout_b, matrix_b.ctypes.data, out_shape[1], ld_b, _mi_scalar(out_scalar, cplx, dbl),
                       output_arr.ctypes.data, ld_out)
         _check_return_value(ret, name)
+
+    if isinstance(matrix_a, DeviceMatrix):   # resident handle: no upload, cached plan
+        run(matrix_a.handle)
+    else:
+        with SparseHandle.from_scipy(matrix_a) as handle:
+            run(handle)
     return output_arr
 
 
@@ -44,8 +51,14 @@ def _sparse_dot_dense(matrix_a, matrix_b, cast=False, scalar=1.0, out=None, out_
         return _out_matrix((matrix_a.shape[0], matrix_b.shape[1]), _np.float32 if both_single else _np.float64,
                            out_arr=out)
 
-    matrix_a, matrix_b = _type_check(matrix_a, matrix_b, cast=cast)
-    a_sparse, b_sparse = _sps.issparse(matrix_a), _sps.issparse(matrix_b)
+    if isinstance(matrix_a, DeviceMatrix) or isinstance(matrix_b, DeviceMatrix):
+        if matrix_a.dtype != matrix_b.dtype:
+            raise ValueError("a DeviceMatrix cannot be cast: operands must share its dtype (%s & %s provided)"
+                             % (matrix_a.dtype, matrix_b.dtype))
+    else:
+        matrix_a, matrix_b = _type_check(matrix_a, matrix_b, cast=cast)
+    a_sparse = _sps.issparse(matrix_a) or isinstance(matrix_a, DeviceMatrix)
+    b_sparse = _sps.issparse(matrix_b) or isinstance(matrix_b, DeviceMatrix)
     if a_sparse == b_sparse:
         raise ValueError("_sparse_dot_dense takes one sparse and one dense array")
     if a_sparse:

@@ -10,7 +10,7 @@ from scipy import sparse as _sps
 
 from ._dense_dense import _dense_dot_dense as _ddd
 from ._gram_matrix import _gram_matrix as _gm
-from ._mi_interface import _is_dense_vector, print_mi_debug, set_debug_mode  # noqa: F401
+from ._mi_interface import DeviceMatrix, _is_dense_vector, print_mi_debug, set_debug_mode  # noqa: F401
 from ._sparse_dense import _sparse_dot_dense as _sdd
 from ._sparse_sparse import _sparse_dot_sparse as _sds
 from ._sparse_vector import _sparse_dot_vector as _sdv
@@ -40,6 +40,19 @@ def dot_product_mkl(matrix_a, matrix_b, cast=False, copy=True, reorder_output=Fa
     if debug:
         _warnings.warn(_DEBUG_MSG, DeprecationWarning)
     print_mi_debug()
+
+    a_dev, b_dev = isinstance(matrix_a, DeviceMatrix), isinstance(matrix_b, DeviceMatrix)
+    if a_dev or b_dev:
+        # GPU-resident sparse operand (sparse_dot_amd.to_device): SpMM / SpMV against a dense operand
+        other = matrix_b if a_dev else matrix_a
+        if isinstance(other, DeviceMatrix) or _sps.issparse(other):
+            raise ValueError("a DeviceMatrix can only be multiplied with a dense numpy operand")
+        if other.ndim == 1:   # vector: run it as a one-column / one-row matrix and restore the shape
+            o2 = other.reshape(-1, 1) if a_dev else other.reshape(1, -1)
+            out2 = None if out is None else (out.reshape(-1, 1) if a_dev else out.reshape(1, -1))
+            r = _sdd(matrix_a if a_dev else o2, o2 if a_dev else matrix_b, cast=cast, out=out2, out_scalar=out_scalar)
+            return out if out is not None else r.ravel()
+        return _sdd(matrix_a, matrix_b, cast=cast, out=out, out_scalar=out_scalar)
 
     a_sparse, b_sparse = _sps.issparse(matrix_a), _sps.issparse(matrix_b)
 

@@ -210,6 +210,37 @@ def test_c_abi_with_device_pointers(gpu, oracle):
     assert rel_err(got, want) <= F32_TOL
 
 
+def test_device_matrix_reuse(gpu, oracle):
+    """sparse_dot_amd.to_device: A stays on the GPU (one upload, cached plan) across products."""
+    a = pos_csr(600, 450, 0.05, np.float64, 44)
+    A = gpu.to_device(a)
+    assert A.shape == (600, 450) and A.dtype == np.float64 and "resident" in repr(A)
+    for seed, order in ((1, "C"), (2, "F"), (3, "C")):
+        b = dense((450, 24), np.float64, seed, order)
+        got = gpu.dot_product_mkl(A, b)
+        assert np.array_equal(got, gpu.dot_product_mkl(a, b))      # same kernels, same bits
+        assert rel_err(got, oracle.spmm(a, b)) <= F64_TOL
+    d = dense((30, 600), np.float64, 5)
+    assert rel_err(gpu.dot_product_mkl(d, A), d @ a.toarray()) <= F64_TOL
+    v = dense((450,), np.float64, 6)
+    r = gpu.dot_product_mkl(A, v)
+    assert r.shape == (600,) and rel_err(r, a.toarray() @ v) <= F64_TOL
+    out = np.ones((600, 24))
+    b = dense((450, 24), np.float64, 7)
+    assert gpu.dot_product_mkl(A, b, out=out, out_scalar=2.0) is out
+    assert rel_err(out, oracle.spmm(a, b) + 2.0) <= 4 * F64_TOL
+    with pytest.raises(ValueError):
+        gpu.dot_product_mkl(A, b.astype(np.float32))               # no implicit casts of a resident matrix
+    with pytest.raises(ValueError):
+        gpu.dot_product_mkl(A, a.T.tocsr())
+    A.free()
+    with pytest.raises(ValueError):
+        gpu.dot_product_mkl(A, b)
+    csc = gpu.to_device(a.tocsc())
+    assert rel_err(gpu.dot_product_mkl(csc, b), oracle.spmm(a, b)) <= F64_TOL
+    csc.free()
+
+
 def test_c_abi_status_codes(gpu):
     from sparse_dot_amd._mi_interface import MI, matrix_descr, sparse_matrix_t
     null = sparse_matrix_t()
