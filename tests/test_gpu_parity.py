@@ -241,6 +241,38 @@ def test_device_matrix_reuse(gpu, oracle):
     csc.free()
 
 
+def test_concurrent_host_threads(gpu, oracle):
+    """ctypes releases the GIL, so products may be issued from several Python threads at once
+    (Threading): per-thread context / scratch, handles are independent."""
+    import threading
+    mats = [(pos_csr(400 + 37 * t, 300, 0.05, np.float64, 70 + t), dense((300, 16 + t), np.float64, 80 + t)) for t in range(6)]
+    sp = [(pos_csr(120, 150, 0.05, np.float64, 90 + t), pos_csr(150, 90, 0.05, np.float64, 95 + t)) for t in range(6)]
+    want = [oracle.spmm(a, b) for a, b in mats]
+    want_sp = [(a @ b).toarray() for a, b in sp]
+    errors = []
+
+    def work(t):
+        try:
+            for _ in range(8):
+                a, b = mats[t]
+                got = gpu.dot_product_mkl(a, b)
+                if rel_err(got, want[t]) > F64_TOL:
+                    errors.append(("spmm", t))
+                x, y = sp[t]
+                c = gpu.dot_product_mkl(x, y)
+                if not np.allclose(c.toarray(), want_sp[t], rtol=1e-12, atol=1e-14):
+                    errors.append(("spgemm", t))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 def test_c_abi_status_codes(gpu):
     from sparse_dot_amd._mi_interface import MI, matrix_descr, sparse_matrix_t
     null = sparse_matrix_t()
