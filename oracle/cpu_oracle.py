@@ -65,17 +65,6 @@ _PREFIX = {
 }
 
 
-def _scalar(x, dtype):
-    """C `T` passed by value: float/double, or _Complex as a two-field struct (same ABI class
-    on x86-64 SysV for float _Complex -> one XMM; handled below by splitting)."""
-    dtype = _np.dtype(dtype)
-    if dtype == _np.float32:
-        return _ct.c_float(float(x))
-    if dtype == _np.float64:
-        return _ct.c_double(float(x))
-    raise TypeError("complex scalars are passed through the *_p helpers")
-
-
 def _fn(name, dtype):
     return getattr(lib(), "orc_%s_%s" % (_PREFIX[_np.dtype(dtype)], name))
 
@@ -136,14 +125,12 @@ def spmm(a, b, alpha=1.0, beta=0.0, c=None, op=OP_N):
     ldc = n if layout == LAYOUT_C else crows
     rs, re, col, val = _csr_parts(a)
     if _is_complex(dt):
-        one = (_ct.c_float * 2)(1.0, 0.0) if dt == _np.complex64 else (_ct.c_double * 2)(1.0, 0.0)
-        # float _Complex by value == struct of two floats in one SSE reg; emulate via casting
+        # `T _Complex` by value has the ABI of a struct of two T (x86-64 SysV): pass it as one
         f = _fn("csr_mm", dt)
         f.restype = _ct.c_int
         cplx = _C8 if dt == _np.complex64 else _C16
         f.argtypes = [_ct.c_int, cplx, _ct.c_int64, _ct.c_int64] + [_ct.c_void_p] * 4 + [
             _ct.c_int, _ct.c_void_p, _ct.c_int64, _ct.c_int64, cplx, _ct.c_void_p, _ct.c_int64]
-        del one
         st = f(op, cplx(1.0, 0.0), m, k, _p(rs), _p(re), _p(col), _p(val), layout, _p(b), n, ldb,
                cplx(0.0, 0.0), _p(out), ldc)
         if st:

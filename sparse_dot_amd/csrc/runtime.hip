@@ -82,17 +82,10 @@ void* Context::scratch_alloc(size_t bytes)
     const size_t off = (scratch_used + 255) & ~size_t(255);
     const size_t need = off + (bytes ? bytes : 1);
     if (need > scratch.bytes) {
-        // grow: the old arena may still be read by kernels already enqueued -> retire, free at sync
+        // grow: kernels already enqueued (by this call or an earlier one) may still read the old
+        // arena, so it is retired -- kept alive until the next synchronise -- and a new one started
         size_t cap = scratch.bytes ? scratch.bytes : (size_t(1) << 20);
         while (cap < need) cap *= 2;
-        if (scratch_used == 0) {
-            // nothing of this call lives in the old arena; earlier calls' kernels might still use it
-            retired.push_back(std::move(scratch));
-            scratch.alloc(cap);
-            scratch_used = (bytes ? bytes : 1);
-            return scratch.p;
-        }
-        // mid-call growth: keep the old arena alive for this call's earlier slices
         retired.push_back(std::move(scratch));
         scratch.alloc(cap);
         scratch_used = (bytes ? bytes : 1);

@@ -45,6 +45,33 @@ def _default_local_spmm(a_block, b):
     return dot_product_mkl(a_block, b)
 
 
+class _DeviceBlock:
+    """This rank's CSR row block uploaded once (C-ABI handle over the library's own HBM copy)."""
+
+    def __init__(self, a_block):
+        from ._mi_interface import SparseHandle
+        self.handle = SparseHandle.from_scipy(a_block)
+        self.shape = a_block.shape
+        self.dtype = _np.dtype(a_block.dtype)
+
+    def spmm_into(self, b_t, c_t):
+        """c_t := A_block @ b_t with torch CUDA tensors (row-major), zero copy, on torch's current stream."""
+        import torch
+        from ._mi_interface import MI, matrix_descr, _check_return_value, _type_letters, _is_double, mi_set_stream
+        dbl, cplx = _is_double(self)
+        letter = _type_letters[(dbl, cplx)]
+        if cplx:
+            raise ValueError("sharded_dot_product supports real dtypes")
+        mi_set_stream(torch.cuda.current_stream().cuda_stream)
+        n = b_t.shape[1]
+        ret = MI.call("mi_sparse_%s_mm" % letter, 10, 1.0, self.handle.ptr, matrix_descr(), 101, b_t.data_ptr(), n, n,
+                      0.0, c_t.data_ptr(), n)
+        _check_return_value(ret, "mi_sparse_%s_mm" % letter)
+
+    def free(self):
+        self.handle.destroy()
+
+
 def sharded_dot_product(a_block, matrix_b, block_rows, src=0, group=None, local_spmm=None, gather=True):
     """C = A @ B for a row-partitioned A.
 
@@ -54,8 +81,11 @@ def sharded_dot_product(a_block, matrix_b, block_rows, src=0, group=None, local_
     :param block_rows: list with every rank's block height (sum = rows of A).
     :param gather: all-gather the output row blocks so every rank returns the full C; with
         gather=False each rank returns only its own block (outputs stay row-distributed).
-    :param local_spmm: callable (a_block, b) -> dense block; defaults to the GPU dot_product_mkl.
-        (Tests inject a CPU function to exercise the collective logic under gloo.)
+    :param local_spmm: callable (a_block, b) -> dense block.  Default: on the "nccl" (RCCL) backend B,
+        the local product and the gathered C stay in HBM -- broadcast -> HIP kernel through the C ABI
+        with device pointers -> all-gather -> one D2H copy of the result; on other backends the GPU
+        dot_product_mkl on host arrays.  (Tests inject a CPU function to exercise the collective logic
+        under gloo.)
     """
     import torch
     import torch.distributed as dist
@@ -66,23 +96,37 @@ def sharded_dot_product(a_block, matrix_b, block_rows, src=0, group=None, local_
         raise ValueError("block_rows must have one entry per rank")
     if a_block.shape[0] != block_rows[rank]:
         raise ValueError("rank %d holds %d rows but block_rows says %d" % (rank, a_block.shape[0], block_rows[rank]))
-    local_spmm = local_spmm or _default_local_spmm
     on_gpu = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
 
     b_host = _np.ascontiguousarray(matrix_b)
+    if a_block.shape[1] != b_host.shape[0]:
+        raise ValueError("Matrix alignment error: %s * %s is not valid" % (a_block.shape, b_host.shape))
     b_t = torch.from_numpy(b_host).to(dev)
-    dist.broadcast(b_t, src=src, group=group)  # RCCL broadcast of dense B
-    b_host = b_t.cpu().numpy() if rank != src else b_host
-
-    c_block = _np.ascontiguousarray(local_spmm(a_block, b_host))
-    if not gather:
-        return c_block
-    n = c_block.shape[1]
+    dist.broadcast(b_t, src=src, group=group)  # RCCL broadcast of dense B over xGMI
+    n = b_t.shape[1]
     hmax = int(max(block_rows))
-    padded = torch.zeros((hmax, n), dtype=torch.from_numpy(c_block).dtype, device=dev)
-    if c_block.shape[0]:
-        padded[:c_block.shape[0]] = torch.from_numpy(c_block).to(dev)
+
+    if on_gpu and local_spmm is None:
+        if a_block.dtype != b_host.dtype:
+            raise ValueError("operands must share one dtype (%s & %s provided)" % (a_block.dtype, b_host.dtype))
+        padded = torch.zeros((hmax, n), dtype=b_t.dtype, device=dev)
+        if a_block.shape[0]:
+            blk = _DeviceBlock(a_block)
+            try:
+                blk.spmm_into(b_t, padded[:a_block.shape[0]])
+                torch.cuda.current_stream().synchronize()
+            finally:
+                blk.free()
+    else:
+        fn = local_spmm or _default_local_spmm
+        b_local = b_t.cpu().numpy() if rank != src else b_host
+        c_block = _np.ascontiguousarray(fn(a_block, b_local))
+        padded = torch.zeros((hmax, n), dtype=torch.from_numpy(c_block).dtype, device=dev)
+        if c_block.shape[0]:
+            padded[:c_block.shape[0]] = torch.from_numpy(c_block).to(dev)
+    if not gather:
+        return padded[:block_rows[rank]].cpu().numpy()
     gathered = torch.empty((world * hmax, n), dtype=padded.dtype, device=dev)
     dist.all_gather_into_tensor(gathered, padded, group=group)  # all-gatherv via padding
     gathered = gathered.cpu().numpy().reshape(world, hmax, n)

@@ -241,6 +241,39 @@ def test_device_matrix_reuse(gpu, oracle):
     csc.free()
 
 
+def test_sharded_dot_product_rccl_single_rank(gpu, oracle):
+    """The multi-GPU path on the one GPU available here: RCCL process group of size 1 -- broadcast(B),
+    HIP kernel on device pointers, all-gather(C).  (World size 2 runs under gloo on CPU in
+    tests/test_distributed_cpu.py; more ranks need more GPUs.)"""
+    torch = pytest.importorskip("torch")
+    import os
+    import socket
+    import torch.distributed as dist
+    from sparse_dot_amd import distributed as D
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        a = pos_csr(900, 700, 0.03, np.float32, 55)
+        b = dense((700, 128), np.float32, 56)
+        bounds = D.partition_rows(a.indptr, 1)
+        assert bounds.tolist() == [0, 900]
+        got = D.sharded_dot_product(D.row_block(a, 0, 900), b, [900])
+        assert got.shape == (900, 128) and got.dtype == np.float32
+        assert rel_err(got, oracle.spmm(a.astype(np.float64), b.astype(np.float64))) <= F32_TOL
+        part = D.sharded_dot_product(D.row_block(a, 0, 900), b, [900], gather=False)
+        assert np.array_equal(part, got)
+    finally:
+        dist.destroy_process_group()
+        gpu.mi_set_stream(0)
+
+
 def test_concurrent_host_threads(gpu, oracle):
     """ctypes releases the GIL, so products may be issued from several Python threads at once
     (Threading): per-thread context / scratch, handles are independent."""
