@@ -305,6 +305,131 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SpMV (N = 1): y := alpha * A x + beta * y  -- the lanes span NONZEROS instead of dense columns.
+// Same work partition, ownership rules and carry / fix-up machinery as k_spmm.  A wave multiplies
+// its chunk's nonzeros by the gathered x entries with fully coalesced (col, val) loads, parks the
+// products in LDS and reduces them per row: rows of up to 32 products by one lane each (most rows
+// of a sparse matrix), longer segments cooperatively with a shuffle reduction.  Traffic is A once
+// (8-12 B per nonzero) plus the x gather, which stays in L2 for vectors of a few MB.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T shfl_down_val(T v, int d)
+{
+    return __shfl_xor(v, d);  // butterfly: every lane ends with the full sum
+}
+template <typename R>
+__device__ __forceinline__ cx<R> shfl_down_val(cx<R> v, int d)
+{
+    return cx<R>{__shfl_xor(v.re, d), __shfl_xor(v.im, d)};
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SPMM_WAVES* WAVE)
+    k_spmv(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
+           const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
+           const T* __restrict__ x, int64_t x_s, T* __restrict__ y, int64_t y_s, T alpha, T beta, int beta_zero,
+           T* __restrict__ carry_val)
+{
+    MI_DYN_SMEM(smem);
+    const int wave_in_block = threadIdx.x / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    const int64_t w = (int64_t)blockIdx.x * SPMM_WAVES + wave_in_block;
+    const bool active = w < nchunks;
+    const size_t per_wave = ((size_t)(ch + SPMM_SPLIT) * sizeof(T) + (size_t)(ch + 2) * sizeof(int32_t) + 15) & ~size_t(15);
+    char* base = smem + per_wave * wave_in_block;
+    T* s_prod = reinterpret_cast<T*>(base);
+    int32_t* s_end = reinterpret_cast<int32_t*>(base + sizeof(T) * (size_t)(ch + SPMM_SPLIT));
+
+    int64_t r0 = 0;
+    int n_owned = 0, has_trail = 0, nproc = 0;
+    if (active) {
+        // identical partition logic to k_spmm (see there for the ownership rules)
+        const int64_t total = nnz + rows;
+        const int64_t s = w * ch;
+        const int64_t e = (s + ch < total) ? s + ch : total;
+        const int64_t ra = chunk_row[w];
+        const int64_t rb = chunk_row[w + 1];
+        int64_t P0;
+        {
+            const int64_t pa = ptr[ra], pa1 = ptr[ra + 1];
+            const bool before = (pa + ra) < s;
+            const bool is_long = (pa1 - pa + 1) > SPMM_SPLIT;
+            if (before && !is_long) {
+                r0 = ra + 1;
+                P0 = pa1;
+            } else {
+                r0 = ra;
+                P0 = before ? s - ra : pa;
+            }
+        }
+        int64_t r_stop, P1;
+        if (rb < rows && (ptr[rb] + rb) < e) {
+            const int64_t pb = ptr[rb], pb1 = ptr[rb + 1];
+            r_stop = rb + 1;
+            if ((pb1 - pb + 1) > SPMM_SPLIT) {
+                P1 = (e - rb < pb1) ? e - rb : pb1;
+                has_trail = 1;
+            } else {
+                P1 = pb1;
+            }
+        } else {
+            r_stop = rb;
+            P1 = (rb < rows) ? ptr[rb] : nnz;
+        }
+        if (r_stop < r0) r_stop = r0;
+        nproc = (int)(r_stop - r0);
+        n_owned = nproc - has_trail;
+        for (int k = lane; k < nproc; k += WAVE) {
+            int64_t en = ptr[r0 + k + 1];
+            if (k == nproc - 1) en = P1;
+            s_end[k] = (int32_t)(en - P0);
+        }
+        const int len = (int)(P1 - P0);
+        for (int k = lane; k < len; k += WAVE) {  // coalesced A stream + gather of x
+            T a = val[P0 + k];
+            if (conj_a) a = vt<T>::conj(a);
+            s_prod[k] = vt<T>::mul(a, x[(int64_t)col[P0 + k] * x_s]);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    // pass 1: one lane per row for segments of at most 32 products
+    for (int k = lane; k < nproc; k += WAVE) {
+        const int begin = k ? s_end[k - 1] : 0;
+        const int end = s_end[k];
+        if (end - begin <= 32) {
+            T sum = vt<T>::zero();
+            for (int p = begin; p < end; ++p) sum = vt<T>::add(sum, s_prod[p]);
+            if (k < n_owned) {
+                T* yy = y + (r0 + k) * y_s;
+                *yy = beta_zero ? vt<T>::mul(alpha, sum) : vt<T>::fma(alpha, sum, vt<T>::mul(beta, *yy));
+            } else {
+                carry_val[w] = sum;
+            }
+        }
+    }
+    // pass 2: longer segments, the whole wave per segment
+    for (int k = 0; k < nproc; ++k) {
+        const int begin = k ? s_end[k - 1] : 0;
+        const int end = s_end[k];
+        if (end - begin <= 32) continue;  // wave-uniform
+        T sum = vt<T>::zero();
+        for (int p = begin + lane; p < end; p += WAVE) sum = vt<T>::add(sum, s_prod[p]);
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) sum = vt<T>::add(sum, shfl_down_val(sum, d));
+        if (lane == 0) {
+            if (k < n_owned) {
+                T* yy = y + (r0 + k) * y_s;
+                *yy = beta_zero ? vt<T>::mul(alpha, sum) : vt<T>::fma(alpha, sum, vt<T>::mul(beta, *yy));
+            } else {
+                carry_val[w] = sum;
+            }
+        }
+    }
+}
+
 // add the carries of every cut row to the row its owner wrote.  The schedule (which chunks carry
 // into which row) depends only on A and the chunk size, so it is precomputed in the plan: one lane
 // group per task sums that row's carries in chunk order (deterministic) and does one
@@ -552,6 +677,19 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
                         ((ldb * (int64_t)sizeof(T)) % 16 == 0) && ((ldc * (int64_t)sizeof(T)) % 16 == 0) &&
                         ((reinterpret_cast<uintptr_t>(B) % 16) == 0) && ((reinterpret_cast<uintptr_t>(C) % 16) == 0) &&
                         ((reinterpret_cast<uintptr_t>(carry_val) % 16) == 0);
+    if (N == 1 && !options().spmm_force_generic) {
+        // SpMV: lanes over nonzeros (k_spmv); same plan, carries and fix-up as the wide kernel
+        const size_t pw = ((size_t)(p.chunk + SPMM_SPLIT) * sizeof(T) + (size_t)(p.chunk + 2) * sizeof(int32_t) + 15) & ~size_t(15);
+        counters().spmm_last_tagged = 0.0;
+        MI_LAUNCH_SMEM((k_spmv<T>), dim3((unsigned)ceil_div(p.nchunks, SPMM_WAVES)), dim3(SPMM_WAVES * WAVE),
+                       pw * SPMM_WAVES, c.stream, m.rows, m.nnz, (const int64_t*)m.ptr, (const int32_t*)m.col,
+                       (const T*)m.val, (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs,
+                       C, c_rs, alpha, beta, (int)(vt<T>::is_zero(beta) ? 1 : 0), carry_val);
+        if (p.n_tasks)
+            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(p.n_tasks * 16, 256)), dim3(256), c.stream,
+                      p.n_tasks, (const int32_t*)p.tasks.as<int32_t>(), (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+        return;
+    }
     // tagged (hot / cold) gather: needs 32-bit byte offsets into B
     const bool use_tags = p.tagged && vec_ok && dense_bytes_below_4g(m.cols, ldb, sizeof(T));
     counters().spmm_last_tagged = use_tags ? 1.0 : 0.0;

@@ -182,6 +182,39 @@ def test_spmv_shapes(gpu, oracle):
     assert r is out and rel_err(r, want + 3.0) <= 4 * F64_TOL
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex128])
+@pytest.mark.parametrize("chunk", [128, 256, 1024])
+def test_spmv_skewed_rows(gpu, oracle, dtype, chunk):
+    """The SpMV kernel (lanes over nonzeros, per-row reduction of LDS-parked products) on hub rows that
+    span many chunks, rows of every length around the 32-product lane / wave split, and empty runs."""
+    rng = np.random.default_rng(23)
+    lens = np.concatenate([rng.integers(0, 70, 2500), [0] * 40, [31, 32, 33, 64, 127, 128, 129, 4000, 1, 700], [0] * 25])
+    ncols = 5000
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(ncols, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.uniform(0.5, 1.5, indices.size)
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    if np.dtype(dtype).kind == "c":
+        data = data + 1j * rng.uniform(0.5, 1.5, indices.size)
+    a = sps.csr_matrix((data.astype(dtype), indices, indptr), shape=(lens.size, ncols))
+    x = dense((ncols,), dtype, 24)
+    want = a.astype(wide).toarray() @ x.astype(wide)
+    gpu.mi_set_option("spmm_chunk", chunk)
+    try:
+        got = gpu.dot_product_mkl(a, x)
+        out = np.full(lens.size, 2.0, dtype=dtype)
+        got2 = gpu.dot_product_mkl(a, x, out=out, out_scalar=0.5)
+        gotT = gpu.dot_product_mkl(dense((lens.size,), dtype, 25), a)     # x^T A through the cached transpose
+        again = gpu.dot_product_mkl(a, x)
+    finally:
+        gpu.mi_set_option("spmm_chunk", 256)
+    assert got.shape == (lens.size,) and rel_err(got[want != 0], want[want != 0]) <= tol(dtype)
+    assert not got[want == 0].any()
+    assert got2 is out and rel_err(out, want + 1.0) <= 4 * tol(dtype)
+    assert rel_err(gotT, dense((lens.size,), dtype, 25).astype(wide) @ a.astype(wide).toarray()) <= tol(dtype)
+    assert np.array_equal(got, again)   # deterministic for a given partition
+
+
 def test_c_abi_with_device_pointers(gpu, oracle):
     """HBM-resident operands: device pointers (torch) straight into the C ABI, zero copy."""
     torch = pytest.importorskip("torch")
