@@ -382,6 +382,108 @@ def test_create_export_roundtrip(gpu, dtype, fmt):
         _destroy_mi_handle(h)  # double destroy is an error, not a crash
 
 
+def _export_csr_via_abi(MI, h, letter, dtype, wide=False):
+    from sparse_dot_amd._mi_interface import _check_return_value
+    it = ct.c_int64 if wide else ct.c_int32
+    npi = np.int64 if wide else np.int32
+    base, r, c = ct.c_int(), it(), it()
+    ps, pe, pi, pv = ct.c_void_p(), ct.c_void_p(), ct.c_void_p(), ct.c_void_p()
+    name = "mi_sparse_%s_export_csr%s" % (letter, "_64" if wide else "")
+    _check_return_value(MI.call(name, h, ct.byref(base), ct.byref(r), ct.byref(c), ct.byref(ps), ct.byref(pe),
+                                ct.byref(pi), ct.byref(pv)), name)
+    assert base.value == 0 and pe.value == ps.value + np.dtype(npi).itemsize   # rows_end == rows_start + 1
+    indptr = np.frombuffer((ct.c_char * ((r.value + 1) * np.dtype(npi).itemsize)).from_address(ps.value), dtype=npi).copy()
+    nnz = int(indptr[-1])
+    idx = np.frombuffer((ct.c_char * (nnz * np.dtype(npi).itemsize)).from_address(pi.value), dtype=npi).copy()
+    val = np.frombuffer((ct.c_char * (nnz * np.dtype(dtype).itemsize)).from_address(pv.value), dtype=dtype).copy()
+    return sps.csr_matrix((val, idx, indptr), shape=(r.value, c.value))
+
+
+def test_c_abi_four_array_csr_base_one_and_wide_indices(gpu):
+    """Handle creation exactly as MKL's create_csr allows it: separate rows_start / rows_end arrays with
+    gaps between rows (not an indptr), 1-based indices, 64-bit index arrays; plus rejection of malformed
+    input with INVALID_VALUE instead of an out-of-bounds gather."""
+    from sparse_dot_amd._mi_interface import MI, matrix_descr, sparse_matrix_t, _check_return_value
+    a = pos_csr(50, 40, 0.2, np.float64, 77)
+    ad = a.toarray()
+    # 4-array form with 3 slots of padding after every row, shuffled row storage order
+    lens = np.diff(a.indptr)
+    order = np.random.default_rng(1).permutation(50)
+    starts = np.zeros(50, dtype=np.int32)
+    pos = 5
+    for r in order:
+        starts[r] = pos
+        pos += lens[r] + 3
+    ends = (starts + lens).astype(np.int32)
+    col4 = np.full(pos, 0, dtype=np.int32)
+    val4 = np.full(pos, np.nan)
+    for r in range(50):
+        col4[starts[r]:ends[r]] = a.indices[a.indptr[r]:a.indptr[r + 1]]
+        val4[starts[r]:ends[r]] = a.data[a.indptr[r]:a.indptr[r + 1]]
+    h = sparse_matrix_t()
+    _check_return_value(MI.call("mi_sparse_d_create_csr", ct.byref(h), 0, 50, 40, starts.ctypes.data, ends.ctypes.data,
+                                col4.ctypes.data, val4.ctypes.data), "create 4-array")
+    assert np.array_equal(_export_csr_via_abi(MI, h, "d", np.float64).toarray(), ad)
+    x = dense((40, 8), np.float64, 3)
+    y = np.zeros((50, 8))
+    _check_return_value(MI.call("mi_sparse_d_mm", 10, 1.0, h, matrix_descr(), 101, x.ctypes.data, 8, 8, 0.0, y.ctypes.data, 8), "mm")
+    assert rel_err(y, ad @ x) <= F64_TOL
+    MI.call("mi_sparse_destroy", h)
+    # base 1, 64-bit indices
+    ip1 = (a.indptr.astype(np.int64) + 1)
+    ix1 = (a.indices.astype(np.int64) + 1)
+    h = sparse_matrix_t()
+    _check_return_value(MI.call("mi_sparse_d_create_csr_64", ct.byref(h), 1, 50, 40, ip1.ctypes.data, ip1.ctypes.data + 8,
+                                ix1.ctypes.data, a.data.ctypes.data), "create base1 _64")
+    back = _export_csr_via_abi(MI, h, "d", np.float64, wide=True)
+    assert np.array_equal(back.toarray(), ad)   # (read through 64-bit index pointers; scipy narrows them again)
+    assert np.array_equal(_export_csr_via_abi(MI, h, "d", np.float64, wide=False).toarray(), ad)   # narrow export of a wide handle
+    MI.call("mi_sparse_destroy", h)
+    # malformed: column index out of range / decreasing row pointer / wrong base
+    bad_idx = a.indices.copy()
+    bad_idx[7] = 40
+    h = sparse_matrix_t()
+    assert MI.call("mi_sparse_d_create_csr", ct.byref(h), 0, 50, 40, a.indptr.ctypes.data, a.indptr.ctypes.data + 4,
+                   bad_idx.ctypes.data, a.data.ctypes.data) == 3
+    assert not h
+    bad_ptr = a.indptr.copy()
+    bad_ptr[10], bad_ptr[11] = bad_ptr[11], bad_ptr[10] - 1
+    assert MI.call("mi_sparse_d_create_csr", ct.byref(h), 0, 50, 40, bad_ptr.ctypes.data, bad_ptr.ctypes.data + 4,
+                   a.indices.ctypes.data, a.data.ctypes.data) == 3
+    assert MI.call("mi_sparse_d_create_csr", ct.byref(h), 7, 50, 40, a.indptr.ctypes.data, a.indptr.ctypes.data + 4,
+                   a.indices.ctypes.data, a.data.ctypes.data) == 3
+    assert MI.call("mi_sparse_d_create_csr", ct.byref(h), 0, -1, 40, a.indptr.ctypes.data, a.indptr.ctypes.data + 4,
+                   a.indices.ctypes.data, a.data.ctypes.data) == 3
+    assert MI.call("mi_sparse_d_create_csr", None, 0, 50, 40, a.indptr.ctypes.data, a.indptr.ctypes.data + 4,
+                   a.indices.ctypes.data, a.data.ctypes.data) == 1
+
+
+def test_c_abi_csc_export_and_syrk_spmmd_direct(gpu, oracle):
+    """export_csc of a CSR-created handle, and the syrk / spmmd entry points called directly."""
+    from sparse_dot_amd._mi_interface import MI, SparseHandle, sparse_matrix_t, _check_return_value
+    a = pos_csr(70, 55, 0.1, np.float32, 78)
+    with SparseHandle.from_scipy(a) as h:
+        csc = h.export("csc_matrix")
+        assert csc.format == "csc" and np.array_equal(csc.toarray(), a.toarray()) and csc.has_sorted_indices
+        out = sparse_matrix_t()
+        _check_return_value(MI.call("mi_sparse_syrk", 11, h.ptr, ct.byref(out)), "syrk")
+        with SparseHandle(out, "s") as g:
+            got = g.export("csr_matrix")
+        want = oracle.syrk_sparse(a)
+        got.sort_indices()
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        np.testing.assert_allclose(got.data, want.data, rtol=F32_TOL)
+        assert MI.call("mi_sparse_syrk", 99, h.ptr, ct.byref(out)) == 3
+        b = pos_csr(55, 30, 0.1, np.float32, 79)
+        with SparseHandle.from_scipy(b) as hb:
+            for layout, order in ((101, "C"), (102, "F")):
+                c = np.full((70, 30), np.nan, dtype=np.float32, order=order)
+                _check_return_value(MI.call("mi_sparse_s_spmmd", 10, h.ptr, hb.ptr, layout, c.ctypes.data,
+                                            30 if order == "C" else 70), "spmmd")
+                np.testing.assert_allclose(c, a.toarray() @ b.toarray(), rtol=F32_TOL, atol=1e-6)
+            assert MI.call("mi_sparse_d_spmmd", 10, h.ptr, hb.ptr, 101, c.ctypes.data, 30) == 3   # wrong precision entry point
+
+
 def test_bsr_handle_and_order(gpu):
     from sparse_dot_amd._mi_interface import SparseHandle
     a = pos_csr(40, 60, 0.2, np.float64, 61).tobsr(blocksize=(4, 4))
