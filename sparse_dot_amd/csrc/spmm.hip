@@ -445,16 +445,36 @@ __global__ void __launch_bounds__(256)
     if (task >= n_tasks) return;
     const int64_t row = tasks[3 * task], first = tasks[3 * task + 1], last = tasks[3 * task + 2];
     for (int64_t jc = (int64_t)li * V; jc < N; jc += (int64_t)LPN * V) {
+        // eight interleaved partial sums (chunks first+g, first+g+8, ...) so that eight carry loads are
+        // in flight at once -- a hub row can be cut into hundreds of chunks -- combined in a fixed
+        // order: the result does not depend on scheduling
+        constexpr int G = 8;
+        T part[G][V];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int v = 0; v < V; ++v) part[g][v] = vt<T>::zero();
+        for (int64_t u = first; u <= last; u += G) {
+            vec<T, V> cvv[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int64_t uu = (u + g <= last) ? u + g : last;  // clamp; masked out below
+                if (V > 1) cvv[g] = *reinterpret_cast<const vec<T, V>*>(carry_val + uu * N + jc);
+                else cvv[g].v[0] = carry_val[uu * N + jc];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (u + g <= last) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) part[g][v] = vt<T>::add(part[g][v], cvv[g].v[v]);
+                }
+            }
+        }
         T sum[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) sum[v] = vt<T>::zero();
-        for (int64_t u = first; u <= last; ++u) {
-            vec<T, V> cvv;
-            if (V > 1) cvv = *reinterpret_cast<const vec<T, V>*>(carry_val + u * N + jc);
-            else cvv.v[0] = carry_val[u * N + jc];
-#pragma unroll
-            for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], cvv.v[v]);
-        }
+        for (int v = 0; v < V; ++v)
+            sum[v] = vt<T>::add(vt<T>::add(vt<T>::add(part[0][v], part[1][v]), vt<T>::add(part[2][v], part[3][v])),
+                                vt<T>::add(vt<T>::add(part[4][v], part[5][v]), vt<T>::add(part[6][v], part[7][v])));
         T* c = C + row * c_rs + jc * c_cs;
         if (V > 1) {
             vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(c);
