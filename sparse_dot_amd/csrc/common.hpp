@@ -301,6 +301,7 @@ namespace mi {
 mi_sparse_matrix* check_handle(mi_sparse_matrix_t h);  // throws NOT_INITIALIZED
 Csr& need_csr(mi_sparse_matrix* h);                    // derive (transpose) if only csrT is there
 Csr& need_csrT(mi_sparse_matrix* h);
+bool rows_sorted(const Csr& a);  // column indices ascending inside every row (one pass over the indices unless known)
 void transpose_csr(char vtype, const Csr& in, Csr& out, bool conj);  // out := in^T (stable, sorted rows)
 void sort_csr(char vtype, Csr& a);                     // in-place order of every row
 mi_sparse_matrix* new_result_handle(char vtype, int index_bytes, int64_t rows, int64_t cols);
@@ -331,6 +332,7 @@ struct Options {
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;
+    int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)
     int64_t spgemm_global_mode = 0;  // 0: one workgroup per row, L2-local atomics; 1: cooperative, agent-scope atomics
     int64_t profile_events = 0;    // bracket the SpMM main kernel with hipEvents (diagnostics)
 };

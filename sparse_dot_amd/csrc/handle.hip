@@ -284,14 +284,10 @@ mi_sparse_matrix* new_result_handle(char vtype, int index_bytes, int64_t rows, i
     return h;
 }
 
-void sort_csr(char vtype, Csr& a)
+bool rows_sorted(const Csr& a)
 {
-    if (a.sorted || a.nnz < 2) {
-        a.sorted = true;
-        return;
-    }
+    if (a.sorted || a.nnz < 2) return true;
     Context& c = ctx();
-    // 0. already sorted? (scipy's canonical matrices are)
     int* flag = static_cast<int*>(c.scratch_alloc(sizeof(int)));
     MI_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), c.stream));
     MI_LAUNCH(k_rows_unsorted, grid1d(a.rows * WAVE, 256), dim3(256), c.stream, (const int64_t*)a.ptr,
@@ -299,10 +295,17 @@ void sort_csr(char vtype, Csr& a)
     int hflag = 0;
     MI_HIP_CHECK(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-    if (!hflag) {
+    return !hflag;
+}
+
+void sort_csr(char vtype, Csr& a)
+{
+    // already sorted? (scipy's canonical matrices are)
+    if (rows_sorted(a)) {
         a.sorted = true;
         return;
     }
+    Context& c = ctx();
     // the arrays are about to be rewritten: if they alias caller HBM, that is what "order" means
     int64_t* perm = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)a.nnz));
     int64_t* counters = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * 2));

@@ -355,6 +355,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.spmm_force_generic = value;
         } else if (!strcmp(name, "spgemm_force_global")) {
             o.spgemm_force_global = value;
+        } else if (!strcmp(name, "spgemm_lds_parts")) {
+            o.spgemm_lds_parts = value;
         } else if (!strcmp(name, "spgemm_global_mode")) {
             o.spgemm_global_mode = value;
         } else if (!strcmp(name, "profile_events")) {

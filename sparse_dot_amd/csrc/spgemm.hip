@@ -415,6 +415,217 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Big rows without global atomics (B with at most ~1.2 M columns, rows of B sorted for the numeric part).
+//  * The set of columns of a row of C is an n-bit bitmap in LDS (n <= ~1.2 M fits the 160 KiB of a
+//    CU): a product only ORs a bit.  Symbolic phase: nnz of the row = popcount of the bitmap.
+//  * Numeric phase: the same bitmap is rebuilt (it costs a few ms for a whole power-law matrix) and cut
+//    into P = ceil(nnz_i / CAP) column RANGES holding exactly CAP distinct columns each (the last one
+//    the rest).  One workgroup per (row, range): it finds, by binary search in the sorted rows of B,
+//    the slice of every B row that falls in its range, walks the slices as one flat list of products
+//    (so hub rows of B spread over the whole workgroup), accumulates them in an LDS hash table that
+//    cannot overflow (CAP = half its slots) and writes its CAP entries at cptr[row] + range * CAP --
+//    no cursor, no global atomic, every product read once.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+constexpr int part_log2s() { return sizeof(T) >= 16 ? 11 : 12; }  // 2048 slots for complex double, else 4096
+
+constexpr int PART_THREADS = 512;
+
+template <bool BOUNDS>
+__global__ void __launch_bounds__(1024)
+    k_spgemm_bitmap(int64_t nbig, const int32_t* __restrict__ row_list, int64_t ncols,
+                    const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
+                    const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int gw, int upper,
+                    int64_t* __restrict__ row_nnz, const int64_t* __restrict__ item_off, int64_t cap,
+                    int32_t* __restrict__ bounds, unsigned long long* work_counter)
+{
+    MI_DYN_SMEM(smem);
+    unsigned* bits = reinterpret_cast<unsigned*>(smem);
+    __shared__ int counter;
+    __shared__ long long next_idx;
+    __shared__ int scan[2][1024];
+    const int tid = threadIdx.x, threads = blockDim.x;
+    const int64_t words = (ncols + 31) / 32;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            next_idx = (long long)atomicAdd(work_counter, 1ull);
+            counter = 0;
+        }
+        __syncthreads();
+        const int64_t idx = next_idx;
+        if (idx >= nbig) break;
+        const int32_t row = row_list[idx];
+        for (int64_t k = tid; k < words; k += threads) bits[k] = 0u;
+        __syncthreads();
+        const int group = tid / gw, ngroups = threads / gw, gl = tid % gw;
+        for (int64_t p = aptr[row] + group; p < aptr[row + 1]; p += ngroups) {
+            const int32_t kk = acol[p];
+            for (int64_t q = bptr[kk] + gl; q < bptr[kk + 1]; q += gw) {
+                const int32_t j = bcol[q];
+                if (upper && j < row) continue;
+                atomicOr(&bits[j >> 5], 1u << (j & 31));
+            }
+        }
+        __syncthreads();
+        if constexpr (!BOUNDS) {
+            int local = 0;
+            for (int64_t k = tid; k < words; k += threads) local += __popc(bits[k]);
+            if (local) atomicAdd(&counter, local);
+            __syncthreads();
+            if (tid == 0) row_nnz[row] = counter;
+        } else {
+            // rank of every set bit -> the column where each range of `cap` distinct columns starts
+            const int64_t per = (words + threads - 1) / threads;
+            const int64_t w0 = (int64_t)tid * per, w1 = w0 + per < words ? w0 + per : words;
+            int local = 0;
+            for (int64_t k = w0; k < w1; ++k) local += __popc(bits[k]);
+            int cur = 0;
+            scan[0][tid] = local;
+            __syncthreads();
+            for (int d = 1; d < threads; d <<= 1) {  // inclusive Hillis-Steele scan of the per-thread counts
+                const int v = scan[cur][tid] + (tid >= d ? scan[cur][tid - d] : 0);
+                scan[cur ^ 1][tid] = v;
+                cur ^= 1;
+                __syncthreads();
+            }
+            int64_t rank = scan[cur][tid] - local;  // set bits before this thread's words
+            int32_t* out = bounds + item_off[idx];
+            if (tid == 0) out[0] = 0;
+            for (int64_t k = w0; k < w1; ++k) {
+                unsigned w = bits[k];
+                const int c = __popc(w);
+                if (c) {
+                    // boundaries b*cap (b >= 1) with rank <= b*cap < rank + c
+                    int64_t b = (rank + cap - 1) / cap;
+                    if (b == 0) b = 1;
+                    int taken = 0;  // set bits of the word already skipped
+                    for (; b * cap < rank + c; ++b) {
+                        const int want = (int)(b * cap - rank);  // 0-based index of the set bit inside the word
+                        for (; taken < want; ++taken) w &= w - 1;
+                        out[b] = (int32_t)(k * 32 + __builtin_ctz(w));
+                    }
+                }
+                rank += c;
+            }
+        }
+    }
+}
+
+__global__ void k_part_items(const int32_t* __restrict__ row_list, const int64_t* __restrict__ cnt, int64_t nb,
+                             int64_t cap, int64_t* __restrict__ items)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nb) items[t] = (cnt[row_list[t]] + cap - 1) / cap;
+}
+
+__device__ __forceinline__ int64_t lower_bound_col(const int32_t* __restrict__ col, int64_t lo, int64_t hi, int32_t key)
+{
+    while (lo < hi) {  // first position in [lo, hi) with col >= key
+        const int64_t mid = (lo + hi) >> 1;
+        if (col[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PART_THREADS)
+    k_spgemm_part(const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off, int64_t nb,
+                  const int32_t* __restrict__ bounds, int64_t ncols, int64_t cap, const int64_t* __restrict__ aptr,
+                  const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
+                  const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
+                  const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol, T* __restrict__ cval)
+{
+    constexpr int LOG2S = part_log2s<T>();
+    constexpr int S = 1 << LOG2S;
+    constexpr int NT = PART_THREADS;
+    __shared__ int32_t keys[S];
+    __shared__ T vals[S];
+    __shared__ int64_t qlo[NT];
+    __shared__ T a_s[NT];
+    __shared__ int pre[2][NT];
+    __shared__ int n_out;
+    const int tid = threadIdx.x;
+    const int64_t item = blockIdx.x;
+    int64_t lo = 0, hi = nb;  // largest t with item_off[t] <= item
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (item_off[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int64_t t = lo;
+    const int64_t pass = item - item_off[t], npass = item_off[t + 1] - item_off[t];
+    const int32_t row = row_list[t];
+    int32_t c_lo = bounds[item];
+    const int64_t c_hi = pass + 1 < npass ? (int64_t)bounds[item + 1] : ncols;
+    if (upper && c_lo < row) c_lo = row;
+    for (int k = tid; k < S; k += NT) {
+        keys[k] = HASH_EMPTY;
+        vals[k] = vt<T>::zero();
+    }
+    if (tid == 0) n_out = 0;
+    __syncthreads();
+    const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+    for (int64_t base = a0; base < a1; base += NT) {
+        // 1. every thread: the slice of one B row that falls in [c_lo, c_hi)
+        int len = 0;
+        if (base + tid < a1) {
+            const int32_t kk = acol[base + tid];
+            const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
+            int64_t s = b0, e = b1;
+            if (b0 < b1) {
+                if (c_lo > 0) s = lower_bound_col(bcol, b0, b1, c_lo);
+                if (c_hi < ncols) e = lower_bound_col(bcol, s, b1, (int32_t)c_hi);
+            }
+            qlo[tid] = s;
+            a_s[tid] = aval[base + tid];
+            len = (int)(e - s);
+        }
+        // 2. inclusive scan of the slice lengths
+        int cur = 0;
+        pre[0][tid] = len;
+        __syncthreads();
+        for (int d = 1; d < NT; d <<= 1) {
+            const int v = pre[cur][tid] + (tid >= d ? pre[cur][tid - d] : 0);
+            pre[cur ^ 1][tid] = v;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const int* inc = pre[cur];
+        const int total = inc[NT - 1];
+        // 3. the slices as one flat list of products
+        for (int f = tid; f < total; f += NT) {
+            int l = 0, h = NT - 1;  // first entry whose inclusive prefix exceeds f
+            while (l < h) {
+                const int mid = (l + h) >> 1;
+                if (inc[mid] > f) h = mid; else l = mid + 1;
+            }
+            const int64_t q = qlo[l] + (f - (l ? inc[l - 1] : 0));
+            const int32_t j = bcol[q];
+            const T v = vt<T>::mul(a_s[l], bval[q]);
+            uint32_t hsh = hash_col(j, LOG2S);
+            for (;;) {
+                const int32_t old = atomicCAS(&keys[hsh], HASH_EMPTY, j);
+                if (old == HASH_EMPTY || old == j) {
+                    atomic_accum(&vals[hsh], v);
+                    break;
+                }
+                hsh = (hsh + 1) & (S - 1);
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t out0 = cptr[row] + pass * cap;
+    for (int k = tid; k < S; k += NT) {
+        const int32_t key = keys[k];
+        if (key != HASH_EMPTY) {
+            const int pos = atomicAdd(&n_out, 1);
+            ccol[out0 + pos] = key;
+            cval[out0 + pos] = vals[k];
+        }
+    }
+}
+
 // ---- dense-output variant (spmmd): one wave per row, products scattered with L2 atomics ------------
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -569,6 +780,54 @@ static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt
                 MI_LAUNCH((k_spgemm_lds<T, 14, 1024, NUMERIC>), dim3((unsigned)b.n[5]), dim3(1024), c.stream,
                           MI_SPGEMM_ARGS(b.list[5]), gw, (int)upper, row_nnz, cptr, ccol, cval);
                 b.n[5] = 0;
+            }
+        }
+    }
+    // Big rows through LDS (column bitmap + range-partitioned hash, see k_spgemm_bitmap / k_spgemm_part);
+    // when B is too wide for a bitmap or its rows are not sorted they stay for the global-memory hash.
+    if (!force_global && options().spgemm_lds_parts) {
+        const int first = NUMERIC ? (sizeof(T) >= 16 ? 4 : 5) : 6;
+        int64_t nbig = 0;
+        for (int k = first; k < NBINS; ++k) nbig += b.n[k];
+        const int64_t words = (B.cols + 31) / 32;
+        bool can = (size_t)words * 4 <= (size_t)148 * 1024 && B.nnz < ((int64_t)1 << 31);
+        if (nbig && can && NUMERIC) can = rows_sorted(B);
+        if (nbig && can) {
+            int32_t* big_list = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)nbig));
+            int64_t off = 0;
+            for (int k = NBINS - 1; k >= first; --k) {  // largest class first
+                if (!b.n[k]) continue;
+                MI_HIP_CHECK(hipMemcpyAsync(big_list + off, b.list[k], sizeof(int32_t) * (size_t)b.n[k],
+                                            hipMemcpyDeviceToDevice, c.stream));
+                off += b.n[k];
+                b.n[k] = 0;
+            }
+            unsigned long long* counter = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long)));
+            MI_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), c.stream));
+            const int64_t nblocks = nbig < 512 ? nbig : 512;
+            if constexpr (!NUMERIC) {
+                MI_LAUNCH_SMEM((k_spgemm_bitmap<false>), dim3((unsigned)nblocks), dim3(1024), (size_t)words * 4, c.stream, nbig,
+                               (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
+                               (const int64_t*)B.ptr, (const int32_t*)B.col, gw, (int)upper, row_nnz,
+                               (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, counter);
+            } else {
+                constexpr int64_t CAP = ((int64_t)1 << part_log2s<T>()) / 2;
+                int64_t* items = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                int64_t* item_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                MI_LAUNCH(k_part_items, dim3((unsigned)ceil_div(nbig, 256)), dim3(256), c.stream, (const int32_t*)big_list,
+                          cnt, nbig, CAP, items);
+                const int64_t n_items = exclusive_scan_i64(items, item_off, nbig);
+                if (n_items > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "SpGEMM result too large for one launch");
+                int32_t* bounds = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(n_items + 1)));
+                MI_LAUNCH_SMEM((k_spgemm_bitmap<true>), dim3((unsigned)nblocks), dim3(1024), (size_t)words * 4, c.stream, nbig,
+                               (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
+                               (const int64_t*)B.ptr, (const int32_t*)B.col, gw, (int)upper, (int64_t*)nullptr,
+                               (const int64_t*)item_off, CAP, bounds, counter);
+                if (n_items)
+                    MI_LAUNCH((k_spgemm_part<T>), dim3((unsigned)n_items), dim3(PART_THREADS), c.stream,
+                              (const int32_t*)big_list, (const int64_t*)item_off, nbig, (const int32_t*)bounds, B.cols, CAP,
+                              (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,
+                              (const int32_t*)B.col, (const T*)B.val, (int)upper, cptr, ccol, cval);
             }
         }
     }

@@ -564,6 +564,52 @@ def test_spgemm_all_bins(gpu, oracle, dtype):
         _check_spgemm(got, want, dtype)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
+def test_spgemm_hub_rows_lds_bitmap_and_partitioned_classes(gpu, dtype):
+    """Rows far beyond the LDS hash bins (tens of thousands of distinct columns): symbolic through the LDS
+    column bitmap, numeric through hash-partitioned LDS classes; same structure and values as the
+    global-memory hash path and as scipy (bit-exact structure, values to tolerance)."""
+    rng = np.random.default_rng(5)
+    k, n = 4000, 60000
+    a = sps.random(200, k, density=0.002, format="lil", random_state=1, dtype=np.float64)
+    a[0, rng.choice(k, 700, replace=False)] = 1.5
+    a[7, rng.choice(k, 90, replace=False)] = -0.5
+    a[13, rng.choice(k, 2500, replace=False)] = 0.25
+    a[199, rng.choice(k, 1500, replace=False)] = 0.75
+    a = a.tocsr().astype(dtype)
+    b = sps.random(k, n, density=100 / n, format="csr", random_state=2, dtype=np.float64).astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        a.data = a.data + 1j * a.data[::-1]
+        b.data = b.data * (1 - 0.5j)
+    want = (a.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64) @ b).tocsr()
+    want.sort_indices()
+    assert np.diff(want.indptr).max() > 40000
+    for parts in (1, 0):
+        gpu.mi_set_option("spgemm_lds_parts", parts)
+        try:
+            got = gpu.dot_product_mkl(a, b)
+        finally:
+            gpu.mi_set_option("spgemm_lds_parts", 1)
+        _check_spgemm(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gram_sparse_hub_rows(gpu, dtype):
+    """A^T A (upper triangle, mkl_sparse_syrk semantics) with hub rows in the product."""
+    rng = np.random.default_rng(6)
+    a = sps.random(3000, 30000, density=20 / 30000, format="lil", random_state=3, dtype=np.float64)
+    a[rng.choice(3000, 800, replace=False), 5] = 1.0      # column 5 of A is heavy -> row 5 of A^T A is a hub
+    a[rng.choice(3000, 1500, replace=False), 29000] = 2.0  # hub near the end: short upper-triangular row
+    a = a.tocsr().astype(dtype)
+    want = sps.triu((a.T.astype(np.float64) @ a.astype(np.float64))).tocsr()
+    want.sort_indices()
+    got = gpu.gram_matrix_mkl(a, reorder_output=True)
+    g = got.tocsr()
+    # explicit zeros can only come from cancellation; all values here are positive
+    assert np.array_equal(g.indptr, want.indptr) and np.array_equal(g.indices, want.indices)
+    assert rel_err(g.data, want.data) <= tol(dtype)
+
+
 def test_spgemm_keeps_cancelled_entries_and_sums_duplicates(gpu):
     a = sps.csr_matrix(np.array([[1.0, -1.0, 0.0], [0.0, 2.0, 0.0]]))
     b = sps.csr_matrix(np.array([[1.0, 0.0], [1.0, 0.0], [0.0, 3.0]]))

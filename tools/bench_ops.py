@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--global-mode", type=int, default=-1)
     ap.add_argument("--no-order", action="store_true", help="SpGEMM: skip the mi_sparse_order timing (needs 2 extra nnz-sized buffers)")
+    ap.add_argument("--lds-parts", type=int, default=-1, help="SpGEMM: 0 disables the LDS bitmap / partitioned-class big-row path")
     ap.add_argument("--force-global", action="store_true", help="SpGEMM: send every row through the global-memory hash")
     args = ap.parse_args()
 
@@ -49,6 +50,8 @@ def main():
         sda.mi_set_option("spgemm_force_global", 1)
     if args.global_mode >= 0:
         sda.mi_set_option("spgemm_global_mode", args.global_mode)
+    if args.lds_parts >= 0:
+        sda.mi_set_option("spgemm_lds_parts", args.lds_parts)
 
     def make(kind, n_rows_log2, ncols, per_row, seed, dtype):
         if kind == "rmat":

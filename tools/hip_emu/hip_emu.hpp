@@ -181,6 +181,8 @@ inline int atomicCAS(int* p, int cmp, int val)
     return cmp;
 }
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline long long atomicMax(long long* p, long long v)
 {
     long long old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
