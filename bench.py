@@ -275,6 +275,7 @@ def main():
         except Exception:
             traffic = None
     tagged = bool(sda.mi_get_counter("spmm_last_tagged"))
+    hot_coverage = round(sda.mi_get_counter("spmm_hot_coverage"), 4)  # of the timed matrix (the counters are "last call")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_spmm<float,4,%d,%d,%s>" % (32 if N == 128 else 64 if N >= 256 else 16, args.unroll or 4,
@@ -358,8 +359,7 @@ def main():
                                       if args.workload == "rmat" else "uniform 32/row", n, n, nnz, n, N),
                        "partition": "1-D row blocks, one block per GPU" if world > 1 else "single GPU",
                        "spmm_chunk": args.chunk or 256,
-                       "hot_cold_tagged_gather": bool(sda.mi_get_counter("spmm_last_tagged")),
-                       "hot_column_coverage": round(sda.mi_get_counter("spmm_hot_coverage"), 4)},
+                       "hot_cold_tagged_gather": tagged, "hot_column_coverage": hot_coverage},
             "roofline": roofline, "cpu_baseline": cpu, "parity_max_rel_err_sample": worst,
         }
         if collectives:

@@ -185,19 +185,25 @@ inline int guarded(F&& body) noexcept
 // ------------------------------------------------------------------------------------------------
 // per-thread context
 // ------------------------------------------------------------------------------------------------
-struct DevBuf {  // owning device allocation
+// Owning device allocation.  Blocks come from / return to a per-device cache (runtime.hip): HBM is
+// expensive to map -- a fresh 100 GB result costs ~1 s in hipMalloc, and hipFree + hipMalloc of the
+// same size several seconds -- so a released block is kept (up to half of the device memory,
+// option "pool_max_mb") and handed to the next request of about the same size.
+struct DevBuf {
     void* p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;  // usable size (>= the size asked for)
+    int dev = -1;      // device the block lives on
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), dev(o.dev) { o.p = nullptr; o.bytes = 0; }
     DevBuf& operator=(DevBuf&& o) noexcept
     {
         if (this != &o) {
             release();
             p = o.p;
             bytes = o.bytes;
+            dev = o.dev;
             o.p = nullptr;
             o.bytes = 0;
         }
@@ -209,6 +215,9 @@ struct DevBuf {  // owning device allocation
     template <typename T>
     T* as() const { return static_cast<T*>(p); }
 };
+
+void pool_trim();       // return every cached block to the driver
+void pool_reset_cap();  // re-read pool_max_mb on the next release
 
 struct Context {
     bool initialised = false;
@@ -334,6 +343,9 @@ struct Options {
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)
     int64_t spgemm_global_mode = 0;  // 0: one workgroup per row, L2-local atomics; 1: cooperative, agent-scope atomics
+    int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
+    int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory
+    int64_t trace_phases = 0;      // print host wall-clock per SpGEMM phase to stderr (diagnostics; synchronises)
     int64_t profile_events = 0;    // bracket the SpMM main kernel with hipEvents (diagnostics)
 };
 struct Counters {

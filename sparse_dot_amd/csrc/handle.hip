@@ -228,6 +228,96 @@ __global__ void __launch_bounds__(1024) k_sort_global(const int64_t* ptr, int32_
     }
 }
 
+// rows longer than SORT_BLOCK_MAX in a matrix of at most ~1 M columns: counting sort through an LDS
+// bitmap of the row's columns.  The sorted position of an entry is the RANK of its column in the
+// bitmap (popcount prefix), the sorted columns are the enumeration of the set bits: O(len + cols/32)
+// per row, no comparisons.  A row with a repeated column (rank would collide; SpGEMM results never
+// have one) is handed to the comparison sort instead.
+constexpr int SORT_BITMAP_GROUP = 8;  // words per stored popcount prefix
+
+__global__ void __launch_bounds__(1024)
+    k_sort_bitmap(const int64_t* __restrict__ ptr, int32_t* col, const int64_t* __restrict__ big_rows, int64_t n_big,
+                  int64_t ncols, int64_t* __restrict__ perm, unsigned long long* n_fallback, int64_t* fallback_rows,
+                  unsigned long long* work_counter)
+{
+    MI_DYN_SMEM(smem);
+    const int64_t words = (ncols + 31) / 32;
+    const int64_t groups = (words + SORT_BITMAP_GROUP - 1) / SORT_BITMAP_GROUP;
+    unsigned* bits = reinterpret_cast<unsigned*>(smem);
+    int* gpre = reinterpret_cast<int*>(bits + words);
+    __shared__ int scan[2][1024];
+    __shared__ long long next_idx;
+    const int tid = threadIdx.x, threads = blockDim.x;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) next_idx = (long long)atomicAdd(work_counter, 1ull);
+        __syncthreads();
+        const int64_t idx = next_idx;
+        if (idx >= n_big) break;
+        const int64_t row = big_rows[idx];
+        const int64_t p0 = ptr[row], len = ptr[row + 1] - p0;
+        for (int64_t k = tid; k < words; k += threads) bits[k] = 0u;
+        __syncthreads();
+        for (int64_t k = tid; k < len; k += threads) {
+            const int32_t c = col[p0 + k];
+            atomicOr(&bits[c >> 5], 1u << (c & 31));
+        }
+        __syncthreads();
+        for (int64_t g = tid; g < groups; g += threads) {
+            int sum = 0;
+            const int64_t w1 = (g + 1) * SORT_BITMAP_GROUP < words ? (g + 1) * SORT_BITMAP_GROUP : words;
+            for (int64_t w = g * SORT_BITMAP_GROUP; w < w1; ++w) sum += __popc(bits[w]);
+            gpre[g] = sum;
+        }
+        __syncthreads();
+        // exclusive scan of the group counts: contiguous chunk per thread + scan of the chunk sums
+        const int64_t per = (groups + threads - 1) / threads;
+        const int64_t g0 = (int64_t)tid * per, g1 = g0 + per < groups ? g0 + per : groups;
+        int local = 0;
+        for (int64_t g = g0; g < g1; ++g) local += gpre[g];
+        int cur = 0;
+        scan[0][tid] = local;
+        __syncthreads();
+        for (int d = 1; d < threads; d <<= 1) {
+            const int v = scan[cur][tid] + (tid >= d ? scan[cur][tid - d] : 0);
+            scan[cur ^ 1][tid] = v;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const int total = scan[cur][threads - 1];
+        if ((int64_t)total != len) {  // repeated column in the row (uniform decision for the whole block)
+            if (tid == 0) fallback_rows[atomicAdd(n_fallback, 1ull)] = row;
+            continue;
+        }
+        int run = scan[cur][tid] - local;
+        for (int64_t g = g0; g < g1; ++g) {
+            const int cnt = gpre[g];
+            gpre[g] = run;
+            run += cnt;
+        }
+        __syncthreads();
+        for (int64_t k = tid; k < len; k += threads) {
+            const int32_t c = col[p0 + k];
+            const int64_t w = c >> 5, g = w / SORT_BITMAP_GROUP;
+            int r = gpre[g] + __popc(bits[w] & ((1u << (c & 31)) - 1u));
+            for (int64_t ww = g * SORT_BITMAP_GROUP; ww < w; ++ww) r += __popc(bits[ww]);
+            perm[p0 + r] = p0 + k;
+        }
+        __syncthreads();  // every column has been read: rewrite them in order from the bitmap
+        for (int64_t g = tid; g < groups; g += threads) {
+            int64_t out = p0 + gpre[g];
+            const int64_t w1 = (g + 1) * SORT_BITMAP_GROUP < words ? (g + 1) * SORT_BITMAP_GROUP : words;
+            for (int64_t w = g * SORT_BITMAP_GROUP; w < w1; ++w) {
+                unsigned word = bits[w];
+                while (word) {
+                    col[out++] = (int32_t)(w * 32 + __builtin_ctz(word));
+                    word &= word - 1;
+                }
+            }
+        }
+    }
+}
+
 // classify rows for the sort tiers: writes row ids of medium / large rows through atomic cursors
 __global__ void k_sort_classify(const int64_t* ptr, int64_t rows, int64_t* n_med, int64_t* med_rows,
                                 int64_t* n_big, int64_t* big_rows)
@@ -315,7 +405,8 @@ void sort_csr(char vtype, Csr& a)
     int64_t hc[2] = {0, 0};
     MI_HIP_CHECK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, c.stream));
     MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-    const int64_t n_med = hc[0], n_big = hc[1];
+    const int64_t n_med = hc[0];
+    int64_t n_big = hc[1];
 
     MI_LAUNCH(k_sort_small, grid1d(a.rows, SORT_ROWS_PER_SMALL_BLOCK), dim3(64), c.stream, (const int64_t*)a.ptr,
               a.col, a.rows, perm);
@@ -328,6 +419,23 @@ void sort_csr(char vtype, Csr& a)
         if (n_med)
             MI_LAUNCH(k_sort_block, dim3((unsigned)n_med), dim3(256), c.stream, (const int64_t*)a.ptr, a.col,
                       (const int64_t*)med_rows, perm);
+        if (n_big) {
+            const int64_t words = (a.cols + 31) / 32;
+            const size_t bitmap_bytes = sizeof(unsigned) * (size_t)(words + ceil_div(words, (int64_t)SORT_BITMAP_GROUP));
+            if (bitmap_bytes <= (size_t)144 * 1024) {  // counting sort through the LDS bitmap; rows it refuses stay "big"
+                unsigned long long* cnt2 = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * 2));
+                int64_t* fallback = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
+                MI_HIP_CHECK(hipMemsetAsync(cnt2, 0, sizeof(unsigned long long) * 2, c.stream));
+                MI_LAUNCH_SMEM(k_sort_bitmap, dim3((unsigned)(n_big < 512 ? n_big : 512)), dim3(1024), bitmap_bytes, c.stream,
+                               (const int64_t*)a.ptr, a.col, (const int64_t*)big_rows, n_big, a.cols, perm, cnt2, fallback,
+                               cnt2 + 1);
+                unsigned long long nf = 0;
+                MI_HIP_CHECK(hipMemcpyAsync(&nf, cnt2, sizeof(nf), hipMemcpyDeviceToHost, c.stream));
+                MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+                n_big = (int64_t)nf;
+                big_rows = fallback;
+            }
+        }
         if (n_big) {
             // slab sizes (pow2-padded row lengths) and their offsets, computed on the device
             int64_t* sizes = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));

@@ -1,5 +1,6 @@
 // runtime.hip -- errors, per-thread context, device memory, service entry points, scan.
 #include <cstdarg>
+#include <map>
 
 #include "common.hpp"
 
@@ -28,27 +29,128 @@ void fail(int status, const char* fmt, ...)
 }
 
 // ---- device memory -----------------------------------------------------------------------------
+namespace {
+constexpr int POOL_MAX_DEVICES = 64;
+struct BlockPool {
+    std::mutex m;
+    std::multimap<size_t, void*> blocks[POOL_MAX_DEVICES];  // size -> cached block, per device
+    size_t cached = 0;
+    size_t cap = 0;  // resolved lazily from pool_max_mb / the device memory
+};
+BlockPool& pool()
+{
+    static BlockPool* p = new BlockPool();  // leaked on purpose: HIP may be gone at static destruction
+    return *p;
+}
+
+// small requests: next power of two (exact-size classes); large ones: next multiple of 2 MiB
+size_t pool_round(size_t n)
+{
+    if (n <= (size_t(1) << 20)) {
+        size_t r = 256;
+        while (r < n) r <<= 1;
+        return r;
+    }
+    const size_t g = size_t(2) << 20;
+    return (n + g - 1) / g * g;
+}
+
+void pool_trim_locked(BlockPool& bp)
+{
+    for (auto& per_dev : bp.blocks) {
+        for (auto& kv : per_dev) (void)hipFree(kv.second);
+        per_dev.clear();
+    }
+    bp.cached = 0;
+}
+}  // namespace
+
+void pool_reset_cap()
+{
+    BlockPool& bp = pool();
+    std::lock_guard<std::mutex> lk(bp.m);
+    bp.cap = 0;
+}
+
+void pool_trim()
+{
+    BlockPool& bp = pool();
+    std::lock_guard<std::mutex> lk(bp.m);
+    pool_trim_locked(bp);
+}
+
 void DevBuf::alloc(size_t n)
 {
     release();
-    ctx().ensure();
-    const size_t want = n ? n : 16;
+    Context& c = ctx();
+    c.ensure();
+    const size_t want = pool_round(n ? n : 16);
+    const int d = c.device;
+    BlockPool& bp = pool();
+    if (d >= 0 && d < POOL_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(bp.m);
+        auto it = bp.blocks[d].lower_bound(want);
+        if (it != bp.blocks[d].end() && it->first <= want + want / 8) {  // best fit, at most 12.5 % slack
+            p = it->second;
+            bytes = it->first;
+            dev = d;
+            bp.cached -= it->first;
+            bp.blocks[d].erase(it);
+            return;
+        }
+    }
     hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {  // give the cache back to the driver and try once more
+        (void)hipGetLastError();
+        pool_trim();
+        e = hipMalloc(&p, want);
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         p = nullptr;
         fail(MI_SPARSE_STATUS_ALLOC_FAILED, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
     }
     bytes = want;
+    dev = d;
 }
 
 void DevBuf::release()
 {
-    if (p) {
-        (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
+    if (!p) return;
+    void* q = p;
+    const size_t n = bytes;
+    p = nullptr;
+    bytes = 0;
+    int cur = -1;
+    if (options().pool_enable && dev >= 0 && dev < POOL_MAX_DEVICES && hipGetDevice(&cur) == hipSuccess && cur == dev) {
+        BlockPool& bp = pool();
+        {
+            std::lock_guard<std::mutex> lk(bp.m);
+            if (!bp.cap) {
+                const int64_t mb = options().pool_max_mb;
+                size_t free_b = 0, total_b = 0;
+                if (mb >= 0)
+                    bp.cap = (size_t)mb << 20;
+                else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                    bp.cap = total_b / 2;
+                if (!bp.cap) bp.cap = 1;  // resolved: nothing is cached
+            }
+            if (bp.cached + n > bp.cap) goto direct;
+        }
+        // same guarantee hipFree gives: nothing enqueued on the device still uses the block once it can be reused
+        if (hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            goto direct;
+        }
+        {
+            std::lock_guard<std::mutex> lk(bp.m);
+            bp.blocks[dev].emplace(n, q);
+            bp.cached += n;
+        }
+        return;
     }
+direct:
+    (void)hipFree(q);
 }
 
 // ---- context -----------------------------------------------------------------------------------
@@ -359,6 +461,17 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.spgemm_lds_parts = value;
         } else if (!strcmp(name, "spgemm_global_mode")) {
             o.spgemm_global_mode = value;
+        } else if (!strcmp(name, "pool_enable")) {
+            o.pool_enable = value;
+            if (!value) mi::pool_trim();
+        } else if (!strcmp(name, "pool_max_mb")) {
+            o.pool_max_mb = value;
+            mi::pool_trim();
+            mi::pool_reset_cap();
+        } else if (!strcmp(name, "pool_trim")) {
+            mi::pool_trim();
+        } else if (!strcmp(name, "trace_phases")) {
+            o.trace_phases = value;
         } else if (!strcmp(name, "profile_events")) {
             o.profile_events = value;
         } else {

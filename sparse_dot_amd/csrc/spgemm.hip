@@ -14,6 +14,7 @@
 // Column order inside a row of C is unspecified (as with mkl_sparse_spmm); mi_sparse_order sorts.
 // Entries that cancel to 0.0 stay (MKL keeps them; scipy prunes -- SURVEY section 8 a3).
 #include "common.hpp"
+#include <chrono>
 
 namespace mi {
 
@@ -431,6 +432,20 @@ template <typename T>
 constexpr int part_log2s() { return sizeof(T) >= 16 ? 11 : 12; }  // 2048 slots for complex double, else 4096
 
 constexpr int PART_THREADS = 512;
+constexpr int PART_UNROLL = 2;
+constexpr int BITMAP_UNROLL = 4;
+
+// inc[0..N) non-decreasing (inclusive prefix sums), f < inc[N-1]: the number of entries <= f, i.e. the
+// index of the slice that holds flat position f.  Fixed trip count, no divergence.
+template <int N>
+__device__ __forceinline__ int flat_find(const int* inc, int f)
+{
+    int l = 0;
+#pragma unroll
+    for (int step = N / 2; step > 0; step >>= 1)
+        if (inc[l + step - 1] <= f) l += step;
+    return l;
+}
 
 template <bool BOUNDS>
 __global__ void __launch_bounds__(1024)
@@ -445,7 +460,8 @@ __global__ void __launch_bounds__(1024)
     __shared__ int counter;
     __shared__ long long next_idx;
     __shared__ int scan[2][1024];
-    const int tid = threadIdx.x, threads = blockDim.x;
+    __shared__ int64_t qlo[1024];
+    const int tid = threadIdx.x, threads = blockDim.x;  // launched with 1024 threads
     const int64_t words = (ncols + 31) / 32;
     for (;;) {
         __syncthreads();
@@ -459,16 +475,44 @@ __global__ void __launch_bounds__(1024)
         const int32_t row = row_list[idx];
         for (int64_t k = tid; k < words; k += threads) bits[k] = 0u;
         __syncthreads();
-        const int group = tid / gw, ngroups = threads / gw, gl = tid % gw;
-        for (int64_t p = aptr[row] + group; p < aptr[row + 1]; p += ngroups) {
-            const int32_t kk = acol[p];
-            for (int64_t q = bptr[kk] + gl; q < bptr[kk + 1]; q += gw) {
-                const int32_t j = bcol[q];
-                if (upper && j < row) continue;
-                atomicOr(&bits[j >> 5], 1u << (j & 31));
+        // the rows of B selected by this row of A, 1024 at a time, walked as one flat list of products (a hub
+        // row of B spreads over the whole workgroup; BITMAP_UNROLL loads in flight per lane)
+        for (int64_t base = aptr[row]; base < aptr[row + 1]; base += 1024) {
+            int len = 0;
+            if (base + tid < aptr[row + 1]) {
+                const int32_t kk = acol[base + tid];
+                const int64_t b0 = bptr[kk];
+                qlo[tid] = b0;
+                len = (int)(bptr[kk + 1] - b0);
             }
+            int cur = 0;
+            scan[0][tid] = len;
+            __syncthreads();
+            for (int d = 1; d < 1024; d <<= 1) {
+                const int v = scan[cur][tid] + (tid >= d ? scan[cur][tid - d] : 0);
+                scan[cur ^ 1][tid] = v;
+                cur ^= 1;
+                __syncthreads();
+            }
+            const int* inc = scan[cur];
+            const int total = inc[1023];
+            for (int f0 = tid; f0 < total; f0 += 1024 * BITMAP_UNROLL) {
+                int32_t j[BITMAP_UNROLL];
+#pragma unroll
+                for (int u = 0; u < BITMAP_UNROLL; ++u) {
+                    const int f = f0 + u * 1024;
+                    j[u] = -1;
+                    if (f < total) {
+                        const int l = flat_find<1024>(inc, f);
+                        j[u] = bcol[qlo[l] + (f - (l ? inc[l - 1] : 0))];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < BITMAP_UNROLL; ++u)
+                    if (j[u] >= 0 && !(upper && j[u] < row)) atomicOr(&bits[j[u] >> 5], 1u << (j[u] & 31));
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if constexpr (!BOUNDS) {
             int local = 0;
             for (int64_t k = tid; k < words; k += threads) local += __popc(bits[k]);
@@ -594,23 +638,32 @@ __global__ void __launch_bounds__(PART_THREADS)
         const int* inc = pre[cur];
         const int total = inc[NT - 1];
         // 3. the slices as one flat list of products
-        for (int f = tid; f < total; f += NT) {
-            int l = 0, h = NT - 1;  // first entry whose inclusive prefix exceeds f
-            while (l < h) {
-                const int mid = (l + h) >> 1;
-                if (inc[mid] > f) h = mid; else l = mid + 1;
-            }
-            const int64_t q = qlo[l] + (f - (l ? inc[l - 1] : 0));
-            const int32_t j = bcol[q];
-            const T v = vt<T>::mul(a_s[l], bval[q]);
-            uint32_t hsh = hash_col(j, LOG2S);
-            for (;;) {
-                const int32_t old = atomicCAS(&keys[hsh], HASH_EMPTY, j);
-                if (old == HASH_EMPTY || old == j) {
-                    atomic_accum(&vals[hsh], v);
-                    break;
+        for (int f0 = tid; f0 < total; f0 += NT * PART_UNROLL) {
+            int32_t j[PART_UNROLL];
+            T v[PART_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PART_UNROLL; ++u) {
+                const int f = f0 + u * NT;
+                j[u] = -1;
+                if (f < total) {
+                    const int l = flat_find<NT>(inc, f);
+                    const int64_t q = qlo[l] + (f - (l ? inc[l - 1] : 0));
+                    j[u] = bcol[q];
+                    v[u] = vt<T>::mul(a_s[l], bval[q]);
                 }
-                hsh = (hsh + 1) & (S - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < PART_UNROLL; ++u) {
+                if (j[u] < 0) continue;
+                uint32_t hsh = hash_col(j[u], LOG2S);
+                for (;;) {
+                    const int32_t old = atomicCAS(&keys[hsh], HASH_EMPTY, j[u]);
+                    if (old == HASH_EMPTY || old == j[u]) {
+                        atomic_accum(&vals[hsh], v[u]);
+                        break;
+                    }
+                    hsh = (hsh + 1) & (S - 1);
+                }
             }
         }
         __syncthreads();
@@ -790,7 +843,7 @@ static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt
         int64_t nbig = 0;
         for (int k = first; k < NBINS; ++k) nbig += b.n[k];
         const int64_t words = (B.cols + 31) / 32;
-        bool can = (size_t)words * 4 <= (size_t)148 * 1024 && B.nnz < ((int64_t)1 << 31);
+        bool can = (size_t)words * 4 <= (size_t)136 * 1024 && B.nnz < ((int64_t)1 << 31);
         if (nbig && can && NUMERIC) can = rows_sorted(B);
         if (nbig && can) {
             int32_t* big_list = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)nbig));
@@ -932,6 +985,15 @@ template <typename T>
 static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
 {
     Context& c = ctx();
+    const bool trace = options().trace_phases != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mi_sparse spgemm] %-18s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (A.cols != B.rows)
         fail(MI_SPARSE_STATUS_INVALID_VALUE, "dimension mismatch: (%lld x %lld) * (%lld x %lld)", (long long)A.rows,
              (long long)A.cols, (long long)B.rows, (long long)B.cols);
@@ -946,17 +1008,21 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
         MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows,
                   (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, ub);
     const int64_t max_ub = device_max(ub, A.rows);
+    mark("row upper bounds");
     run_phase<T, false>(A, B, upper, ub, max_ub, row_nnz, nullptr, nullptr, nullptr);
+    mark("symbolic");
     const int64_t nnz = exclusive_scan_i64(row_nnz, C.ptr, C.rows);
     C.nnz = nnz;
     C.col_own.alloc(sizeof(int32_t) * (size_t)nnz);
     C.val_own.alloc(sizeof(T) * (size_t)nnz);
     C.col = C.col_own.as<int32_t>();
     C.val = C.val_own.p;
+    mark("scan + allocate C");
     if (nnz > 0) {
         const int64_t max_nnz = device_max(row_nnz, A.rows);
         run_phase<T, true>(A, B, upper, row_nnz, max_nnz, nullptr, C.ptr, C.col, static_cast<T*>(C.val));
     }
+    mark("numeric");
     C.valid = true;
     C.sorted = false;
 }

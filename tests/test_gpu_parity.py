@@ -524,6 +524,33 @@ def test_order_huge_row_global_tier(gpu):
     assert np.array_equal(out.indices, ref.indices) and np.array_equal(out.data, ref.data)
 
 
+@pytest.mark.parametrize("dup", [False, True])
+def test_order_big_rows_bitmap_counting_sort(gpu, dup):
+    """Rows longer than the LDS comparison-sort tiers are ordered by a counting sort through an LDS column
+    bitmap; a row with a repeated column falls back to the (stable) comparison sort."""
+    from sparse_dot_amd._mi_interface import SparseHandle
+    rng = np.random.default_rng(31)
+    ncols = 200000
+    lens = [20000, 3, 9000, 0, 150000, 600, 8193]
+    cols = [rng.permutation(ncols)[:l].astype(np.int32) for l in lens]
+    if dup:
+        cols[0][5] = cols[0][9000]
+        cols[4][0] = cols[4][1] = cols[4][149999]
+    ind = np.concatenate(cols)
+    dat = rng.uniform(0.5, 1.5, ind.size)
+    ptr = np.concatenate([[0], np.cumsum(lens)])
+    a = sps.csr_matrix((dat, ind, ptr), shape=(len(lens), ncols))
+    with SparseHandle.from_scipy(a) as h:
+        h.order()
+        out = h.export("csr_matrix")
+    ri, rd = ind.copy(), dat.copy()
+    for r in range(len(lens)):
+        lo, hi = ptr[r], ptr[r + 1]
+        o = np.argsort(ind[lo:hi], kind="stable")
+        ri[lo:hi], rd[lo:hi] = ind[lo:hi][o], dat[lo:hi][o]
+    assert np.array_equal(out.indices, ri) and np.array_equal(out.data, rd)
+
+
 # ---- SpGEMM -----------------------------------------------------------------------------------------
 def _check_spgemm(got, want, dtype):
     g = got.tocsr().copy()
@@ -608,6 +635,22 @@ def test_gram_sparse_hub_rows(gpu, dtype):
     # explicit zeros can only come from cancellation; all values here are positive
     assert np.array_equal(g.indptr, want.indptr) and np.array_equal(g.indices, want.indices)
     assert rel_err(g.data, want.data) <= tol(dtype)
+
+
+def test_device_block_cache_options(gpu, oracle):
+    """Released device blocks are cached for reuse (hipMalloc of large results is slow); the cache can be
+    switched off, capped and trimmed through mi_sparse_set_option, and results do not depend on it."""
+    a = pos_csr(400, 300, 0.05, np.float64, 5)
+    b = pos_csr(300, 350, 0.05, np.float64, 6)
+    want = oracle.spgemm(a, b)
+    try:
+        for setting in (("pool_enable", 0), ("pool_enable", 1), ("pool_max_mb", 1), ("pool_trim", 1), ("pool_max_mb", -1)):
+            gpu.mi_set_option(*setting)
+            for _ in range(3):
+                _check_spgemm(gpu.dot_product_mkl(a, b), want, np.float64)
+    finally:
+        gpu.mi_set_option("pool_enable", 1)
+        gpu.mi_set_option("pool_max_mb", -1)
 
 
 def test_spgemm_keeps_cancelled_entries_and_sums_duplicates(gpu):

@@ -96,7 +96,7 @@ def main():
         b = make(args.kind, args.scale, 1 << args.scale, per_row, 23 if args.kind == "rmat" else 2, dt)
         ha = handle("d", *a[:3], a[3], a[4])
         hb = handle("d", *b[:3], b[3], b[4])
-        times = []
+        times, order_times = [], []
         hc = None
         for rep in range(args.reps + 1):
             if hc is not None:
@@ -108,6 +108,11 @@ def main():
             torch.cuda.synchronize()
             if rep:
                 times.append(time.perf_counter() - t0)
+            if not args.no_order and rep < args.reps:  # the last result is ordered after the row-sum check below
+                t0 = time.perf_counter()
+                _check_return_value(MI.call("mi_sparse_order", hc), "order")
+                torch.cuda.synchronize()
+                order_times.append(time.perf_counter() - t0)  # first one pays the scratch-arena growth (hipMalloc)
         t = sorted(times)[len(times) // 2]
         m, n, nnzc, _, _, _ = dev_csr(hc, dt)
         # products = sum_k colnnz_A(k) * rownnz_B(k)
@@ -128,12 +133,13 @@ def main():
         if not args.no_order:
             _check_return_value(MI.call("mi_sparse_order", hc), "order")
         torch.cuda.synchronize()
-        t_order = time.perf_counter() - t0
+        order_times.append(time.perf_counter() - t0)
+        t_order = min(order_times)
         nbytes = (a[1].numel() + b[1].numel() + nnzc) * 12 + 3 * (m + 1) * 8
         out.update({"config": "%s 2^%d x 2^%d, %d/row fp64 x same" % (args.kind, args.scale, args.scale, per_row),
                     "nnzA": int(a[1].numel()), "nnzB": int(b[1].numel()), "nnzC": int(nnzc), "products": products,
                     "ms": t * 1e3, "gflops": 2 * products / t / 1e9, "algorithmic_GBps": nbytes / t / 1e9,
-                    "order_ms": t_order * 1e3, "rowsum_max_rel_err": rel,
+                    "order_ms": t_order * 1e3, "order_first_call_ms": order_times[0] * 1e3, "rowsum_max_rel_err": rel,
                     "checks": {"rowsum_1e-12": rel <= 1e-12, "nnzC_le_products": nnzc <= products}})
         for h in (ha, hb, hc):
             MI.call("mi_sparse_destroy", h)

@@ -195,6 +195,9 @@ inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "s
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = *t = size_t(8) << 30; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int)
 {
     std::snprintf(p->name, sizeof(p->name), "host-thread emulation");
