@@ -342,6 +342,9 @@ struct Options {
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)
+    int64_t spgemm_part_log2s_bias = 0;  // tuning: +1 / -1 forces the larger / smaller table of the numeric big-row kernel
+    int64_t spgemm_slice_table = 1;  // big rows, numeric: precompute the B-row slices of every (row, range) (k_part_slices)
+    int64_t spgemm_slice_table_max = (int64_t)3 << 30;  // ... unless the table would exceed this many int32 entries
     int64_t spgemm_global_mode = 0;  // 0: one workgroup per row, L2-local atomics; 1: cooperative, agent-scope atomics
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory

@@ -457,6 +457,12 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.spmm_force_generic = value;
         } else if (!strcmp(name, "spgemm_force_global")) {
             o.spgemm_force_global = value;
+        } else if (!strcmp(name, "spgemm_part_log2s_bias")) {
+            o.spgemm_part_log2s_bias = value;
+        } else if (!strcmp(name, "spgemm_slice_table")) {
+            o.spgemm_slice_table = value;
+        } else if (!strcmp(name, "spgemm_slice_table_max")) {
+            o.spgemm_slice_table_max = value;
         } else if (!strcmp(name, "spgemm_lds_parts")) {
             o.spgemm_lds_parts = value;
         } else if (!strcmp(name, "spgemm_global_mode")) {

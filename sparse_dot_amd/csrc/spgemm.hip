@@ -25,10 +25,21 @@ __device__ __forceinline__ uint32_t hash_col(int32_t c, int log2s)
     return (uint32_t)((uint32_t)c * 2654435761u) >> (32 - log2s);
 }
 
+__device__ __forceinline__ int64_t lower_bound_col(const int32_t* __restrict__ col, int64_t lo, int64_t hi, int32_t key)
+{
+    while (lo < hi) {  // first position in [lo, hi) with col >= key
+        const int64_t mid = (lo + hi) >> 1;
+        if (col[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 // ---- phase 0: upper bounds -----------------------------------------------------------------------
+// `upper`: 0 = full product, 1 = upper triangle only (products with column < row are dropped one by one),
+// 2 = upper triangle and the rows of B are sorted (the dropped part of every B row is skipped by a search).
 __global__ void __launch_bounds__(256)
     k_row_ub(int64_t rows, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
-             const int64_t* __restrict__ bptr, int64_t* __restrict__ ub)
+             const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub)
 {
     // 8 lanes per row
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,7 +49,10 @@ __global__ void __launch_bounds__(256)
     if (row < rows) {
         for (int64_t p = aptr[row] + sub; p < aptr[row + 1]; p += 8) {
             const int32_t k = acol[p];
-            s += bptr[k + 1] - bptr[k];
+            int64_t b0 = bptr[k];
+            const int64_t b1 = bptr[k + 1];
+            if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, (int32_t)row);
+            s += b1 - b0;
         }
     }
     s += __shfl_xor(s, 1);
@@ -48,23 +62,17 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---- binning -------------------------------------------------------------------------------------
-// bins 0-3: LDS tables (<=32, <=128, <=512, <=2048).  Bins 4..NBINS-1: rows for the global-memory
-// hash, classed by ceil(log2(count)) (4: <=4096, 5: <=8192, ... last: everything larger) so the
-// persistent kernel can take them largest first (longest-processing-time-first scheduling).
-constexpr int NLDSBINS = 4;
-constexpr int NBINS = 18;
+// Bin k holds the rows with 32 * 2^(k-1) < count <= 32 * 2^k (bin 0: count <= 32; the last bin: everything
+// larger).  Bins 0-6 (<= 2048) always run on LDS hash tables of twice their limit, bin 7 (<= 4096) too
+// unless the values are complex double (table too large), bin 8 (<= 8192) in the symbolic phase only
+// (keys fit, values do not).  Larger rows: LDS bitmap / range-partitioned hash, or the global-memory hash,
+// taken largest class first (longest-processing-time-first scheduling).
+constexpr int NBINS = 22;
+__host__ __device__ inline int64_t bin_limit(int k) { return (int64_t)32 << k; }
 __host__ __device__ inline int bin_of(int64_t c)
 {
-    if (c <= 32) return 0;
-    if (c <= 128) return 1;
-    if (c <= 512) return 2;
-    if (c <= 2048) return 3;
-    int b = 4;
-    int64_t lim = 4096;
-    while (c > lim && b < NBINS - 1) {
-        lim <<= 1;
-        ++b;
-    }
+    int b = 0;
+    while (c > bin_limit(b) && b < NBINS - 1) ++b;
     return b;
 }
 
@@ -95,7 +103,45 @@ __global__ void __launch_bounds__(256)
     if (b >= 0 && lists) lists[b][base[b] + pos] = (int32_t)i;
 }
 
+// Inclusive prefix sums of one int per thread over a workgroup of NT threads, left in inc[0..NT): a
+// shuffle scan inside each wave, then the wave totals through LDS -- two barriers instead of the
+// 2 * log2(NT) of a Hillis-Steele scan (this runs once per NT nonzeros of A in the big-row kernels).
+template <int NT>
+__device__ __forceinline__ void block_scan_inclusive(int v, int* inc, int* wave_tot, int tid)
+{
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_up(v, d);
+        if (lane >= d) v += n;
+    }
+    if (lane == 63) wave_tot[w] = v;
+    __syncthreads();
+    int add = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k)
+        if (k < w) add += wave_tot[k];
+    inc[tid] = v + add;
+    __syncthreads();
+}
+
+template <int N>
+__device__ __forceinline__ int flat_find(const int* inc, int f)
+{
+    int l = 0;
+#pragma unroll
+    for (int step = N / 2; step > 0; step >>= 1)
+        if (inc[l + step - 1] <= f) l += step;
+    return l;
+}
+
 // ---- LDS hash kernel: one workgroup per row -------------------------------------------------------
+// The B rows selected by the row of A are taken THREADS at a time: every thread fetches the extent of
+// one of them, a workgroup scan turns the lengths into offsets, and the products are walked as one flat
+// list -- the dependent chain acol -> bptr -> bcol is paid once per THREADS nonzeros of A, not once per
+// nonzero, and a row of A with thousands of nonzeros but few surviving products (the last rows of an
+// upper-triangular gram matrix) does not serialise on one lane group.
+constexpr int LDS_UNROLL = 2;
 template <typename T, int LOG2S, int THREADS, bool NUMERIC>
 __global__ void __launch_bounds__(THREADS)
     k_spgemm_lds(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
@@ -107,6 +153,10 @@ __global__ void __launch_bounds__(THREADS)
     constexpr int S = 1 << LOG2S;
     __shared__ int32_t keys[S];
     __shared__ T vals[NUMERIC ? S : 1];
+    __shared__ int64_t qlo[THREADS];
+    __shared__ T a_s[NUMERIC ? THREADS : 1];
+    __shared__ int inc[THREADS];
+    __shared__ int wave_tot[THREADS / 64];
     __shared__ int counter;
     const int tid = threadIdx.x;
     const int32_t row = row_list[blockIdx.x];
@@ -117,42 +167,64 @@ __global__ void __launch_bounds__(THREADS)
     if (tid == 0) counter = 0;
     __syncthreads();
 
-    const int group = tid / gw, ngroups = THREADS / gw, gl = tid % gw;
     int local = 0;
     const int64_t a0 = aptr[row], a1 = aptr[row + 1];
-    for (int64_t p = a0 + group; p < a1; p += ngroups) {
-        const int32_t kk = acol[p];
-        T a = vt<T>::zero();
-        if (NUMERIC) a = aval[p];
-        const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
-        for (int64_t q = b0 + gl; q < b1; q += gw) {
-            const int32_t j = bcol[q];
-            if (upper && j < row) continue;
-            uint32_t h = hash_col(j, LOG2S);
-            for (;;) {
-                const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, j);
-                if (old == HASH_EMPTY || old == j) {
-                    if (NUMERIC) atomic_accum(&vals[h], vt<T>::mul(a, bval[q]));
-                    else if (old == HASH_EMPTY) ++local;
-                    break;
+    for (int64_t base = a0; base < a1; base += THREADS) {
+        int len = 0;
+        if (base + tid < a1) {
+            const int32_t kk = acol[base + tid];
+            int64_t b0 = bptr[kk];
+            const int64_t b1 = bptr[kk + 1];
+            if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, row);  // sorted B: skip the lower triangle
+            qlo[tid] = b0;
+            if (NUMERIC) a_s[tid] = aval[base + tid];
+            len = (int)(b1 - b0);
+        }
+        block_scan_inclusive<THREADS>(len, inc, wave_tot, tid);
+        const int total = inc[THREADS - 1];
+        for (int f0 = tid; f0 < total; f0 += THREADS * LDS_UNROLL) {
+            int32_t j[LDS_UNROLL];
+            T v[LDS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < LDS_UNROLL; ++u) {
+                const int f = f0 + u * THREADS;
+                j[u] = -1;
+                if (f < total) {
+                    const int l = flat_find<THREADS>(inc, f);
+                    const int64_t q = qlo[l] + (f - (l ? inc[l - 1] : 0));
+                    j[u] = bcol[q];
+                    if (NUMERIC) v[u] = vt<T>::mul(a_s[l], bval[q]);
                 }
-                h = (h + 1) & (S - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < LDS_UNROLL; ++u) {
+                if (j[u] < 0 || (upper && j[u] < row)) continue;
+                uint32_t h = hash_col(j[u], LOG2S);
+                for (;;) {
+                    const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, j[u]);
+                    if (old == HASH_EMPTY || old == j[u]) {
+                        if (NUMERIC) atomic_accum(&vals[h], v[u]);
+                        else if (old == HASH_EMPTY) ++local;
+                        break;
+                    }
+                    h = (h + 1) & (S - 1);
+                }
             }
         }
+        __syncthreads();
     }
     if (!NUMERIC) {
         if (local) atomicAdd(&counter, local);
         __syncthreads();
         if (tid == 0) row_nnz[row] = counter;
     } else {
-        __syncthreads();
-        const int64_t base = cptr[row];
+        const int64_t out0 = cptr[row];
         for (int k = tid; k < S; k += THREADS) {
             const int32_t key = keys[k];
             if (key != HASH_EMPTY) {
                 const int pos = atomicAdd(&counter, 1);
-                ccol[base + pos] = key;
-                cval[base + pos] = vals[k];
+                ccol[out0 + pos] = key;
+                cval[out0 + pos] = vals[k];
             }
         }
     }
@@ -428,23 +500,28 @@ __global__ void __launch_bounds__(256)
 //    cannot overflow (CAP = half its slots) and writes its CAP entries at cptr[row] + range * CAP --
 //    no cursor, no global atomic, every product read once.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-constexpr int part_log2s() { return sizeof(T) >= 16 ? 11 : 12; }  // 2048 slots for complex double, else 4096
-
-constexpr int PART_THREADS = 512;
-constexpr int PART_UNROLL = 2;
-constexpr int BITMAP_UNROLL = 4;
+#ifndef MI_PART_UNROLL
+#define MI_PART_UNROLL 2
+#endif
+#ifndef MI_BITMAP_UNROLL
+#define MI_BITMAP_UNROLL 4
+#endif
+#ifndef MI_PART_THREADS
+#define MI_PART_THREADS 512
+#endif
+constexpr int PART_THREADS = MI_PART_THREADS;
+constexpr int PART_UNROLL = MI_PART_UNROLL;
+constexpr int BITMAP_UNROLL = MI_BITMAP_UNROLL;
 
 // inc[0..N) non-decreasing (inclusive prefix sums), f < inc[N-1]: the number of entries <= f, i.e. the
 // index of the slice that holds flat position f.  Fixed trip count, no divergence.
-template <int N>
-__device__ __forceinline__ int flat_find(const int* inc, int f)
+// word w of a row bitmap lives at bits[BITMAP_IDX(w)]: one pad word per 32, so that a thread walking its own
+// run of consecutive words (rank computation below) and its neighbours hit different LDS banks
+#define BITMAP_IDX(w) ((w) + ((w) >> 5))
+static inline size_t bitmap_lds_bytes(int64_t ncols)
 {
-    int l = 0;
-#pragma unroll
-    for (int step = N / 2; step > 0; step >>= 1)
-        if (inc[l + step - 1] <= f) l += step;
-    return l;
+    const int64_t words = (ncols + 31) / 32;
+    return sizeof(unsigned) * (size_t)(BITMAP_IDX(words) + 1);
 }
 
 template <bool BOUNDS>
@@ -452,17 +529,19 @@ __global__ void __launch_bounds__(1024)
     k_spgemm_bitmap(int64_t nbig, const int32_t* __restrict__ row_list, int64_t ncols,
                     const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
                     const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int gw, int upper,
-                    int64_t* __restrict__ row_nnz, const int64_t* __restrict__ item_off, int64_t cap,
-                    int32_t* __restrict__ bounds, unsigned long long* work_counter)
+                    int64_t* __restrict__ row_nnz, const int64_t* __restrict__ boff, int64_t cap,
+                    int32_t* __restrict__ bounds, int64_t* __restrict__ boff_by_row, unsigned long long* work_counter)
 {
     MI_DYN_SMEM(smem);
     unsigned* bits = reinterpret_cast<unsigned*>(smem);
     __shared__ int counter;
     __shared__ long long next_idx;
-    __shared__ int scan[2][1024];
+    __shared__ int scan[1024];
+    __shared__ int wave_tot[16];
     __shared__ int64_t qlo[1024];
-    const int tid = threadIdx.x, threads = blockDim.x;  // launched with 1024 threads
+    const int tid = threadIdx.x, threads = 1024;  // launched with 1024 threads
     const int64_t words = (ncols + 31) / 32;
+    const int64_t padded = BITMAP_IDX(words) + 1;
     for (;;) {
         __syncthreads();
         if (tid == 0) {
@@ -473,28 +552,29 @@ __global__ void __launch_bounds__(1024)
         const int64_t idx = next_idx;
         if (idx >= nbig) break;
         const int32_t row = row_list[idx];
-        for (int64_t k = tid; k < words; k += threads) bits[k] = 0u;
+        for (int64_t k = tid; k < padded; k += threads) bits[k] = 0u;
         __syncthreads();
         // the rows of B selected by this row of A, 1024 at a time, walked as one flat list of products (a hub
-        // row of B spreads over the whole workgroup; BITMAP_UNROLL loads in flight per lane)
-        for (int64_t base = aptr[row]; base < aptr[row + 1]; base += 1024) {
-            int len = 0;
-            if (base + tid < aptr[row + 1]) {
-                const int32_t kk = acol[base + tid];
-                const int64_t b0 = bptr[kk];
-                qlo[tid] = b0;
-                len = (int)(bptr[kk + 1] - b0);
+        // row of B spreads over the whole workgroup; BITMAP_UNROLL loads in flight per lane).  The extents of
+        // the next 1024 rows are fetched while the current ones are walked.
+        const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+        int64_t b0_n = 0, b1_n = 0;
+        auto fetch = [&](int64_t p) {
+            b0_n = b1_n = 0;
+            if (p < a1) {
+                const int32_t kk = acol[p];
+                b0_n = bptr[kk];
+                b1_n = bptr[kk + 1];
+                if (upper == 2 && b0_n < b1_n) b0_n = lower_bound_col(bcol, b0_n, b1_n, row);  // sorted B: skip the lower triangle
             }
-            int cur = 0;
-            scan[0][tid] = len;
-            __syncthreads();
-            for (int d = 1; d < 1024; d <<= 1) {
-                const int v = scan[cur][tid] + (tid >= d ? scan[cur][tid - d] : 0);
-                scan[cur ^ 1][tid] = v;
-                cur ^= 1;
-                __syncthreads();
-            }
-            const int* inc = scan[cur];
+        };
+        fetch(a0 + tid);
+        for (int64_t base = a0; base < a1; base += 1024) {
+            qlo[tid] = b0_n;
+            const int len = (int)(b1_n - b0_n);
+            fetch(base + 1024 + tid);
+            block_scan_inclusive<1024>(len, scan, wave_tot, tid);
+            const int* inc = scan;
             const int total = inc[1023];
             for (int f0 = tid; f0 < total; f0 += 1024 * BITMAP_UNROLL) {
                 int32_t j[BITMAP_UNROLL];
@@ -509,13 +589,13 @@ __global__ void __launch_bounds__(1024)
                 }
 #pragma unroll
                 for (int u = 0; u < BITMAP_UNROLL; ++u)
-                    if (j[u] >= 0 && !(upper && j[u] < row)) atomicOr(&bits[j[u] >> 5], 1u << (j[u] & 31));
+                    if (j[u] >= 0 && !(upper && j[u] < row)) atomicOr(&bits[BITMAP_IDX(j[u] >> 5)], 1u << (j[u] & 31));
             }
             __syncthreads();
         }
         if constexpr (!BOUNDS) {
             int local = 0;
-            for (int64_t k = tid; k < words; k += threads) local += __popc(bits[k]);
+            for (int64_t k = tid; k < padded; k += threads) local += __popc(bits[k]);  // pad words are zero
             if (local) atomicAdd(&counter, local);
             __syncthreads();
             if (tid == 0) row_nnz[row] = counter;
@@ -524,21 +604,17 @@ __global__ void __launch_bounds__(1024)
             const int64_t per = (words + threads - 1) / threads;
             const int64_t w0 = (int64_t)tid * per, w1 = w0 + per < words ? w0 + per : words;
             int local = 0;
-            for (int64_t k = w0; k < w1; ++k) local += __popc(bits[k]);
-            int cur = 0;
-            scan[0][tid] = local;
-            __syncthreads();
-            for (int d = 1; d < threads; d <<= 1) {  // inclusive Hillis-Steele scan of the per-thread counts
-                const int v = scan[cur][tid] + (tid >= d ? scan[cur][tid - d] : 0);
-                scan[cur ^ 1][tid] = v;
-                cur ^= 1;
-                __syncthreads();
+            for (int64_t k = w0; k < w1; ++k) local += __popc(bits[BITMAP_IDX(k)]);
+            block_scan_inclusive<1024>(local, scan, wave_tot, tid);
+            int64_t rank = scan[tid] - local;  // set bits before this thread's words
+            int32_t* out = bounds + boff[idx];
+            if (tid == 0) {
+                out[0] = 0;
+                row_nnz[row] = scan[1023];
+                boff_by_row[row] = boff[idx];
             }
-            int64_t rank = scan[cur][tid] - local;  // set bits before this thread's words
-            int32_t* out = bounds + item_off[idx];
-            if (tid == 0) out[0] = 0;
             for (int64_t k = w0; k < w1; ++k) {
-                unsigned w = bits[k];
+                unsigned w = bits[BITMAP_IDX(k)];
                 const int c = __popc(w);
                 if (c) {
                     // boundaries b*cap (b >= 1) with rank <= b*cap < rank + c
@@ -558,37 +634,96 @@ __global__ void __launch_bounds__(1024)
 }
 
 __global__ void k_part_items(const int32_t* __restrict__ row_list, const int64_t* __restrict__ cnt, int64_t nb,
-                             int64_t cap, int64_t* __restrict__ items)
+                             int64_t cap, int64_t clamp, int64_t* __restrict__ items)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < nb) items[t] = (cnt[row_list[t]] + cap - 1) / cap;
+    if (t >= nb) return;
+    int64_t c = cnt[row_list[t]];
+    if (c > clamp) c = clamp;
+    items[t] = (c + cap - 1) / cap;
 }
 
-__device__ __forceinline__ int64_t lower_bound_col(const int32_t* __restrict__ col, int64_t lo, int64_t hi, int32_t key)
+// Slice table for the numeric big-row kernel: for big row t with na nonzeros and P ranges,
+//   bnd[slice_base[t] + p * na + e] = first position (absolute, in B's arrays) of B row acol[e] whose
+// column is >= the start of range p (p = 0..P-1), and the end of that B row for p = P.
+// One thread per (big row, nonzero of A): the P boundaries of one B row are found left to right by
+// galloping from the previous one, with every thread of the GPU busy -- inside k_spgemm_part the same
+// searches would be dependent loads in a workgroup-synchronous phase (measured: the dominant cost).
+__global__ void k_part_slice_sizes(const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off,
+                                   const int64_t* __restrict__ aptr, int64_t nb, int64_t* __restrict__ n_ent,
+                                   int64_t* __restrict__ n_slice)
 {
-    while (lo < hi) {  // first position in [lo, hi) with col >= key
-        const int64_t mid = (lo + hi) >> 1;
-        if (col[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb) return;
+    const int32_t row = row_list[t];
+    const int64_t na = aptr[row + 1] - aptr[row];
+    n_ent[t] = na;
+    n_slice[t] = na * (item_off[t + 1] - item_off[t] + 1);
 }
 
-template <typename T>
+__global__ void __launch_bounds__(256)
+    k_part_slices(const int32_t* __restrict__ row_list, int64_t nb, const int64_t* __restrict__ ent_off,
+                  const int64_t* __restrict__ item_off, const int32_t* __restrict__ bounds,
+                  const int64_t* __restrict__ boff_by_row, const int64_t* __restrict__ aptr,
+                  const int32_t* __restrict__ acol, const int64_t* __restrict__ bptr,
+                  const int32_t* __restrict__ bcol, int upper, const int64_t* __restrict__ slice_base,
+                  int32_t* __restrict__ bnd)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ent_off[nb]) return;
+    int64_t lo = 0, hi = nb;  // largest t with ent_off[t] <= g
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ent_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    const int64_t t = lo, e = g - ent_off[t], na = ent_off[t + 1] - ent_off[t];
+    const int32_t row = row_list[t];
+    const int64_t P = item_off[t + 1] - item_off[t];
+    const int32_t kk = acol[aptr[row] + e];
+    const int64_t b1 = bptr[kk + 1];
+    int64_t cur = bptr[kk];
+    int32_t* out = bnd + slice_base[t] + e;
+    const int32_t* rb = bounds + boff_by_row[row];
+    for (int64_t p = 0; p < P; ++p) {
+        int32_t x = rb[p];
+        if (upper && x < row) x = row;
+        if (x > 0 && cur < b1 && bcol[cur] < x) {
+            // gallop: double the step while the column is still below x, then bisect the last step
+            int64_t step = 1, prev = cur;
+            while (prev + step < b1 && bcol[prev + step] < x) {
+                prev += step;
+                step <<= 1;
+            }
+            int64_t l = prev + 1, h = prev + step < b1 ? prev + step : b1;  // bcol[prev] < x; answer in (prev, h]
+            while (l < h) {
+                const int64_t mid = (l + h) >> 1;
+                if (bcol[mid] < x) l = mid + 1; else h = mid;
+            }
+            cur = l;
+        }
+        out[p * na] = (int32_t)cur;
+    }
+    out[P * na] = (int32_t)b1;
+}
+
+template <typename T, int LOG2S, bool PRE>
 __global__ void __launch_bounds__(PART_THREADS)
     k_spgemm_part(const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off, int64_t nb,
-                  const int32_t* __restrict__ bounds, int64_t ncols, int64_t cap, const int64_t* __restrict__ aptr,
+                  const int32_t* __restrict__ bounds, const int64_t* __restrict__ boff_by_row, int64_t ncols,
+                  int64_t cap, const int64_t* __restrict__ aptr,
                   const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
+                  const int64_t* __restrict__ slice_base, const int32_t* __restrict__ bnd,
                   const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol, T* __restrict__ cval)
 {
-    constexpr int LOG2S = part_log2s<T>();
     constexpr int S = 1 << LOG2S;
     constexpr int NT = PART_THREADS;
     __shared__ int32_t keys[S];
     __shared__ T vals[S];
     __shared__ int64_t qlo[NT];
     __shared__ T a_s[NT];
-    __shared__ int pre[2][NT];
+    __shared__ int pre[NT];
+    __shared__ int wave_tot[NT / 64];
     __shared__ int n_out;
     const int tid = threadIdx.x;
     const int64_t item = blockIdx.x;
@@ -600,8 +735,9 @@ __global__ void __launch_bounds__(PART_THREADS)
     const int64_t t = lo;
     const int64_t pass = item - item_off[t], npass = item_off[t + 1] - item_off[t];
     const int32_t row = row_list[t];
-    int32_t c_lo = bounds[item];
-    const int64_t c_hi = pass + 1 < npass ? (int64_t)bounds[item + 1] : ncols;
+    const int32_t* rb = bounds + boff_by_row[row];
+    int32_t c_lo = rb[pass];
+    const int64_t c_hi = pass + 1 < npass ? (int64_t)rb[pass + 1] : ncols;
     if (upper && c_lo < row) c_lo = row;
     for (int k = tid; k < S; k += NT) {
         keys[k] = HASH_EMPTY;
@@ -610,32 +746,41 @@ __global__ void __launch_bounds__(PART_THREADS)
     if (tid == 0) n_out = 0;
     __syncthreads();
     const int64_t a0 = aptr[row], a1 = aptr[row + 1];
-    for (int64_t base = a0; base < a1; base += NT) {
-        // 1. every thread: the slice of one B row that falls in [c_lo, c_hi)
-        int len = 0;
-        if (base + tid < a1) {
-            const int32_t kk = acol[base + tid];
-            const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
-            int64_t s = b0, e = b1;
-            if (b0 < b1) {
-                if (c_lo > 0) s = lower_bound_col(bcol, b0, b1, c_lo);
-                if (c_hi < ncols) e = lower_bound_col(bcol, s, b1, (int32_t)c_hi);
+    // slice of B row acol[p] that falls in [c_lo, c_hi), and the A value: loaded one chunk ahead so that the
+    // latency of these loads is hidden behind the product walk of the current chunk
+    int64_t s_n = 0, e_n = 0;
+    T a_n = vt<T>::zero();
+    const int32_t* sl0 = nullptr;
+    if constexpr (PRE) sl0 = bnd + slice_base[t] + pass * (a1 - a0);  // slices precomputed by k_part_slices
+    auto fetch = [&](int64_t p) {
+        s_n = e_n = 0;
+        if (p < a1) {
+            if constexpr (PRE) {
+                s_n = sl0[p - a0];
+                e_n = sl0[p - a0 + (a1 - a0)];
+            } else {
+                const int32_t kk = acol[p];
+                const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
+                s_n = b0;
+                e_n = b1;
+                if (b0 < b1) {
+                    if (c_lo > 0) s_n = lower_bound_col(bcol, b0, b1, c_lo);
+                    if (c_hi < ncols) e_n = lower_bound_col(bcol, s_n, b1, (int32_t)c_hi);
+                }
             }
-            qlo[tid] = s;
-            a_s[tid] = aval[base + tid];
-            len = (int)(e - s);
+            a_n = aval[p];
         }
+    };
+    fetch(a0 + tid);
+    for (int64_t base = a0; base < a1; base += NT) {
+        // 1. this chunk's slices into LDS, the next chunk's on their way
+        qlo[tid] = s_n;
+        a_s[tid] = a_n;
+        const int len = (int)(e_n - s_n);
+        fetch(base + NT + tid);
         // 2. inclusive scan of the slice lengths
-        int cur = 0;
-        pre[0][tid] = len;
-        __syncthreads();
-        for (int d = 1; d < NT; d <<= 1) {
-            const int v = pre[cur][tid] + (tid >= d ? pre[cur][tid - d] : 0);
-            pre[cur ^ 1][tid] = v;
-            cur ^= 1;
-            __syncthreads();
-        }
-        const int* inc = pre[cur];
+        block_scan_inclusive<NT>(len, pre, wave_tot, tid);
+        const int* inc = pre;
         const int total = inc[NT - 1];
         // 3. the slices as one flat list of products
         for (int f0 = tid; f0 < total; f0 += NT * PART_UNROLL) {
@@ -794,93 +939,153 @@ static int64_t device_max_row_len(const Csr& A)
     return device_max(len, A.rows);
 }
 
+// What the symbolic phase leaves for the numeric phase about the big rows (LDS bitmap path).
+struct BigRows {
+    int log2s = 11;            // table size of the numeric range kernel; a range holds cap = 2^log2s / 2 columns
+    int64_t cap = 1024;
+    bool b_sorted = false;     // rows of B sorted (needed to cut B rows into column ranges by search)
+    bool have_bounds = false;  // symbolic phase ran the bitmap kernel and stored the range starts
+    DevBuf boff_by_row;        // int64[A.rows]: offset of a big row's range starts in `bounds`
+    DevBuf bounds;             // int32: range starts, P_max = ceil(min(ub, cols) / cap) slots per big row
+};
+
 template <typename T, bool NUMERIC>
-static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt, int64_t max_cnt, int64_t* row_nnz,
-                      const int64_t* cptr, int32_t* ccol, T* cval)
+static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt, int64_t max_cnt, int64_t* row_nnz,
+                      const int64_t* cptr, int32_t* ccol, T* cval, BigRows& big)
 {
     Context& c = ctx();
     const int gw = pick_gw(B);
     const int gw64 = gw > 64 ? 64 : gw;
     Bins b = make_bins(cnt, A.rows);
     const bool force_global = options().spgemm_force_global != 0;
+    // big rows (beyond the numeric LDS tables): LDS bitmap in the symbolic phase, range-partitioned LDS hash in
+    // the numeric one -- when B is narrow enough for a bitmap (and, numeric, its rows are sorted)
+    const int first_big = sizeof(T) >= 16 ? 7 : 8;
+    const bool use_bitmap = !force_global && options().spgemm_lds_parts &&
+                            (NUMERIC ? big.have_bounds
+                                     : (bitmap_lds_bytes(B.cols) <= (size_t)140 * 1024 && B.nnz < ((int64_t)1 << 31)));
 #define MI_SPGEMM_ARGS(list)                                                                                       \
     (const int32_t*)list, (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,   \
         (const int32_t*)B.col, (const T*)B.val
     if (!force_global) {
-        if (b.n[0])
-            MI_LAUNCH((k_spgemm_lds<T, 6, 64, NUMERIC>), dim3((unsigned)b.n[0]), dim3(64), c.stream,
-                      MI_SPGEMM_ARGS(b.list[0]), gw64, (int)upper, row_nnz, cptr, ccol, cval);
-        if (b.n[1])
-            MI_LAUNCH((k_spgemm_lds<T, 8, 64, NUMERIC>), dim3((unsigned)b.n[1]), dim3(64), c.stream,
-                      MI_SPGEMM_ARGS(b.list[1]), gw64, (int)upper, row_nnz, cptr, ccol, cval);
-        if (b.n[2])
-            MI_LAUNCH((k_spgemm_lds<T, 10, 128, NUMERIC>), dim3((unsigned)b.n[2]), dim3(128), c.stream,
-                      MI_SPGEMM_ARGS(b.list[2]), gw64, (int)upper, row_nnz, cptr, ccol, cval);
-        if (b.n[3])
-            MI_LAUNCH((k_spgemm_lds<T, 12, 256, NUMERIC>), dim3((unsigned)b.n[3]), dim3(256), c.stream,
-                      MI_SPGEMM_ARGS(b.list[3]), gw, (int)upper, row_nnz, cptr, ccol, cval);
-        // class 4 (<= 4096): 8192-slot table -- 32 KiB of keys + up to 64 KiB of values
-        if constexpr (!NUMERIC || sizeof(T) <= 8) {
-            if (b.n[4]) {
-                MI_LAUNCH((k_spgemm_lds<T, 13, 1024, NUMERIC>), dim3((unsigned)b.n[4]), dim3(1024), c.stream,
-                          MI_SPGEMM_ARGS(b.list[4]), gw, (int)upper, row_nnz, cptr, ccol, cval);
-                b.n[4] = 0;
-            }
-        }
-        // class 5 (<= 8192): keys only fit (symbolic phase): 16384-slot table = 64 KiB
+#define MI_SPGEMM_BIN(k, LOG2S, THREADS, GW)                                                                       \
+    if (b.n[k]) {                                                                                                  \
+        MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC>), dim3((unsigned)b.n[k]), dim3(THREADS), c.stream,       \
+                  MI_SPGEMM_ARGS(b.list[k]), GW, (int)upper, row_nnz, cptr, ccol, cval);                             \
+        b.n[k] = 0;                                                                                                \
+    }
+        MI_SPGEMM_BIN(0, 6, 64, gw64)
+        MI_SPGEMM_BIN(1, 7, 64, gw64)
+        MI_SPGEMM_BIN(2, 8, 64, gw64)
+        MI_SPGEMM_BIN(3, 9, 128, gw64)
+        MI_SPGEMM_BIN(4, 10, 128, gw64)
+        MI_SPGEMM_BIN(5, 11, 256, gw)
+        MI_SPGEMM_BIN(6, 12, 256, gw)
+        // bin 7 (<= 4096): 8192-slot table -- 32 KiB of keys + up to 64 KiB of values.  (Symbolic phase with
+        // the bitmap available: every row the numeric phase will treat as big must pass through the bitmap.)
         if constexpr (!NUMERIC) {
-            if (b.n[5]) {
-                MI_LAUNCH((k_spgemm_lds<T, 14, 1024, NUMERIC>), dim3((unsigned)b.n[5]), dim3(1024), c.stream,
-                          MI_SPGEMM_ARGS(b.list[5]), gw, (int)upper, row_nnz, cptr, ccol, cval);
-                b.n[5] = 0;
+            if (!(use_bitmap && first_big <= 7)) {
+                MI_SPGEMM_BIN(7, 13, 1024, gw)
             }
+            // bin 8 (<= 8192): only the keys fit: 16384-slot table = 64 KiB
+            if (!use_bitmap) {
+                MI_SPGEMM_BIN(8, 14, 1024, gw)
+            }
+        } else if constexpr (sizeof(T) <= 8) {
+            MI_SPGEMM_BIN(7, 13, 1024, gw)
         }
+#undef MI_SPGEMM_BIN
     }
     // Big rows through LDS (column bitmap + range-partitioned hash, see k_spgemm_bitmap / k_spgemm_part);
     // when B is too wide for a bitmap or its rows are not sorted they stay for the global-memory hash.
-    if (!force_global && options().spgemm_lds_parts) {
-        const int first = NUMERIC ? (sizeof(T) >= 16 ? 4 : 5) : 6;
+    if (use_bitmap) {
         int64_t nbig = 0;
-        for (int k = first; k < NBINS; ++k) nbig += b.n[k];
-        const int64_t words = (B.cols + 31) / 32;
-        bool can = (size_t)words * 4 <= (size_t)136 * 1024 && B.nnz < ((int64_t)1 << 31);
-        if (nbig && can && NUMERIC) can = rows_sorted(B);
-        if (nbig && can) {
+        for (int k = first_big; k < NBINS; ++k) nbig += b.n[k];
+        if (nbig) {
             int32_t* big_list = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)nbig));
             int64_t off = 0;
-            for (int k = NBINS - 1; k >= first; --k) {  // largest class first
+            for (int k = NBINS - 1; k >= first_big; --k) {  // largest class first
                 if (!b.n[k]) continue;
                 MI_HIP_CHECK(hipMemcpyAsync(big_list + off, b.list[k], sizeof(int32_t) * (size_t)b.n[k],
                                             hipMemcpyDeviceToDevice, c.stream));
                 off += b.n[k];
                 b.n[k] = 0;
             }
-            unsigned long long* counter = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long)));
-            MI_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), c.stream));
-            const int64_t nblocks = nbig < 512 ? nbig : 512;
+            int64_t* items = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+            int64_t* item_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
             if constexpr (!NUMERIC) {
-                MI_LAUNCH_SMEM((k_spgemm_bitmap<false>), dim3((unsigned)nblocks), dim3(1024), (size_t)words * 4, c.stream, nbig,
-                               (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
-                               (const int64_t*)B.ptr, (const int32_t*)B.col, gw, (int)upper, row_nnz,
-                               (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, counter);
+                unsigned long long* counter = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long)));
+                MI_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned long long), c.stream));
+                const int64_t nblocks = nbig < 512 ? nbig : 512;
+                // range starts are recorded only if the numeric phase can use them (sorted B, sane size)
+                int64_t n_bounds = 0;
+                if (big.b_sorted) {
+                    MI_LAUNCH(k_part_items, dim3((unsigned)ceil_div(nbig, 256)), dim3(256), c.stream,
+                              (const int32_t*)big_list, cnt, nbig, big.cap, B.cols, items);
+                    n_bounds = exclusive_scan_i64(items, item_off, nbig);
+                }
+                if (big.b_sorted && n_bounds < ((int64_t)1 << 31)) {
+                    big.boff_by_row.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
+                    big.bounds.alloc(sizeof(int32_t) * (size_t)(n_bounds + 1));
+                    MI_LAUNCH_SMEM((k_spgemm_bitmap<true>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
+                                   c.stream, nbig, (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr,
+                                   (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, gw, upper, row_nnz,
+                                   (const int64_t*)item_off, big.cap, big.bounds.as<int32_t>(),
+                                   big.boff_by_row.as<int64_t>(), counter);
+                    big.have_bounds = true;
+                } else {
+                    MI_LAUNCH_SMEM((k_spgemm_bitmap<false>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
+                                   c.stream, nbig, (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr,
+                                   (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, gw, upper, row_nnz,
+                                   (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, counter);
+                }
             } else {
-                constexpr int64_t CAP = ((int64_t)1 << part_log2s<T>()) / 2;
-                int64_t* items = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
-                int64_t* item_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                const int64_t CAP = big.cap;
                 MI_LAUNCH(k_part_items, dim3((unsigned)ceil_div(nbig, 256)), dim3(256), c.stream, (const int32_t*)big_list,
-                          cnt, nbig, CAP, items);
+                          cnt, nbig, CAP, (int64_t)1 << 62, items);
                 const int64_t n_items = exclusive_scan_i64(items, item_off, nbig);
                 if (n_items > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "SpGEMM result too large for one launch");
-                int32_t* bounds = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(n_items + 1)));
-                MI_LAUNCH_SMEM((k_spgemm_bitmap<true>), dim3((unsigned)nblocks), dim3(1024), (size_t)words * 4, c.stream, nbig,
-                               (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
-                               (const int64_t*)B.ptr, (const int32_t*)B.col, gw, (int)upper, (int64_t*)nullptr,
-                               (const int64_t*)item_off, CAP, bounds, counter);
-                if (n_items)
-                    MI_LAUNCH((k_spgemm_part<T>), dim3((unsigned)n_items), dim3(PART_THREADS), c.stream,
-                              (const int32_t*)big_list, (const int64_t*)item_off, nbig, (const int32_t*)bounds, B.cols, CAP,
+                // slice table (see k_part_slices) unless it would be unreasonably large
+                int64_t* n_ent = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                int64_t* n_slice = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                int64_t* ent_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                int64_t* slice_base = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                MI_LAUNCH(k_part_slice_sizes, dim3((unsigned)ceil_div(nbig, 256)), dim3(256), c.stream,
+                          (const int32_t*)big_list, (const int64_t*)item_off, (const int64_t*)A.ptr, nbig, n_ent, n_slice);
+                const int64_t total_ent = exclusive_scan_i64(n_ent, ent_off, nbig);
+                const int64_t total_slices = exclusive_scan_i64(n_slice, slice_base, nbig);
+                const bool pre = options().spgemm_slice_table && total_slices <= options().spgemm_slice_table_max &&
+                                 ceil_div(total_ent, 256) < 2000000000;
+                const int32_t* bounds = big.bounds.as<int32_t>();
+                const int64_t* brow = big.boff_by_row.as<int64_t>();
+                int32_t* bnd = nullptr;
+                if (pre) {
+                    bnd = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(total_slices + 1)));
+                    if (total_ent)
+                        MI_LAUNCH(k_part_slices, dim3((unsigned)ceil_div(total_ent, 256)), dim3(256), c.stream,
+                                  (const int32_t*)big_list, nbig, (const int64_t*)ent_off, (const int64_t*)item_off, bounds,
+                                  brow, (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr,
+                                  (const int32_t*)B.col, upper, (const int64_t*)slice_base, bnd);
+                }
+                auto launch = [&](auto log2s_tag, auto pre_tag) {
+                    constexpr int L = decltype(log2s_tag)::value;
+                    constexpr bool P = decltype(pre_tag)::value;
+                    MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)n_items), dim3(PART_THREADS), c.stream,
+                              (const int32_t*)big_list, (const int64_t*)item_off, nbig, bounds, brow, B.cols, CAP,
                               (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,
-                              (const int32_t*)B.col, (const T*)B.val, (int)upper, cptr, ccol, cval);
+                              (const int32_t*)B.col, (const T*)B.val, upper, (const int64_t*)slice_base,
+                              (const int32_t*)bnd, cptr, ccol, cval);
+                };
+                if (n_items) {
+                    constexpr int LO = sizeof(T) >= 16 ? 10 : 11, HI = LO + 1;
+                    using lo_t = std::integral_constant<int, LO>;
+                    using hi_t = std::integral_constant<int, HI>;
+                    if (big.log2s == HI) {
+                        if (pre) launch(hi_t{}, std::true_type{}); else launch(hi_t{}, std::false_type{});
+                    } else {
+                        if (pre) launch(lo_t{}, std::true_type{}); else launch(lo_t{}, std::false_type{});
+                    }
+                }
             }
         }
     }
@@ -894,11 +1099,10 @@ static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt
         // per size class so that tables (cleared and compacted per row) and workgroups are sized for
         // the class: many small workgroups for the mid-size rows, few large ones for the hub rows.
         {
-            const int first = force_global ? 0 : NLDSBINS;
-            static const int64_t lds_limits[NLDSBINS] = {32, 128, 512, 2048};
+            const int first = 0;  // bins already served above have n == 0
             for (int k = NBINS - 1; k >= first; --k) {
                 if (!b.n[k]) continue;
-                int64_t limit = (k < NLDSBINS) ? lds_limits[k] : ((int64_t)4096 << (k - NLDSBINS));
+                int64_t limit = bin_limit(k);
                 if (k == NBINS - 1 || limit > max_cnt) limit = max_cnt;
                 const int64_t cap = limit < B.cols ? limit : B.cols;
                 int64_t slab = 4;
@@ -925,11 +1129,10 @@ static void run_phase(const Csr& A, const Csr& B, bool upper, const int64_t* cnt
         // global-memory hash: every class that did not go to an LDS bin, largest first.  All rows of a
         // class use one table size; they are processed in batches whose tables fit a 4 GiB workspace.
         {
-            const int first = force_global ? 0 : NLDSBINS;
-            static const int64_t lds_limits[NLDSBINS] = {32, 128, 512, 2048};
+            const int first = 0;  // bins already served above have n == 0
             for (int k = NBINS - 1; k >= first; --k) {
                 if (!b.n[k]) continue;
-                int64_t limit = (k < NLDSBINS) ? lds_limits[k] : ((int64_t)4096 << (k - NLDSBINS));
+                int64_t limit = bin_limit(k);
                 if (k == NBINS - 1 || limit > max_cnt) limit = max_cnt;
                 const int64_t cap = limit < B.cols ? limit : B.cols;
                 int log2s = 2;
@@ -997,6 +1200,17 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
     if (A.cols != B.rows)
         fail(MI_SPARSE_STATUS_INVALID_VALUE, "dimension mismatch: (%lld x %lld) * (%lld x %lld)", (long long)A.rows,
              (long long)A.cols, (long long)B.rows, (long long)B.cols);
+    // upper triangle of a product with sorted B rows: the part of every B row left of the diagonal is skipped
+    // by a search instead of being read and dropped (half of the products of a gram matrix)
+    BigRows big;
+    big.b_sorted = rows_sorted(B);
+    const int upper_mode = upper ? (big.b_sorted ? 2 : 1) : 0;
+    // table of the numeric big-row kernel: 2048 slots (1024 for complex double) give the best occupancy on wide
+    // power-law products; a narrow B (dense-ish result rows, few ranges per row) is better off with twice that
+    big.log2s = (sizeof(T) >= 16 ? 10 : 11) + (B.cols <= 65536 ? 1 : 0) + (int)options().spgemm_part_log2s_bias;
+    if (big.log2s < (sizeof(T) >= 16 ? 10 : 11)) big.log2s = sizeof(T) >= 16 ? 10 : 11;
+    if (big.log2s > (sizeof(T) >= 16 ? 11 : 12)) big.log2s = sizeof(T) >= 16 ? 11 : 12;
+    big.cap = ((int64_t)1 << big.log2s) / 2;
     C.rows = A.rows;
     C.cols = B.cols;
     C.ptr_own.alloc(sizeof(int64_t) * (size_t)(C.rows + 1));
@@ -1006,10 +1220,10 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
     MI_HIP_CHECK(hipMemsetAsync(row_nnz, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
     if (A.rows > 0)
         MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows,
-                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, ub);
+                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, upper_mode, ub);
     const int64_t max_ub = device_max(ub, A.rows);
     mark("row upper bounds");
-    run_phase<T, false>(A, B, upper, ub, max_ub, row_nnz, nullptr, nullptr, nullptr);
+    run_phase<T, false>(A, B, upper_mode, ub, max_ub, row_nnz, nullptr, nullptr, nullptr, big);
     mark("symbolic");
     const int64_t nnz = exclusive_scan_i64(row_nnz, C.ptr, C.rows);
     C.nnz = nnz;
@@ -1020,7 +1234,7 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
     mark("scan + allocate C");
     if (nnz > 0) {
         const int64_t max_nnz = device_max(row_nnz, A.rows);
-        run_phase<T, true>(A, B, upper, row_nnz, max_nnz, nullptr, C.ptr, C.col, static_cast<T*>(C.val));
+        run_phase<T, true>(A, B, upper_mode, row_nnz, max_nnz, nullptr, C.ptr, C.col, static_cast<T*>(C.val), big);
     }
     mark("numeric");
     C.valid = true;

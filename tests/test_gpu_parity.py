@@ -611,12 +611,14 @@ def test_spgemm_hub_rows_lds_bitmap_and_partitioned_classes(gpu, dtype):
     want = (a.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64) @ b).tocsr()
     want.sort_indices()
     assert np.diff(want.indptr).max() > 40000
-    for parts in (1, 0):
+    for parts, slice_table in ((1, 1), (1, 0), (0, 1)):  # slice table / in-kernel searches / global-memory hash
         gpu.mi_set_option("spgemm_lds_parts", parts)
+        gpu.mi_set_option("spgemm_slice_table", slice_table)
         try:
             got = gpu.dot_product_mkl(a, b)
         finally:
             gpu.mi_set_option("spgemm_lds_parts", 1)
+            gpu.mi_set_option("spgemm_slice_table", 1)
         _check_spgemm(got, want, dtype)
 
 
@@ -630,11 +632,16 @@ def test_gram_sparse_hub_rows(gpu, dtype):
     a = a.tocsr().astype(dtype)
     want = sps.triu((a.T.astype(np.float64) @ a.astype(np.float64))).tocsr()
     want.sort_indices()
-    got = gpu.gram_matrix_mkl(a, reorder_output=True)
-    g = got.tocsr()
-    # explicit zeros can only come from cancellation; all values here are positive
-    assert np.array_equal(g.indptr, want.indptr) and np.array_equal(g.indices, want.indices)
-    assert rel_err(g.data, want.data) <= tol(dtype)
+    for slice_table in (1, 0):
+        gpu.mi_set_option("spgemm_slice_table", slice_table)
+        try:
+            got = gpu.gram_matrix_mkl(a, reorder_output=True)
+        finally:
+            gpu.mi_set_option("spgemm_slice_table", 1)
+        g = got.tocsr()
+        # explicit zeros can only come from cancellation; all values here are positive
+        assert np.array_equal(g.indptr, want.indptr) and np.array_equal(g.indices, want.indices)
+        assert rel_err(g.data, want.data) <= tol(dtype)
 
 
 def test_device_block_cache_options(gpu, oracle):
@@ -651,6 +658,26 @@ def test_device_block_cache_options(gpu, oracle):
     finally:
         gpu.mi_set_option("pool_enable", 1)
         gpu.mi_set_option("pool_max_mb", -1)
+
+
+def test_gram_sparse_unsorted_input_rows(gpu):
+    """The upper-triangle shortcut (skip the part of each B row left of the diagonal by a search) needs sorted
+    rows; a matrix whose rows are not sorted takes the drop-one-by-one path and gives the same result."""
+    rng = np.random.default_rng(8)
+    a = sps.random(500, 700, density=0.02, format="csr", random_state=4, dtype=np.float64)
+    want = sps.triu(a.T @ a).tocsr()
+    want.sort_indices()
+    ind, dat = a.indices.copy(), a.data.copy()
+    for r in range(a.shape[0]):  # shuffle inside every row
+        lo, hi = a.indptr[r], a.indptr[r + 1]
+        o = rng.permutation(hi - lo)
+        ind[lo:hi], dat[lo:hi] = a.indices[lo:hi][o], a.data[lo:hi][o]
+    shuffled = sps.csr_matrix((dat, ind, a.indptr.copy()), shape=a.shape)
+    assert not shuffled.has_sorted_indices
+    for m in (a, shuffled):
+        g = gpu.gram_matrix_mkl(m, reorder_output=True).tocsr()
+        assert np.array_equal(g.indptr, want.indptr) and np.array_equal(g.indices, want.indices)
+        assert rel_err(g.data, want.data) <= 1e-12
 
 
 def test_spgemm_keeps_cancelled_entries_and_sums_duplicates(gpu):

@@ -52,6 +52,9 @@ def main():
         sda.mi_set_option("spgemm_global_mode", args.global_mode)
     if args.lds_parts >= 0:
         sda.mi_set_option("spgemm_lds_parts", args.lds_parts)
+    for kv in os.environ.get("MI_BENCH_OPTS", "").split(","):  # e.g. MI_BENCH_OPTS=spgemm_part_log2s_bias=1
+        if "=" in kv:
+            sda.mi_set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
     def make(kind, n_rows_log2, ncols, per_row, seed, dtype):
         if kind == "rmat":

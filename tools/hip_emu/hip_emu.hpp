@@ -147,6 +147,20 @@ inline T __shfl_xor(T v, int mask)
 }
 
 template <typename T>
+inline T __shfl_up(T v, int delta)
+{
+    static_assert(sizeof(T) <= 16, "shuffle payload too large");
+    hip_emu::WaveState& w = hip_emu::st().waves[hip_emu::t_tid / 64];
+    const int lane = hip_emu::t_tid % 64;
+    std::memcpy(w.slot[lane], &v, sizeof(T));
+    w.bar.arrive_and_wait();
+    T r = v;
+    if (lane - delta >= 0) std::memcpy(&r, w.slot[lane - delta], sizeof(T));
+    w.bar.arrive_and_wait();
+    return r;
+}
+
+template <typename T>
 inline T __shfl(T v, int src)
 {
     static_assert(sizeof(T) <= 16, "shuffle payload too large");
