@@ -27,6 +27,8 @@
 namespace mi {
 // Launch helper: converts the arguments to the kernel's parameter types (so call sites need no
 // casts) and hides the <<< >>> syntax from the host-emulation build.
+[[noreturn]] void launch_too_large(unsigned long long threads);  // throws (runtime.hip)
+
 template <typename... KArgs, typename... Args>
 inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t stream, Args&&... args)
 {
@@ -34,6 +36,8 @@ inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t sme
     (void)stream;
     hip_emu::launch(kernel, grid, block, smem, static_cast<KArgs>(args)...);
 #else
+    // HIP runs at most 2^32 - 1 threads per grid dimension and silently drops the rest
+    if ((unsigned long long)grid.x * block.x >= (1ull << 32)) launch_too_large((unsigned long long)grid.x * block.x);
     kernel<<<grid, block, smem, stream>>>(static_cast<KArgs>(args)...);
 #endif
 }

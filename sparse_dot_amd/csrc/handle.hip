@@ -32,8 +32,8 @@ __global__ void k_widen_ptr(const I* in, int64_t n, int64_t base, int64_t* out)
 template <typename I>
 __global__ void k_narrow_col(const I* in, int64_t n, int64_t base, int32_t* out)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (int32_t)((int64_t)in[i] - base);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (int32_t)((int64_t)in[i] - base);
 }
 
 // general 4-array CSR -> compact: one wave per row copies [rs[i], re[i]) to [ptr[i], ptr[i+1])
@@ -86,8 +86,8 @@ __global__ void k_check_ptr(const int64_t* ptr, int64_t rows, int64_t nnz_limit,
 
 __global__ void k_check_col(const int32_t* col, int64_t nnz, int64_t cols, int* bad)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nnz && (col[i] < 0 || (int64_t)col[i] >= cols)) atomicOr(bad, 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+        if (col[i] < 0 || (int64_t)col[i] >= cols) atomicOr(bad, 4);
 }
 
 // ================================================================================================
@@ -96,8 +96,8 @@ __global__ void k_check_col(const int32_t* col, int64_t nnz, int64_t cols, int* 
 // ================================================================================================
 __global__ void k_col_hist(const int32_t* col, int64_t nnz, int64_t* counts)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nnz) atomicAdd((unsigned long long*)&counts[col[i]], 1ull);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd((unsigned long long*)&counts[col[i]], 1ull);
 }
 
 template <typename T, bool CONJ>
@@ -319,13 +319,13 @@ __global__ void __launch_bounds__(1024)
 }
 
 // classify rows for the sort tiers: writes row ids of medium / large rows through atomic cursors
-__global__ void k_sort_classify(const int64_t* ptr, int64_t rows, int64_t* n_med, int64_t* med_rows,
+__global__ void k_sort_classify(const int64_t* ptr, int64_t rows, int64_t big_thr, int64_t* n_med, int64_t* med_rows,
                                 int64_t* n_big, int64_t* big_rows)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     const int64_t len = ptr[i + 1] - ptr[i];
-    if (len > SORT_BLOCK_MAX) {
+    if (len > big_thr) {
         const int64_t d = (int64_t)atomicAdd((unsigned long long*)n_big, 1ull);
         if (big_rows) big_rows[d] = i;
     } else if (len > SORT_SMALL_MAX) {
@@ -348,14 +348,19 @@ __global__ void k_big_row_sizes(const int64_t* ptr, const int64_t* rows_list, in
 template <typename T>
 __global__ void k_gather_vals(const T* in, const int64_t* perm, int64_t nnz, T* out)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nnz) out[i] = in[perm[i]];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[perm[i]];
 }
 
 // ================================================================================================
 // host side
 // ================================================================================================
 static inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)(n > 0 ? ceil_div(n, block) : 1)); }
+// for grid-stride kernels: at most 2^20 workgroups (element counts beyond 2^32 are legal for nnz)
+static inline dim3 grid1d_stride(int64_t n, int block)
+{
+    const int64_t b = n > 0 ? ceil_div(n, block) : 1;
+    return dim3((unsigned)(b < (1 << 20) ? b : (1 << 20)));
+}
 
 mi_sparse_matrix* check_handle(mi_sparse_matrix_t h)
 {
@@ -400,7 +405,13 @@ void sort_csr(char vtype, Csr& a)
     int64_t* perm = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)a.nnz));
     int64_t* counters = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * 2));
     MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 2, c.stream));
-    MI_LAUNCH(k_sort_classify, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows,
+    // rows too long for one wave: counting sort through an LDS column bitmap when the matrix is narrow enough
+    // for one (then the block-wide comparison sort is not used at all), else comparison sorts in LDS / HBM
+    const int64_t words = (a.cols + 31) / 32;
+    const size_t bitmap_bytes = sizeof(unsigned) * (size_t)(words + ceil_div(words, (int64_t)SORT_BITMAP_GROUP));
+    const bool use_bitmap = bitmap_bytes <= (size_t)144 * 1024;
+    const int64_t big_thr = use_bitmap ? SORT_SMALL_MAX : SORT_BLOCK_MAX;
+    MI_LAUNCH(k_sort_classify, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, big_thr,
               counters, (int64_t*)nullptr, counters + 1, (int64_t*)nullptr);
     int64_t hc[2] = {0, 0};
     MI_HIP_CHECK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, c.stream));
@@ -414,15 +425,13 @@ void sort_csr(char vtype, Csr& a)
         int64_t* med_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_med + 1)));
         int64_t* big_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
         MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 2, c.stream));
-        MI_LAUNCH(k_sort_classify, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows,
+        MI_LAUNCH(k_sort_classify, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, big_thr,
                   counters, med_rows, counters + 1, big_rows);
         if (n_med)
             MI_LAUNCH(k_sort_block, dim3((unsigned)n_med), dim3(256), c.stream, (const int64_t*)a.ptr, a.col,
                       (const int64_t*)med_rows, perm);
         if (n_big) {
-            const int64_t words = (a.cols + 31) / 32;
-            const size_t bitmap_bytes = sizeof(unsigned) * (size_t)(words + ceil_div(words, (int64_t)SORT_BITMAP_GROUP));
-            if (bitmap_bytes <= (size_t)144 * 1024) {  // counting sort through the LDS bitmap; rows it refuses stay "big"
+            if (use_bitmap) {  // rows the counting sort refuses (repeated column) go to the HBM comparison sort
                 unsigned long long* cnt2 = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * 2));
                 int64_t* fallback = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
                 MI_HIP_CHECK(hipMemsetAsync(cnt2, 0, sizeof(unsigned long long) * 2, c.stream));
@@ -453,7 +462,7 @@ void sort_csr(char vtype, Csr& a)
     void* tmp = c.scratch_alloc(vb * (size_t)a.nnz);
     by_type(vtype, [&](auto tag) {
         using T = decltype(tag);
-        MI_LAUNCH((k_gather_vals<T>), grid1d(a.nnz, 256), dim3(256), c.stream, (const T*)a.val,
+        MI_LAUNCH((k_gather_vals<T>), grid1d_stride(a.nnz, 256), dim3(256), c.stream, (const T*)a.val,
                   (const int64_t*)perm, a.nnz, (T*)tmp);
     });
     MI_HIP_CHECK(hipMemcpyAsync(a.val, tmp, vb * (size_t)a.nnz, hipMemcpyDeviceToDevice, c.stream));
@@ -475,7 +484,7 @@ void transpose_csr(char vtype, const Csr& in, Csr& out, bool conj)
     int64_t* counts = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(out.rows + 1)));
     MI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(out.rows + 1), c.stream));
     if (in.nnz)
-        MI_LAUNCH(k_col_hist, grid1d(in.nnz, 256), dim3(256), c.stream, (const int32_t*)in.col, in.nnz, counts);
+        MI_LAUNCH(k_col_hist, grid1d_stride(in.nnz, 256), dim3(256), c.stream, (const int32_t*)in.col, in.nnz, counts);
     exclusive_scan_i64(counts, out.ptr, out.rows);
     // cursors start at the row pointers
     MI_HIP_CHECK(hipMemcpyAsync(counts, out.ptr, sizeof(int64_t) * (size_t)out.rows, hipMemcpyDeviceToDevice,
@@ -586,7 +595,7 @@ static void build_csr(Csr& out, int base, int64_t nrows, int64_t ncols, const I*
                     dcol = ctmp.as<I>();
                 }
                 if (nnz)
-                    MI_LAUNCH((k_narrow_col<I>), grid1d(nnz, 256), dim3(256), c.stream, dcol, nnz, (int64_t)base,
+                    MI_LAUNCH((k_narrow_col<I>), grid1d_stride(nnz, 256), dim3(256), c.stream, dcol, nnz, (int64_t)base,
                               out.col);
                 MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // ctmp is released here
             }
@@ -666,7 +675,7 @@ static void build_csr(Csr& out, int base, int64_t nrows, int64_t ncols, const I*
     MI_LAUNCH(k_check_ptr, grid1d(nrows > 0 ? nrows : 1, 256), dim3(256), c.stream, (const int64_t*)out.ptr, nrows,
               (int64_t)INT64_MAX, bad);
     if (out.nnz)
-        MI_LAUNCH(k_check_col, grid1d(out.nnz, 256), dim3(256), c.stream, (const int32_t*)out.col, out.nnz, ncols,
+        MI_LAUNCH(k_check_col, grid1d_stride(out.nnz, 256), dim3(256), c.stream, (const int32_t*)out.col, out.nnz, ncols,
                   bad);
     int hbad = 0;
     MI_HIP_CHECK(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, c.stream));
@@ -783,8 +792,7 @@ static int create_bsr_generic(mi_sparse_matrix_t* A, int base, int block_layout,
 template <typename I>
 __global__ void k_export_ptr(const int64_t* in, int64_t n, I* out)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (I)in[i];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (I)in[i];
 }
 template <typename I>
 __global__ void k_export_col(const int32_t* in, int64_t n, I* out)
@@ -820,7 +828,7 @@ static int export_generic(mi_sparse_matrix_t A, bool csc, int* base, I* rows, I*
                 MI_HIP_CHECK(hipMemcpyAsync(e.col.data(), m.col, sizeof(int32_t) * (size_t)m.nnz, hipMemcpyDeviceToHost, c.stream));
             } else {
                 I* dcol = static_cast<I*>(c.scratch_alloc(sizeof(I) * (size_t)m.nnz));
-                MI_LAUNCH((k_export_col<I>), grid1d(m.nnz, 256), dim3(256), c.stream, (const int32_t*)m.col, m.nnz, dcol);
+                MI_LAUNCH((k_export_col<I>), grid1d_stride(m.nnz, 256), dim3(256), c.stream, (const int32_t*)m.col, m.nnz, dcol);
                 MI_HIP_CHECK(hipMemcpyAsync(e.col.data(), dcol, sizeof(I) * (size_t)m.nnz, hipMemcpyDeviceToHost, c.stream));
             }
             MI_HIP_CHECK(hipMemcpyAsync(e.val.data(), m.val, sizeof(T) * (size_t)m.nnz, hipMemcpyDeviceToHost, c.stream));
@@ -951,7 +959,7 @@ mi_sparse_status_t mi_sparse_order(mi_sparse_matrix_t A)
             } else {
                 int64_t* tmp = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)primary.nnz));
                 if (h->index_bytes == 8) {
-                    MI_LAUNCH((mi::k_export_col<int64_t>), mi::grid1d(primary.nnz, 256), dim3(256), c.stream,
+                    MI_LAUNCH((mi::k_export_col<int64_t>), mi::grid1d_stride(primary.nnz, 256), dim3(256), c.stream,
                               (const int32_t*)primary.col, primary.nnz, tmp);
                     MI_HIP_CHECK(hipMemcpyAsync(h->user_col, tmp, sizeof(int64_t) * (size_t)primary.nnz,
                                                 hipMemcpyDeviceToHost, c.stream));

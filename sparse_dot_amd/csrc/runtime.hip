@@ -28,6 +28,11 @@ void fail(int status, const char* fmt, ...)
     throw status_error{status};
 }
 
+void launch_too_large(unsigned long long threads)
+{
+    fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "internal launch of %llu threads exceeds the 2^32 per-grid limit (operand too large)", threads);
+}
+
 // ---- device memory -----------------------------------------------------------------------------
 namespace {
 constexpr int POOL_MAX_DEVICES = 64;

@@ -649,45 +649,54 @@ __global__ void k_part_items(const int32_t* __restrict__ row_list, const int64_t
 // One thread per (big row, nonzero of A): the P boundaries of one B row are found left to right by
 // galloping from the previous one, with every thread of the GPU busy -- inside k_spgemm_part the same
 // searches would be dependent loads in a workgroup-synchronous phase (measured: the dominant cost).
+constexpr int SLICE_PASSES = 8;  // range starts found by one thread of k_part_slices (first by bisection, rest by galloping)
+
 __global__ void k_part_slice_sizes(const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off,
-                                   const int64_t* __restrict__ aptr, int64_t nb, int64_t* __restrict__ n_ent,
+                                   const int64_t* __restrict__ aptr, int64_t nb, int64_t* __restrict__ n_work,
                                    int64_t* __restrict__ n_slice)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nb) return;
     const int32_t row = row_list[t];
     const int64_t na = aptr[row + 1] - aptr[row];
-    n_ent[t] = na;
-    n_slice[t] = na * (item_off[t + 1] - item_off[t] + 1);
+    const int64_t P = item_off[t + 1] - item_off[t];
+    n_work[t] = na * ((P + SLICE_PASSES - 1) / SLICE_PASSES);
+    n_slice[t] = na * (P + 1);
 }
 
 __global__ void __launch_bounds__(256)
-    k_part_slices(const int32_t* __restrict__ row_list, int64_t nb, const int64_t* __restrict__ ent_off,
+    k_part_slices(int64_t block_base, const int32_t* __restrict__ row_list, int64_t nb,
+                  const int64_t* __restrict__ work_off,
                   const int64_t* __restrict__ item_off, const int32_t* __restrict__ bounds,
                   const int64_t* __restrict__ boff_by_row, const int64_t* __restrict__ aptr,
                   const int32_t* __restrict__ acol, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, int upper, const int64_t* __restrict__ slice_base,
                   int32_t* __restrict__ bnd)
 {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ent_off[nb]) return;
-    int64_t lo = 0, hi = nb;  // largest t with ent_off[t] <= g
+    const int64_t g = (block_base + blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= work_off[nb]) return;
+    int64_t lo = 0, hi = nb;  // largest t with work_off[t] <= g
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
-        if (ent_off[mid] <= g) lo = mid; else hi = mid;
+        if (work_off[mid] <= g) lo = mid; else hi = mid;
     }
-    const int64_t t = lo, e = g - ent_off[t], na = ent_off[t + 1] - ent_off[t];
+    const int64_t t = lo;
     const int32_t row = row_list[t];
+    const int64_t a0 = aptr[row], na = aptr[row + 1] - a0;
     const int64_t P = item_off[t + 1] - item_off[t];
-    const int32_t kk = acol[aptr[row] + e];
-    const int64_t b1 = bptr[kk + 1];
-    int64_t cur = bptr[kk];
+    const int64_t e = (g - work_off[t]) % na, p0 = (g - work_off[t]) / na * SLICE_PASSES;
+    const int64_t p1 = p0 + SLICE_PASSES < P ? p0 + SLICE_PASSES : P;
+    const int32_t kk = acol[a0 + e];
+    const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
     int32_t* out = bnd + slice_base[t] + e;
     const int32_t* rb = bounds + boff_by_row[row];
-    for (int64_t p = 0; p < P; ++p) {
+    int64_t cur = b0;
+    for (int64_t p = p0; p < p1; ++p) {
         int32_t x = rb[p];
         if (upper && x < row) x = row;
-        if (x > 0 && cur < b1 && bcol[cur] < x) {
+        if (p == p0 && p0 > 0) {
+            cur = lower_bound_col(bcol, b0, b1, x);  // first range start of this thread: bisect the whole row
+        } else if (x > 0 && cur < b1 && bcol[cur] < x) {
             // gallop: double the step while the column is still below x, then bisect the last step
             int64_t step = 1, prev = cur;
             while (prev + step < b1 && bcol[prev + step] < x) {
@@ -703,13 +712,13 @@ __global__ void __launch_bounds__(256)
         }
         out[p * na] = (int32_t)cur;
     }
-    out[P * na] = (int32_t)b1;
+    if (p1 == P) out[P * na] = (int32_t)b1;
 }
 
 template <typename T, int LOG2S, bool PRE>
 __global__ void __launch_bounds__(PART_THREADS)
-    k_spgemm_part(const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off, int64_t nb,
-                  const int32_t* __restrict__ bounds, const int64_t* __restrict__ boff_by_row, int64_t ncols,
+    k_spgemm_part(int64_t item_base, const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off,
+                  int64_t nb, const int32_t* __restrict__ bounds, const int64_t* __restrict__ boff_by_row, int64_t ncols,
                   int64_t cap, const int64_t* __restrict__ aptr,
                   const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
@@ -726,7 +735,7 @@ __global__ void __launch_bounds__(PART_THREADS)
     __shared__ int wave_tot[NT / 64];
     __shared__ int n_out;
     const int tid = threadIdx.x;
-    const int64_t item = blockIdx.x;
+    const int64_t item = item_base + blockIdx.x;
     int64_t lo = 0, hi = nb;  // largest t with item_off[t] <= item
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
@@ -939,6 +948,15 @@ static int64_t device_max_row_len(const Csr& A)
     return device_max(len, A.rows);
 }
 
+// HIP launches at most 2^32 - 1 threads per grid (more are silently not run): split a 1-D grid of `nblocks`
+// workgroups of `threads` threads into launches of at most 2^31 threads; f(first block, number of blocks).
+template <typename F>
+static void launch_batched(int64_t nblocks, int threads, F&& f)
+{
+    const int64_t maxb = ((int64_t)1 << 31) / threads;
+    for (int64_t off = 0; off < nblocks; off += maxb) f(off, nblocks - off < maxb ? nblocks - off : maxb);
+}
+
 // What the symbolic phase leaves for the numeric phase about the big rows (LDS bitmap path).
 struct BigRows {
     int log2s = 11;            // table size of the numeric range kernel; a range holds cap = 2^log2s / 2 columns
@@ -970,8 +988,10 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
     if (!force_global) {
 #define MI_SPGEMM_BIN(k, LOG2S, THREADS, GW)                                                                       \
     if (b.n[k]) {                                                                                                  \
-        MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC>), dim3((unsigned)b.n[k]), dim3(THREADS), c.stream,       \
-                  MI_SPGEMM_ARGS(b.list[k]), GW, (int)upper, row_nnz, cptr, ccol, cval);                             \
+        launch_batched(b.n[k], THREADS, [&](int64_t off, int64_t nb) {                                             \
+            MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC>), dim3((unsigned)nb), dim3(THREADS), c.stream,       \
+                      MI_SPGEMM_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);                   \
+        });                                                                                                        \
         b.n[k] = 0;                                                                                                \
     }
         MI_SPGEMM_BIN(0, 6, 64, gw64)
@@ -1044,37 +1064,38 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                 MI_LAUNCH(k_part_items, dim3((unsigned)ceil_div(nbig, 256)), dim3(256), c.stream, (const int32_t*)big_list,
                           cnt, nbig, CAP, (int64_t)1 << 62, items);
                 const int64_t n_items = exclusive_scan_i64(items, item_off, nbig);
-                if (n_items > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "SpGEMM result too large for one launch");
                 // slice table (see k_part_slices) unless it would be unreasonably large
-                int64_t* n_ent = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                int64_t* n_work = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
                 int64_t* n_slice = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
-                int64_t* ent_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                int64_t* work_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
                 int64_t* slice_base = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
                 MI_LAUNCH(k_part_slice_sizes, dim3((unsigned)ceil_div(nbig, 256)), dim3(256), c.stream,
-                          (const int32_t*)big_list, (const int64_t*)item_off, (const int64_t*)A.ptr, nbig, n_ent, n_slice);
-                const int64_t total_ent = exclusive_scan_i64(n_ent, ent_off, nbig);
+                          (const int32_t*)big_list, (const int64_t*)item_off, (const int64_t*)A.ptr, nbig, n_work, n_slice);
+                const int64_t total_work = exclusive_scan_i64(n_work, work_off, nbig);
                 const int64_t total_slices = exclusive_scan_i64(n_slice, slice_base, nbig);
-                const bool pre = options().spgemm_slice_table && total_slices <= options().spgemm_slice_table_max &&
-                                 ceil_div(total_ent, 256) < 2000000000;
+                const bool pre = options().spgemm_slice_table && total_slices <= options().spgemm_slice_table_max;
                 const int32_t* bounds = big.bounds.as<int32_t>();
                 const int64_t* brow = big.boff_by_row.as<int64_t>();
                 int32_t* bnd = nullptr;
                 if (pre) {
                     bnd = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(total_slices + 1)));
-                    if (total_ent)
-                        MI_LAUNCH(k_part_slices, dim3((unsigned)ceil_div(total_ent, 256)), dim3(256), c.stream,
-                                  (const int32_t*)big_list, nbig, (const int64_t*)ent_off, (const int64_t*)item_off, bounds,
-                                  brow, (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr,
-                                  (const int32_t*)B.col, upper, (const int64_t*)slice_base, bnd);
+                    launch_batched(ceil_div(total_work, 256), 256, [&](int64_t off, int64_t nblk) {
+                        MI_LAUNCH(k_part_slices, dim3((unsigned)nblk), dim3(256), c.stream, off, (const int32_t*)big_list, nbig,
+                                  (const int64_t*)work_off, (const int64_t*)item_off, bounds, brow, (const int64_t*)A.ptr,
+                                  (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, upper,
+                                  (const int64_t*)slice_base, bnd);
+                    });
                 }
                 auto launch = [&](auto log2s_tag, auto pre_tag) {
                     constexpr int L = decltype(log2s_tag)::value;
                     constexpr bool P = decltype(pre_tag)::value;
-                    MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)n_items), dim3(PART_THREADS), c.stream,
-                              (const int32_t*)big_list, (const int64_t*)item_off, nbig, bounds, brow, B.cols, CAP,
-                              (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,
-                              (const int32_t*)B.col, (const T*)B.val, upper, (const int64_t*)slice_base,
-                              (const int32_t*)bnd, cptr, ccol, cval);
+                    launch_batched(n_items, PART_THREADS, [&](int64_t off, int64_t nblk) {
+                        MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)nblk), dim3(PART_THREADS), c.stream, off,
+                                  (const int32_t*)big_list, (const int64_t*)item_off, nbig, bounds, brow, B.cols, CAP,
+                                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,
+                                  (const int32_t*)B.col, (const T*)B.val, upper, (const int64_t*)slice_base,
+                                  (const int32_t*)bnd, cptr, ccol, cval);
+                    });
                 };
                 if (n_items) {
                     constexpr int LO = sizeof(T) >= 16 ? 10 : 11, HI = LO + 1;

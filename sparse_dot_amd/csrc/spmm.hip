@@ -528,15 +528,13 @@ static void convert_layout(int64_t rows, int64_t cols, const T* src, int64_t s_r
 // ------------------------------------------------------------------------------------------------
 __global__ void k_count_cols(const int32_t* __restrict__ col, int64_t nnz, unsigned* __restrict__ counts)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nnz) atomicAdd(&counts[col[i]], 1u);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&counts[col[i]], 1u);
 }
 
 __global__ void k_tag_cols(const int32_t* __restrict__ col, int64_t nnz, const unsigned* __restrict__ counts,
                            unsigned threshold, int32_t* __restrict__ tagged)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nnz) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t c = col[i];
         tagged[i] = counts[c] >= threshold ? c : (int32_t)((unsigned)c | 0x80000000u);
     }
@@ -556,7 +554,7 @@ static void plan_hot_cold(SpmmPlan& p, const Csr& m, int64_t hot_rows)
     Context& c = ctx();
     unsigned* counts = static_cast<unsigned*>(c.scratch_alloc(sizeof(unsigned) * (size_t)m.cols));
     MI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned) * (size_t)m.cols, c.stream));
-    MI_LAUNCH(k_count_cols, dim3((unsigned)ceil_div(m.nnz, 256)), dim3(256), c.stream, (const int32_t*)m.col, m.nnz,
+    MI_LAUNCH(k_count_cols, dim3((unsigned)(ceil_div(m.nnz, 256) < (1 << 20) ? ceil_div(m.nnz, 256) : (1 << 20))), dim3(256), c.stream, (const int32_t*)m.col, m.nnz,
               counts);
     std::vector<unsigned> hc((size_t)m.cols);
     MI_HIP_CHECK(hipMemcpyAsync(hc.data(), counts, sizeof(unsigned) * (size_t)m.cols, hipMemcpyDeviceToHost, c.stream));
@@ -573,7 +571,7 @@ static void plan_hot_cold(SpmmPlan& p, const Csr& m, int64_t hot_rows)
     // worth it only when a small set takes a real share of the gather and ties did not blow the set up
     if (!force && (p.hot_coverage < 0.10 || nhot > 2 * hot_rows)) return;
     p.col_tagged.alloc(sizeof(int32_t) * (size_t)m.nnz);
-    MI_LAUNCH(k_tag_cols, dim3((unsigned)ceil_div(m.nnz, 256)), dim3(256), c.stream, (const int32_t*)m.col, m.nnz,
+    MI_LAUNCH(k_tag_cols, dim3((unsigned)(ceil_div(m.nnz, 256) < (1 << 20) ? ceil_div(m.nnz, 256) : (1 << 20))), dim3(256), c.stream, (const int32_t*)m.col, m.nnz,
               (const unsigned*)counts, thr, p.col_tagged.as<int32_t>());
     p.tagged = true;
 }

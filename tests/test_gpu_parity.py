@@ -536,6 +536,7 @@ def test_order_big_rows_bitmap_counting_sort(gpu, dup):
     if dup:
         cols[0][5] = cols[0][9000]
         cols[4][0] = cols[4][1] = cols[4][149999]
+        cols[5][7] = cols[5][300]
     ind = np.concatenate(cols)
     dat = rng.uniform(0.5, 1.5, ind.size)
     ptr = np.concatenate([[0], np.cumsum(lens)])
