@@ -204,6 +204,9 @@ def main():
         sda.mi_set_option("spmm_unroll", args.unroll)
     if args.hot_kb >= 0:
         sda.mi_set_option("spmm_hot_kb", args.hot_kb)
+    for kv in os.environ.get("MI_BENCH_OPTS", "").split(","):  # tuning hook, e.g. MI_BENCH_OPTS=pool_enable=0
+        if "=" in kv:
+            sda.mi_set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
     # ---- synthetic inputs, generated on the device ------------------------------------------------
     N = args.ncols

@@ -376,8 +376,14 @@ mi_sparse_status_t mi_sparse_set_stream(void *hip_stream);
 mi_sparse_status_t mi_sparse_synchronize(void);
 /* Reason for the calling thread's most recent non-zero status ("" if none). */
 const char *mi_sparse_last_error(void);
-/* Tuning / diagnostic knob: name -> integer value (e.g. "spmm_chunk"); unknown names return
- * INVALID_VALUE.  Used by bench.py to A/B kernel variants; defaults are the shipped choice. */
+/* Tuning / diagnostic knob: name -> integer value; unknown names return INVALID_VALUE.  Used by
+ * bench.py / tools to A/B kernel variants; defaults are the shipped choice.  Names:
+ *   spmm_chunk, spmm_unroll, spmm_hot_kb, spmm_hot_force, spmm_force_generic   (SpMM kernel variants)
+ *   spgemm_lds_parts, spgemm_slice_table, spgemm_slice_table_max, spgemm_part_log2s_bias,
+ *   spgemm_force_global, spgemm_global_mode                                     (SpGEMM big-row paths)
+ *   pool_enable (0: hipFree released device blocks at once), pool_max_mb (cap on cached bytes,
+ *   -1 = half of the device memory), pool_trim (any value: return the cache to the driver now)
+ *   profile_events, trace_phases                                               (diagnostics) */
 mi_sparse_status_t mi_sparse_set_option(const char *name, int64_t value);
 /* Diagnostic counters of the calling thread.  With option "profile_events" = 1 the SpMM executor
  * brackets its main kernel with hipEvents on the launch stream and accumulates
