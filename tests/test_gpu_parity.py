@@ -681,6 +681,82 @@ def test_gram_sparse_unsorted_input_rows(gpu):
         assert rel_err(g.data, want.data) <= 1e-12
 
 
+def _rand_rows(k, n, per_row, rng):
+    """k x n CSR with ~per_row distinct random columns per row (sps.random is far too slow for n ~ 1e6)."""
+    cols = [np.unique(rng.integers(0, n, per_row)) for _ in range(k)]
+    ptr = np.concatenate([[0], np.cumsum([c.size for c in cols])])
+    ind = np.concatenate(cols).astype(np.int32)
+    return sps.csr_matrix((rng.uniform(0.5, 1.5, ind.size), ind, ptr), shape=(k, n))
+
+
+def _hub_case(kind):
+    """Crafted SpGEMM operands around the edges of the big-row (bitmap / column-range) path."""
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    if kind == "exact_range_multiples":
+        # C rows with exactly 1024, 2048, 3072 and 4097 distinct columns (ranges hold 1024 columns when B is wide)
+        n, k = 70000, 8
+        bcols = [np.sort(rng.choice(n, m, replace=False)) for m in (1024, 2048, 3072, 4097, 5, 0, 8193, 16384)]
+        b = sps.csr_matrix((np.concatenate([rng.uniform(0.5, 1.5, c.size) for c in bcols]), np.concatenate(bcols),
+                            np.concatenate([[0], np.cumsum([c.size for c in bcols])])), shape=(k, n))
+        a = sps.csr_matrix(np.vstack([np.eye(k), np.ones((2, k)), np.zeros((1, k))]))
+        return a, b
+    if kind == "wide_bitmap_limit":
+        # B as wide as a 2^20-column bitmap allows, hub row of A selecting many B rows
+        n, k = 1 << 20, 3000
+        b = _rand_rows(k, n, 40, rng)
+        a = sps.random(40, k, density=0.01, format="lil", random_state=12, dtype=np.float64)
+        a[3, rng.choice(k, 900, replace=False)] = 1.25
+        a[17, :] = 0
+        return a.tocsr(), b
+    if kind == "too_wide_for_bitmap":
+        n, k = 1_300_000, 2000   # falls back to the global-memory hash
+        b = _rand_rows(k, n, 30, rng)
+        a = sps.random(30, k, density=0.01, format="lil", random_state=14, dtype=np.float64)
+        a[5, rng.choice(k, 700, replace=False)] = 0.5
+        return a.tocsr(), b
+    if kind == "duplicates_in_b":
+        # non-canonical B: repeated column entries inside a row (sorted non-strictly); they must be summed
+        n, k = 50000, 600
+        b0 = sps.random(k, n, density=60 / n, format="csr", random_state=15, dtype=np.float64)
+        ind = np.repeat(b0.indices, 2)
+        dat = np.repeat(b0.data, 2) * np.tile([0.25, 0.75], b0.nnz)
+        b = sps.csr_matrix((dat, ind, b0.indptr * 2), shape=b0.shape)
+        a = sps.random(20, k, density=0.02, format="lil", random_state=16, dtype=np.float64)
+        a[0, rng.choice(k, 400, replace=False)] = 2.0
+        return a.tocsr(), b
+    if kind == "unsorted_b":
+        n, k = 50000, 600
+        b0 = sps.random(k, n, density=60 / n, format="csr", random_state=17, dtype=np.float64)
+        ind, dat = b0.indices.copy(), b0.data.copy()
+        for r in range(k):
+            lo, hi = b0.indptr[r], b0.indptr[r + 1]
+            o = rng.permutation(hi - lo)
+            ind[lo:hi], dat[lo:hi] = b0.indices[lo:hi][o], b0.data[lo:hi][o]
+        b = sps.csr_matrix((dat, ind, b0.indptr.copy()), shape=b0.shape)
+        a = sps.random(20, k, density=0.02, format="lil", random_state=18, dtype=np.float64)
+        a[0, rng.choice(k, 400, replace=False)] = 2.0
+        return a.tocsr(), b
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex64])
+@pytest.mark.parametrize("kind", ["exact_range_multiples", "wide_bitmap_limit", "too_wide_for_bitmap", "duplicates_in_b",
+                                  "unsorted_b"])
+def test_spgemm_big_row_edges(gpu, kind, dtype):
+    a, b = _hub_case(kind)
+    a, b = a.astype(dtype), b.astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        a.data = a.data * (1 + 0.5j)
+        b.data = b.data * (0.5 - 1j)
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    want = (a.astype(wide) @ b.astype(wide)).tocsr()   # scipy sums duplicates and keeps structural entries
+    want.sort_indices()
+    got = gpu.dot_product_mkl(a, b)
+    _check_spgemm(got, want, dtype)
+    got = gpu.dot_product_mkl(a, b, reorder_output=True)
+    assert np.array_equal(got.indices, want.indices) and np.array_equal(got.indptr, want.indptr)
+
+
 def test_spgemm_keeps_cancelled_entries_and_sums_duplicates(gpu):
     a = sps.csr_matrix(np.array([[1.0, -1.0, 0.0], [0.0, 2.0, 0.0]]))
     b = sps.csr_matrix(np.array([[1.0, 0.0], [1.0, 0.0], [0.0, 3.0]]))
