@@ -297,14 +297,17 @@ def main():
                 fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / reps * 1e3
-        gathered = torch.empty((world * n, N), device=dev, dtype=torch.float32)
-        collectives = {
-            "broadcast_B_ms": round(timed(lambda: bcast(B)), 3),
-            "allgather_C_ms": round(timed(lambda: allgather_rows(gathered, C)), 3),
-            "backend": backend,
-            "note": "RCCL over xGMI; not part of the timed step (weak scaling, outputs stay row-distributed)",
-        }
-        del gathered
+        try:  # informational: a failure here must not cost the headline line
+            gathered = torch.empty((world * n, N), device=dev, dtype=torch.float32)
+            collectives = {
+                "broadcast_B_ms": round(timed(lambda: bcast(B)), 3),
+                "allgather_C_ms": round(timed(lambda: allgather_rows(gathered, C)), 3),
+                "backend": backend,
+                "note": "RCCL over xGMI; not part of the timed step (weak scaling, outputs stay row-distributed)",
+            }
+            del gathered
+        except Exception as exc:  # noqa: BLE001
+            collectives = {"error": "%s: %s" % (type(exc).__name__, exc), "backend": backend}
 
     # ---- secondary workload the north_star asks to report alongside: uniform-random CSR, same shape ----
     secondary = None

@@ -141,7 +141,16 @@ __device__ __forceinline__ int flat_find(const int* inc, int f)
 // list -- the dependent chain acol -> bptr -> bcol is paid once per THREADS nonzeros of A, not once per
 // nonzero, and a row of A with thousands of nonzeros but few surviving products (the last rows of an
 // upper-triangular gram matrix) does not serialise on one lane group.
-constexpr int LDS_UNROLL = 2;
+#ifndef MI_BIN3_THREADS  // tuning hooks
+#define MI_BIN3_THREADS 64
+#endif
+#ifndef MI_BIN4_THREADS
+#define MI_BIN4_THREADS 128
+#endif
+#ifndef MI_LDS_UNROLL
+#define MI_LDS_UNROLL 2
+#endif
+constexpr int LDS_UNROLL = MI_LDS_UNROLL;
 template <typename T, int LOG2S, int THREADS, bool NUMERIC>
 __global__ void __launch_bounds__(THREADS)
     k_spgemm_lds(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
@@ -169,6 +178,8 @@ __global__ void __launch_bounds__(THREADS)
 
     int local = 0;
     const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+    int64_t out0 = 0;
+    if (NUMERIC) out0 = cptr[row];  // needed last: issued first so that its latency is hidden
     for (int64_t base = a0; base < a1; base += THREADS) {
         int len = 0;
         if (base + tid < a1) {
@@ -218,7 +229,6 @@ __global__ void __launch_bounds__(THREADS)
         __syncthreads();
         if (tid == 0) row_nnz[row] = counter;
     } else {
-        const int64_t out0 = cptr[row];
         for (int k = tid; k < S; k += THREADS) {
             const int32_t key = keys[k];
             if (key != HASH_EMPTY) {
@@ -997,8 +1007,8 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
         MI_SPGEMM_BIN(0, 6, 64, gw64)
         MI_SPGEMM_BIN(1, 7, 64, gw64)
         MI_SPGEMM_BIN(2, 8, 64, gw64)
-        MI_SPGEMM_BIN(3, 9, 128, gw64)
-        MI_SPGEMM_BIN(4, 10, 128, gw64)
+        MI_SPGEMM_BIN(3, 9, MI_BIN3_THREADS, gw64)
+        MI_SPGEMM_BIN(4, 10, MI_BIN4_THREADS, gw64)
         MI_SPGEMM_BIN(5, 11, 256, gw)
         MI_SPGEMM_BIN(6, 12, 256, gw)
         // bin 7 (<= 4096): 8192-slot table -- 32 KiB of keys + up to 64 KiB of values.  (Symbolic phase with

@@ -3,12 +3,12 @@
 set -e
 cd "$(dirname "$0")/../sparse_dot_amd/csrc"
 mkdir -p build/var
-for spec in "s11:-DMI_PART_LOG2S=11" "t1024:-DMI_PART_THREADS=1024" "s11t256:-DMI_PART_LOG2S=11 -DMI_PART_THREADS=256" "s13t1024:-DMI_PART_LOG2S=13 -DMI_PART_THREADS=1024"; do
+for spec in "b4t64:-DMI_BIN4_THREADS=64" "b3t128:-DMI_BIN3_THREADS=128"; do
   tag=${spec%%:*}; def=${spec#*:}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $def -c spgemm.hip -o build/var/spgemm_$tag.o &
 done
 wait
-for tag in s11 t1024 s11t256 s13t1024; do
+for tag in b4t64 b3t128; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/var/libmi_sparse_$tag.so build/runtime.o build/handle.o build/spmm.o build/var/spgemm_$tag.o build/gram.o build/dense.o
 done
 ls -la build/var/*.so
