@@ -683,9 +683,23 @@ __global__ void __launch_bounds__(256)
                   const int32_t* __restrict__ bcol, int upper, const int64_t* __restrict__ slice_base,
                   int32_t* __restrict__ bnd)
 {
+    // row of this work item: largest t with work_off[t] <= g.  The first and the last thread of the workgroup
+    // search the whole table, the others only between those two results (usually the same row).
+    __shared__ int64_t t_edge[2];
+    const int64_t total = work_off[nb];
     const int64_t g = (block_base + blockIdx.x) * blockDim.x + threadIdx.x;
-    if (g >= work_off[nb]) return;
-    int64_t lo = 0, hi = nb;  // largest t with work_off[t] <= g
+    if (threadIdx.x == 0 || threadIdx.x == blockDim.x - 1) {
+        const int64_t ge = g < total ? g : total - 1;
+        int64_t lo = 0, hi = nb;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (work_off[mid] <= ge) lo = mid; else hi = mid;
+        }
+        t_edge[threadIdx.x ? 1 : 0] = lo;
+    }
+    __syncthreads();
+    if (g >= total) return;
+    int64_t lo = t_edge[0], hi = t_edge[1] + 1;
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
         if (work_off[mid] <= g) lo = mid; else hi = mid;
@@ -725,15 +739,60 @@ __global__ void __launch_bounds__(256)
     if (p1 == P) out[P * na] = (int32_t)b1;
 }
 
+// Everything a (row, range) workgroup needs about its row in ONE 64-byte load, and the row of every work
+// item in one 4-byte load: the first version found its row by a 19-step binary search over the item offsets
+// (dependent loads, ~10 us) at the start of each of millions of workgroups.
+struct alignas(64) PartDesc {
+    int64_t a0, na;         // the row's nonzeros in A
+    int64_t item0;          // first work item of the row (range index = item - item0)
+    int64_t slice_base;     // the row's slice table in bnd (k_part_slices)
+    int64_t out0;           // cptr[row]
+    int64_t boff;           // the row's range starts in bounds
+    int32_t row, npass;
+    int64_t pad_;
+};
+
+__global__ void k_part_desc(const int32_t* __restrict__ row_list, int64_t nb, const int64_t* __restrict__ item_off,
+                            const int64_t* __restrict__ aptr, const int64_t* __restrict__ slice_base,
+                            const int64_t* __restrict__ cptr, const int64_t* __restrict__ boff_by_row,
+                            PartDesc* __restrict__ desc)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb) return;
+    const int32_t row = row_list[t];
+    PartDesc d;
+    d.a0 = aptr[row];
+    d.na = aptr[row + 1] - d.a0;
+    d.item0 = item_off[t];
+    d.slice_base = slice_base[t];
+    d.out0 = cptr[row];
+    d.boff = boff_by_row[row];
+    d.row = row;
+    d.npass = (int32_t)(item_off[t + 1] - item_off[t]);
+    d.pad_ = 0;
+    desc[t] = d;
+}
+
+__global__ void k_part_item_map(int64_t n_items, int64_t nb, const int64_t* __restrict__ item_off,
+                                int32_t* __restrict__ item_t)
+{
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_items; g += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = nb;  // largest t with item_off[t] <= g
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (item_off[mid] <= g) lo = mid; else hi = mid;
+        }
+        item_t[g] = (int32_t)lo;
+    }
+}
+
 template <typename T, int LOG2S, bool PRE>
 __global__ void __launch_bounds__(PART_THREADS)
-    k_spgemm_part(int64_t item_base, const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off,
-                  int64_t nb, const int32_t* __restrict__ bounds, const int64_t* __restrict__ boff_by_row, int64_t ncols,
-                  int64_t cap, const int64_t* __restrict__ aptr,
+    k_spgemm_part(int64_t item_base, const int32_t* __restrict__ item_t, const PartDesc* __restrict__ desc,
+                  const int32_t* __restrict__ bounds, int64_t ncols, int64_t cap,
                   const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
-                  const int64_t* __restrict__ slice_base, const int32_t* __restrict__ bnd,
-                  const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol, T* __restrict__ cval)
+                  const int32_t* __restrict__ bnd, int32_t* __restrict__ ccol, T* __restrict__ cval)
 {
     constexpr int S = 1 << LOG2S;
     constexpr int NT = PART_THREADS;
@@ -746,31 +805,30 @@ __global__ void __launch_bounds__(PART_THREADS)
     __shared__ int n_out;
     const int tid = threadIdx.x;
     const int64_t item = item_base + blockIdx.x;
-    int64_t lo = 0, hi = nb;  // largest t with item_off[t] <= item
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (item_off[mid] <= item) lo = mid; else hi = mid;
+    const PartDesc d = desc[item_t[item]];
+    const int64_t pass = item - d.item0;
+    const int32_t row = d.row;
+    int32_t c_lo = 0;
+    int64_t c_hi = ncols;
+    if constexpr (!PRE) {
+        const int32_t* rb = bounds + d.boff;
+        c_lo = rb[pass];
+        if (pass + 1 < d.npass) c_hi = rb[pass + 1];
+        if (upper && c_lo < row) c_lo = row;
     }
-    const int64_t t = lo;
-    const int64_t pass = item - item_off[t], npass = item_off[t + 1] - item_off[t];
-    const int32_t row = row_list[t];
-    const int32_t* rb = bounds + boff_by_row[row];
-    int32_t c_lo = rb[pass];
-    const int64_t c_hi = pass + 1 < npass ? (int64_t)rb[pass + 1] : ncols;
-    if (upper && c_lo < row) c_lo = row;
     for (int k = tid; k < S; k += NT) {
         keys[k] = HASH_EMPTY;
         vals[k] = vt<T>::zero();
     }
     if (tid == 0) n_out = 0;
     __syncthreads();
-    const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+    const int64_t a0 = d.a0, a1 = d.a0 + d.na;
     // slice of B row acol[p] that falls in [c_lo, c_hi), and the A value: loaded one chunk ahead so that the
     // latency of these loads is hidden behind the product walk of the current chunk
     int64_t s_n = 0, e_n = 0;
     T a_n = vt<T>::zero();
     const int32_t* sl0 = nullptr;
-    if constexpr (PRE) sl0 = bnd + slice_base[t] + pass * (a1 - a0);  // slices precomputed by k_part_slices
+    if constexpr (PRE) sl0 = bnd + d.slice_base + pass * d.na;  // slices precomputed by k_part_slices
     auto fetch = [&](int64_t p) {
         s_n = e_n = 0;
         if (p < a1) {
@@ -832,7 +890,7 @@ __global__ void __launch_bounds__(PART_THREADS)
         }
         __syncthreads();
     }
-    const int64_t out0 = cptr[row] + pass * cap;
+    const int64_t out0 = d.out0 + pass * cap;
     for (int k = tid; k < S; k += NT) {
         const int32_t key = keys[k];
         if (key != HASH_EMPTY) {
@@ -1096,15 +1154,23 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                                   (const int64_t*)slice_base, bnd);
                     });
                 }
+                PartDesc* desc = static_cast<PartDesc*>(c.scratch_alloc(sizeof(PartDesc) * (size_t)(nbig + 1)));
+                int32_t* item_t = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(n_items + 1)));
+                MI_LAUNCH(k_part_desc, dim3((unsigned)ceil_div(nbig, 256)), dim3(256), c.stream, (const int32_t*)big_list, nbig,
+                          (const int64_t*)item_off, (const int64_t*)A.ptr, (const int64_t*)slice_base, cptr, brow, desc);
+                if (n_items) {
+                    const int64_t gb = ceil_div(n_items, 256);
+                    MI_LAUNCH(k_part_item_map, dim3((unsigned)(gb < (1 << 20) ? gb : (1 << 20))), dim3(256), c.stream, n_items,
+                              nbig, (const int64_t*)item_off, item_t);
+                }
                 auto launch = [&](auto log2s_tag, auto pre_tag) {
                     constexpr int L = decltype(log2s_tag)::value;
                     constexpr bool P = decltype(pre_tag)::value;
                     launch_batched(n_items, PART_THREADS, [&](int64_t off, int64_t nblk) {
                         MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)nblk), dim3(PART_THREADS), c.stream, off,
-                                  (const int32_t*)big_list, (const int64_t*)item_off, nbig, bounds, brow, B.cols, CAP,
-                                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,
-                                  (const int32_t*)B.col, (const T*)B.val, upper, (const int64_t*)slice_base,
-                                  (const int32_t*)bnd, cptr, ccol, cval);
+                                  (const int32_t*)item_t, (const PartDesc*)desc, bounds, B.cols, CAP, (const int32_t*)A.col,
+                                  (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val, upper,
+                                  (const int32_t*)bnd, ccol, cval);
                     });
                 };
                 if (n_items) {
