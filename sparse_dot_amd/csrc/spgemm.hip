@@ -611,6 +611,7 @@ __global__ void __launch_bounds__(1024)
             if (tid == 0) row_nnz[row] = counter;
         } else {
             // rank of every set bit -> the column where each range of `cap` distinct columns starts
+            const int cap_log2 = 63 - __builtin_clzll((unsigned long long)cap);
             const int64_t per = (words + threads - 1) / threads;
             const int64_t w0 = (int64_t)tid * per, w1 = w0 + per < words ? w0 + per : words;
             int local = 0;
@@ -628,7 +629,7 @@ __global__ void __launch_bounds__(1024)
                 const int c = __popc(w);
                 if (c) {
                     // boundaries b*cap (b >= 1) with rank <= b*cap < rank + c
-                    int64_t b = (rank + cap - 1) / cap;
+                    int64_t b = (rank + cap - 1) >> cap_log2;  // cap is a power of two
                     if (b == 0) b = 1;
                     int taken = 0;  // set bits of the word already skipped
                     for (; b * cap < rank + c; ++b) {
@@ -708,7 +709,11 @@ __global__ void __launch_bounds__(256)
     const int32_t row = row_list[t];
     const int64_t a0 = aptr[row], na = aptr[row + 1] - a0;
     const int64_t P = item_off[t + 1] - item_off[t];
-    const int64_t e = (g - work_off[t]) % na, p0 = (g - work_off[t]) / na * SLICE_PASSES;
+    const int64_t local = g - work_off[t];
+    int64_t chunk;  // 64-bit integer division is a long software loop on the GPU: take the 32-bit one when it fits
+    if ((uint64_t)local < (1ull << 32) && (uint64_t)na < (1ull << 32)) chunk = (int64_t)((uint32_t)local / (uint32_t)na);
+    else chunk = local / na;
+    const int64_t e = local - chunk * na, p0 = chunk * SLICE_PASSES;
     const int64_t p1 = p0 + SLICE_PASSES < P ? p0 + SLICE_PASSES : P;
     const int32_t kk = acol[a0 + e];
     const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];

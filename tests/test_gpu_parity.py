@@ -552,6 +552,28 @@ def test_order_big_rows_bitmap_counting_sort(gpu, dup):
     assert np.array_equal(out.indices, ri) and np.array_equal(out.data, rd)
 
 
+@pytest.mark.parametrize("ncols", [(1 << 23) - 1, (1 << 23) + 5, 3_000_000_0])
+def test_order_small_rows_wide_matrices(gpu, ncols):
+    """Rows of up to 512 entries are sorted with (column, position) keys packed in 32 bits when the matrix has
+    fewer than 2^23 columns and in 64 bits otherwise: exercise both, with columns at the top of the range."""
+    from sparse_dot_amd._mi_interface import SparseHandle
+    rng = np.random.default_rng(41)
+    lens = [512, 1, 300, 0, 511, 2, 64]
+    cols = [rng.choice(np.arange(ncols - 5000, ncols), l, replace=False).astype(np.int32) for l in lens]
+    cols[0][0] = ncols - 1
+    cols[4][510] = 0
+    ind = np.concatenate(cols)
+    dat = rng.uniform(0.5, 1.5, ind.size)
+    ptr = np.concatenate([[0], np.cumsum(lens)])
+    a = sps.csr_matrix((dat, ind, ptr), shape=(len(lens), ncols))
+    with SparseHandle.from_scipy(a) as h:
+        h.order()
+        out = h.export("csr_matrix")
+    ref = sps.csr_matrix((dat.copy(), ind.copy(), ptr.copy()), shape=a.shape)
+    ref.sort_indices()
+    assert np.array_equal(out.indices, ref.indices) and np.array_equal(out.data, ref.data)
+
+
 # ---- SpGEMM -----------------------------------------------------------------------------------------
 def _check_spgemm(got, want, dtype):
     g = got.tocsr().copy()
