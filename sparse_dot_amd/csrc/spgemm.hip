@@ -660,7 +660,10 @@ __global__ void k_part_items(const int32_t* __restrict__ row_list, const int64_t
 // One thread per (big row, nonzero of A): the P boundaries of one B row are found left to right by
 // galloping from the previous one, with every thread of the GPU busy -- inside k_spgemm_part the same
 // searches would be dependent loads in a workgroup-synchronous phase (measured: the dominant cost).
-constexpr int SLICE_PASSES = 8;  // range starts found by one thread of k_part_slices (first by bisection, rest by galloping)
+#ifndef MI_SLICE_PASSES
+#define MI_SLICE_PASSES 8
+#endif
+constexpr int SLICE_PASSES = MI_SLICE_PASSES;  // range starts found by one thread of k_part_slices (first by bisection, rest by galloping)
 
 __global__ void k_part_slice_sizes(const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off,
                                    const int64_t* __restrict__ aptr, int64_t nb, int64_t* __restrict__ n_work,
@@ -1147,6 +1150,9 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                 const int64_t total_work = exclusive_scan_i64(n_work, work_off, nbig);
                 const int64_t total_slices = exclusive_scan_i64(n_slice, slice_base, nbig);
                 const bool pre = options().spgemm_slice_table && total_slices <= options().spgemm_slice_table_max;
+                if (options().trace_phases)
+                    fprintf(stderr, "[mi_sparse spgemm] big rows %lld, range items %lld, slice entries %lld, slice threads %lld\n",
+                            (long long)nbig, (long long)n_items, (long long)total_slices, (long long)total_work);
                 const int32_t* bounds = big.bounds.as<int32_t>();
                 const int64_t* brow = big.boff_by_row.as<int64_t>();
                 int32_t* bnd = nullptr;
