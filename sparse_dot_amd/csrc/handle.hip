@@ -961,6 +961,13 @@ mi_sparse_status_t mi_sparse_order(mi_sparse_matrix_t A)
         mi::sort_csr(h->vtype, primary);
         mi::Csr& other = created_csc ? h->csr : h->csrT;
         if (other.valid) mi::sort_csr(h->vtype, other);
+        // the SpMM plans cache a hot/cold-tagged COPY of the column indices in storage order: stale once the
+        // entries have moved (the row partition itself depends only on the row pointer and stays valid)
+        for (mi::SpmmPlan* p : {&h->plan, &h->planT}) {
+            p->hot_rows_budget = -1;
+            p->tagged = false;
+            p->col_tagged.release();
+        }
         // MKL orders the caller's arrays in place; mirror that for host-created handles
         if (!was_sorted && h->user_col && h->user_val && h->origin != 'b' && primary.nnz) {
             if (h->index_bytes == 4 && h->user_base == 0) {

@@ -123,6 +123,37 @@ def test_spmm_hot_cold_tagged_gather(gpu, oracle, dtype, n):
     assert rel_err(tagged, oracle.spmm(a.astype(wide), b.astype(wide))) <= tol(dtype)
 
 
+def test_order_invalidates_the_cached_tagged_columns(gpu):
+    """The SpMM plan caches a hot/cold-tagged copy of the column indices in storage order; mi_sparse_order moves
+    the entries, so a product after ordering must not use the stale copy."""
+    rng = np.random.default_rng(19)
+    m, k, n = 600, 500, 32
+    lens = rng.integers(1, 40, m)
+    p = 1.0 / np.arange(1, k + 1) ** 1.1
+    p /= p.sum()
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = np.concatenate([rng.choice(k, l, replace=False, p=p) for l in lens]).astype(np.int32)  # unsorted rows
+    data = rng.uniform(0.5, 1.5, indices.size)
+    a = sps.csr_matrix((data, indices, indptr), shape=(m, k))
+    assert not a.has_sorted_indices
+    b = dense((k, n), np.float64, 20)
+    want = a.toarray() @ b
+    gpu.mi_set_option("spmm_hot_force", 1)
+    gpu.mi_set_option("spmm_hot_kb", 64)
+    try:
+        A = gpu.to_device(a)
+        first = gpu.dot_product_mkl(A, b)
+        assert gpu.mi_get_counter("spmm_last_tagged") == 1.0
+        A.handle.order()
+        second = gpu.dot_product_mkl(A, b)
+        assert gpu.mi_get_counter("spmm_last_tagged") == 1.0
+        A.free()
+    finally:
+        gpu.mi_set_option("spmm_hot_force", 0)
+        gpu.mi_set_option("spmm_hot_kb", 8192)
+    assert rel_err(first, want) <= 1e-12 and rel_err(second, want) <= 1e-12
+
+
 def test_spmm_determinism(gpu):
     a = pos_csr(4000, 3000, 0.02, np.float32, 5)
     b = dense((3000, 128), np.float32, 6)
