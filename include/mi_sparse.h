@@ -260,8 +260,10 @@ mi_sparse_status_t mi_sparse_get_info(mi_sparse_matrix_t A, int64_t *rows, int64
                                       char *value_type, int *index_bytes);
 
 /* DEVICE pointers of the handle's canonical CSR arrays -- indptr: int64_t[rows + 1], col_indx:
- * int32_t[nnz], values: nnz elements of the handle's value type -- valid until destroy.  Lets
- * HBM-resident callers consume spmm / syrk results without a host round trip. */
+ * int32_t[nnz], values: nnz elements of the handle's value type -- valid until the handle is
+ * destroyed or re-ordered (mi_sparse_order may move a library-owned result's values to a new
+ * block: fetch the pointers again after it).  Lets HBM-resident callers consume spmm / syrk results
+ * without a host round trip. */
 mi_sparse_status_t mi_sparse_get_device_csr(mi_sparse_matrix_t A, void **indptr, void **col_indx,
                                             void **values);
 

@@ -467,15 +467,30 @@ void sort_csr(char vtype, Csr& a)
                       (const int64_t*)big_rows, (const int64_t*)doff, slabs, perm);
         }
     }
-    // permute values through a temporary
+    // permute the values: into a fresh block that replaces the old one when the library owns the storage
+    // (results of spmm / syrk / transposes), through a temporary and back when the values alias caller HBM
     const size_t vb = value_bytes(vtype);
-    void* tmp = c.scratch_alloc(vb * (size_t)a.nnz);
+    const bool owned = a.val_own.p && a.val == a.val_own.p;
+    DevBuf fresh;
+    void* tmp;
+    if (owned) {
+        fresh.alloc(vb * (size_t)a.nnz);
+        tmp = fresh.p;
+    } else {
+        tmp = c.scratch_alloc(vb * (size_t)a.nnz);
+    }
     by_type(vtype, [&](auto tag) {
         using T = decltype(tag);
         MI_LAUNCH((k_gather_vals<T>), grid1d_stride(a.nnz, 256), dim3(256), c.stream, (const T*)a.val,
                   (const int64_t*)perm, a.nnz, (T*)tmp);
     });
-    MI_HIP_CHECK(hipMemcpyAsync(a.val, tmp, vb * (size_t)a.nnz, hipMemcpyDeviceToDevice, c.stream));
+    if (owned) {
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // the old block goes back to the cache: nothing may still read it
+        a.val_own = std::move(fresh);
+        a.val = a.val_own.p;
+    } else {
+        MI_HIP_CHECK(hipMemcpyAsync(a.val, tmp, vb * (size_t)a.nnz, hipMemcpyDeviceToDevice, c.stream));
+    }
     a.sorted = true;
 }
 
