@@ -155,12 +155,19 @@ constexpr int SORT_SMALL_MAX = 512;    // one wave (64-thread block) per row, ke
 constexpr int SORT_BLOCK_MAX = 8192;   // one 256-thread block per row, keys in LDS
 constexpr int SORT_ROWS_PER_SMALL_BLOCK = 8;
 
-// rows with 2 <= len <= SORT_SMALL_MAX.  Writes sorted columns in place and perm[p] = source
-// position (absolute) for the value permutation pass.  K = uint32_t packs (column, position) into 32 bits
+// Every sort kernel writes the sorted columns in place and moves the VALUES itself, from `vin` to the same
+// positions of `vout` (a different block: out of place), as opaque 4- / 8- / 16-byte words V -- no
+// permutation array, no separate gather pass.
+struct alignas(16) Word16 {
+    uint64_t a, b;
+};
+
+// rows with len <= SORT_SMALL_MAX.  K = uint32_t packs (column, position) into 32 bits
 // (matrices with fewer than 2^23 columns: 23 + 9 bits) -- half the LDS traffic and single-instruction
 // compares of the 64-bit form.
-template <typename K>
-__global__ void __launch_bounds__(64) k_sort_small(const int64_t* ptr, int32_t* col, int64_t rows, int64_t* perm)
+template <typename K, typename V>
+__global__ void __launch_bounds__(64)
+    k_sort_small(const int64_t* ptr, int32_t* col, int64_t rows, const V* __restrict__ vin, V* __restrict__ vout)
 {
     constexpr int POS_BITS = sizeof(K) == 4 ? 9 : 32;  // SORT_SMALL_MAX == 512 == 2^9
     constexpr K POS_MASK = (K)(((uint64_t)1 << POS_BITS) - 1);
@@ -173,7 +180,7 @@ __global__ void __launch_bounds__(64) k_sort_small(const int64_t* ptr, int32_t* 
         const int64_t len = ptr[row + 1] - p0;
         if (len > SORT_SMALL_MAX) continue;
         if (len < 2) {
-            if (len == 1 && lane == 0) perm[p0] = p0;
+            if (len == 1 && lane == 0) vout[p0] = vin[p0];
             continue;
         }
         int64_t n = 2;
@@ -185,15 +192,16 @@ __global__ void __launch_bounds__(64) k_sort_small(const int64_t* ptr, int32_t* 
         for (int64_t k = lane; k < len; k += 64) {
             const K key = keys[k];
             col[p0 + k] = (int32_t)(key >> POS_BITS);
-            perm[p0 + k] = p0 + (int64_t)(key & POS_MASK);
+            vout[p0 + k] = vin[p0 + (int64_t)(key & POS_MASK)];
         }
         __syncthreads();
     }
 }
 
 // rows with SORT_SMALL_MAX < len <= SORT_BLOCK_MAX: row list given explicitly
+template <typename V>
 __global__ void __launch_bounds__(256) k_sort_block(const int64_t* ptr, int32_t* col, const int64_t* row_list,
-                                                    int64_t* perm)
+                                                    const V* __restrict__ vin, V* __restrict__ vout)
 {
     __shared__ uint64_t keys[SORT_BLOCK_MAX];
     const int64_t row = row_list[blockIdx.x];
@@ -208,14 +216,16 @@ __global__ void __launch_bounds__(256) k_sort_block(const int64_t* ptr, int32_t*
     for (int64_t k = threadIdx.x; k < len; k += 256) {
         const uint64_t key = keys[k];
         col[p0 + k] = (int32_t)(key >> 32);
-        perm[p0 + k] = p0 + (int64_t)(key & 0xffffffffull);
+        vout[p0 + k] = vin[p0 + (int64_t)(key & 0xffffffffull)];
     }
 }
 
 // rows longer than SORT_BLOCK_MAX: keys live in a global scratch slab (pow2-padded), one
 // 1024-thread block per row.  Rare (hub rows of power-law matrices).
+template <typename V>
 __global__ void __launch_bounds__(1024) k_sort_global(const int64_t* ptr, int32_t* col, const int64_t* row_list,
-                                                      const int64_t* slab_off, uint64_t* slabs, int64_t* perm)
+                                                      const int64_t* slab_off, uint64_t* slabs,
+                                                      const V* __restrict__ vin, V* __restrict__ vout)
 {
     const int64_t row = row_list[blockIdx.x];
     uint64_t* keys = slabs + slab_off[blockIdx.x];
@@ -230,7 +240,7 @@ __global__ void __launch_bounds__(1024) k_sort_global(const int64_t* ptr, int32_
     for (int64_t k = threadIdx.x; k < len; k += 1024) {
         const uint64_t key = keys[k];
         col[p0 + k] = (int32_t)(key >> 32);
-        perm[p0 + k] = p0 + (int64_t)(key & 0xffffffffull);
+        vout[p0 + k] = vin[p0 + (int64_t)(key & 0xffffffffull)];
     }
 }
 
@@ -241,10 +251,11 @@ __global__ void __launch_bounds__(1024) k_sort_global(const int64_t* ptr, int32_
 // have one) is handed to the comparison sort instead.
 constexpr int SORT_BITMAP_GROUP = 8;  // words per stored popcount prefix
 
+template <typename V>
 __global__ void __launch_bounds__(1024)
     k_sort_bitmap(const int64_t* __restrict__ ptr, int32_t* col, const int64_t* __restrict__ big_rows, int64_t n_big,
-                  int64_t ncols, int64_t* __restrict__ perm, unsigned long long* n_fallback, int64_t* fallback_rows,
-                  unsigned long long* work_counter)
+                  int64_t ncols, const V* __restrict__ vin, V* __restrict__ vout, unsigned long long* n_fallback,
+                  int64_t* fallback_rows, unsigned long long* work_counter)
 {
     MI_DYN_SMEM(smem);
     const int64_t words = (ncols + 31) / 32;
@@ -307,7 +318,7 @@ __global__ void __launch_bounds__(1024)
             const int64_t w = c >> 5, g = w / SORT_BITMAP_GROUP;
             int r = gpre[g] + __popc(bits[w] & ((1u << (c & 31)) - 1u));
             for (int64_t ww = g * SORT_BITMAP_GROUP; ww < w; ++ww) r += __popc(bits[ww]);
-            perm[p0 + r] = p0 + k;
+            vout[p0 + r] = vin[p0 + k];
         }
         __syncthreads();  // every column has been read: rewrite them in order from the bitmap
         for (int64_t g = tid; g < groups; g += threads) {
@@ -349,12 +360,6 @@ __global__ void k_big_row_sizes(const int64_t* ptr, const int64_t* rows_list, in
     int64_t p2 = 2;
     while (p2 < len) p2 <<= 1;
     sizes[i] = p2;
-}
-
-template <typename T>
-__global__ void k_gather_vals(const T* in, const int64_t* perm, int64_t nnz, T* out)
-{
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[perm[i]];
 }
 
 // ================================================================================================
@@ -407,8 +412,19 @@ void sort_csr(char vtype, Csr& a)
         return;
     }
     Context& c = ctx();
-    // the arrays are about to be rewritten: if they alias caller HBM, that is what "order" means
-    int64_t* perm = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)a.nnz));
+    // the arrays are about to be rewritten: if they alias caller HBM, that is what "order" means.  Values go
+    // into a fresh block that replaces the old one when the library owns the storage (results of spmm / syrk /
+    // transposes), through a temporary and back when they alias caller HBM.
+    const size_t vb = value_bytes(vtype);
+    const bool owned = a.val_own.p && a.val == a.val_own.p;
+    DevBuf fresh;
+    void* vout_raw;
+    if (owned) {
+        fresh.alloc(vb * (size_t)a.nnz);
+        vout_raw = fresh.p;
+    } else {
+        vout_raw = c.scratch_alloc(vb * (size_t)a.nnz);
+    }
     int64_t* counters = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * 2));
     MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 2, c.stream));
     // rows too long for one wave: counting sort through an LDS column bitmap when the matrix is narrow enough
@@ -424,36 +440,40 @@ void sort_csr(char vtype, Csr& a)
     MI_HIP_CHECK(hipStreamSynchronize(c.stream));
     const int64_t n_med = hc[0];
     int64_t n_big = hc[1];
-
-    if (a.cols < ((int64_t)1 << 23))
-        MI_LAUNCH((k_sort_small<uint32_t>), grid1d(a.rows, SORT_ROWS_PER_SMALL_BLOCK), dim3(64), c.stream,
-                  (const int64_t*)a.ptr, a.col, a.rows, perm);
-    else
-        MI_LAUNCH((k_sort_small<uint64_t>), grid1d(a.rows, SORT_ROWS_PER_SMALL_BLOCK), dim3(64), c.stream,
-                  (const int64_t*)a.ptr, a.col, a.rows, perm);
+    int64_t* med_rows = nullptr;
+    int64_t* big_rows = nullptr;
     if (n_med || n_big) {
-        int64_t* med_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_med + 1)));
-        int64_t* big_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
+        med_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_med + 1)));
+        big_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
         MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 2, c.stream));
         MI_LAUNCH(k_sort_classify, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, big_thr,
                   counters, med_rows, counters + 1, big_rows);
+    }
+    auto run = [&](auto word) {
+        using V = decltype(word);
+        const V* vin = static_cast<const V*>(a.val);
+        V* vout = static_cast<V*>(vout_raw);
+        if (a.cols < ((int64_t)1 << 23))
+            MI_LAUNCH((k_sort_small<uint32_t, V>), grid1d(a.rows, SORT_ROWS_PER_SMALL_BLOCK), dim3(64), c.stream,
+                      (const int64_t*)a.ptr, a.col, a.rows, vin, vout);
+        else
+            MI_LAUNCH((k_sort_small<uint64_t, V>), grid1d(a.rows, SORT_ROWS_PER_SMALL_BLOCK), dim3(64), c.stream,
+                      (const int64_t*)a.ptr, a.col, a.rows, vin, vout);
         if (n_med)
-            MI_LAUNCH(k_sort_block, dim3((unsigned)n_med), dim3(256), c.stream, (const int64_t*)a.ptr, a.col,
-                      (const int64_t*)med_rows, perm);
-        if (n_big) {
-            if (use_bitmap) {  // rows the counting sort refuses (repeated column) go to the HBM comparison sort
-                unsigned long long* cnt2 = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * 2));
-                int64_t* fallback = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
-                MI_HIP_CHECK(hipMemsetAsync(cnt2, 0, sizeof(unsigned long long) * 2, c.stream));
-                MI_LAUNCH_SMEM(k_sort_bitmap, dim3((unsigned)(n_big < 512 ? n_big : 512)), dim3(1024), bitmap_bytes, c.stream,
-                               (const int64_t*)a.ptr, a.col, (const int64_t*)big_rows, n_big, a.cols, perm, cnt2, fallback,
-                               cnt2 + 1);
-                unsigned long long nf = 0;
-                MI_HIP_CHECK(hipMemcpyAsync(&nf, cnt2, sizeof(nf), hipMemcpyDeviceToHost, c.stream));
-                MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-                n_big = (int64_t)nf;
-                big_rows = fallback;
-            }
+            MI_LAUNCH((k_sort_block<V>), dim3((unsigned)n_med), dim3(256), c.stream, (const int64_t*)a.ptr, a.col,
+                      (const int64_t*)med_rows, vin, vout);
+        if (n_big && use_bitmap) {  // rows the counting sort refuses (repeated column) go to the HBM comparison sort
+            unsigned long long* cnt2 = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * 2));
+            int64_t* fallback = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
+            MI_HIP_CHECK(hipMemsetAsync(cnt2, 0, sizeof(unsigned long long) * 2, c.stream));
+            MI_LAUNCH_SMEM((k_sort_bitmap<V>), dim3((unsigned)(n_big < 512 ? n_big : 512)), dim3(1024), bitmap_bytes, c.stream,
+                           (const int64_t*)a.ptr, a.col, (const int64_t*)big_rows, n_big, a.cols, vin, vout, cnt2, fallback,
+                           cnt2 + 1);
+            unsigned long long nf = 0;
+            MI_HIP_CHECK(hipMemcpyAsync(&nf, cnt2, sizeof(nf), hipMemcpyDeviceToHost, c.stream));
+            MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+            n_big = (int64_t)nf;
+            big_rows = fallback;
         }
         if (n_big) {
             // slab sizes (pow2-padded row lengths) and their offsets, computed on the device
@@ -463,33 +483,19 @@ void sort_csr(char vtype, Csr& a)
                       (const int64_t*)big_rows, n_big, sizes);
             const int64_t total = exclusive_scan_i64(sizes, doff, n_big);
             uint64_t* slabs = static_cast<uint64_t*>(c.scratch_alloc(sizeof(uint64_t) * (size_t)total));
-            MI_LAUNCH(k_sort_global, dim3((unsigned)n_big), dim3(1024), c.stream, (const int64_t*)a.ptr, a.col,
-                      (const int64_t*)big_rows, (const int64_t*)doff, slabs, perm);
+            MI_LAUNCH((k_sort_global<V>), dim3((unsigned)n_big), dim3(1024), c.stream, (const int64_t*)a.ptr, a.col,
+                      (const int64_t*)big_rows, (const int64_t*)doff, slabs, vin, vout);
         }
-    }
-    // permute the values: into a fresh block that replaces the old one when the library owns the storage
-    // (results of spmm / syrk / transposes), through a temporary and back when the values alias caller HBM
-    const size_t vb = value_bytes(vtype);
-    const bool owned = a.val_own.p && a.val == a.val_own.p;
-    DevBuf fresh;
-    void* tmp;
-    if (owned) {
-        fresh.alloc(vb * (size_t)a.nnz);
-        tmp = fresh.p;
-    } else {
-        tmp = c.scratch_alloc(vb * (size_t)a.nnz);
-    }
-    by_type(vtype, [&](auto tag) {
-        using T = decltype(tag);
-        MI_LAUNCH((k_gather_vals<T>), grid1d_stride(a.nnz, 256), dim3(256), c.stream, (const T*)a.val,
-                  (const int64_t*)perm, a.nnz, (T*)tmp);
-    });
+    };
+    if (vb == 4) run(uint32_t{});
+    else if (vb == 8) run(uint64_t{});
+    else run(Word16{});
     if (owned) {
         MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // the old block goes back to the cache: nothing may still read it
         a.val_own = std::move(fresh);
         a.val = a.val_own.p;
     } else {
-        MI_HIP_CHECK(hipMemcpyAsync(a.val, tmp, vb * (size_t)a.nnz, hipMemcpyDeviceToDevice, c.stream));
+        MI_HIP_CHECK(hipMemcpyAsync(a.val, vout_raw, vb * (size_t)a.nnz, hipMemcpyDeviceToDevice, c.stream));
     }
     a.sorted = true;
 }
