@@ -343,6 +343,7 @@ struct Options {
     int64_t spmm_force_generic = 0;
     int64_t spmm_unroll = 4;       // 4 or 8 independent B-row loads in flight per lane
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
+    int64_t spmm_slices = 1;       // XCD-affine column slices of the dense operand (1, 2, 4, 8)
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)

@@ -456,6 +456,10 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
         } else if (!strcmp(name, "spmm_hot_kb")) {
             if (value < 0) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_hot_kb must be >= 0");
             o.spmm_hot_kb = value;
+        } else if (!strcmp(name, "spmm_slices")) {
+            if (value != 1 && value != 2 && value != 4 && value != 8)
+                mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_slices must be 1, 2, 4 or 8");
+            o.spmm_slices = value;
         } else if (!strcmp(name, "spmm_hot_force")) {
             o.spmm_hot_force = value;
         } else if (!strcmp(name, "spmm_force_generic")) {

@@ -125,13 +125,27 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
            const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
            const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
-           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val)
+           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices)
 {
     MI_DYN_SMEM(smem);
     constexpr int NG = WAVE / LPN;  // lane groups per wave, each on its own nonzero
     const int wave_in_block = threadIdx.x / WAVE;
     const int lane = threadIdx.x % WAVE;
-    const int64_t w = (int64_t)blockIdx.x * SPMM_WAVES + wave_in_block;
+    // XCD-affine column slicing: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed
+    // only -- any placement is correct).  With S slices the XCDs are split into S sets, set s only ever
+    // touches dense columns [s * N / S, (s + 1) * N / S): its L2 holds N / S values per row of B instead of
+    // N, i.e. S times more hot rows.  Each chunk of A is then processed once per slice.
+    int64_t cb = blockIdx.x;
+    int64_t jlo = 0, jhi = N;
+    if (slices > 1) {  // slices in {2, 4, 8}
+        const int xcd = (int)(blockIdx.x & 7u);
+        const int per = 8 / slices;  // XCDs per slice
+        cb = (int64_t)(blockIdx.x >> 3) * per + (xcd % per);
+        const int64_t ns = N / slices;
+        jlo = (xcd / per) * ns;
+        jhi = jlo + ns;
+    }
+    const int64_t w = cb * SPMM_WAVES + wave_in_block;
     const bool active = w < nchunks;
 
     // carve this wave's LDS: staged nonzeros first (largest alignment), then the row ends
@@ -206,11 +220,11 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     if constexpr (TAG) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
 #endif
 
-    for (int64_t j0 = 0; j0 < N; j0 += (int64_t)LPN * V) {
+    for (int64_t j0 = jlo; j0 < jhi; j0 += (int64_t)LPN * V) {
         const int64_t jc = j0 + (int64_t)li * V;  // first column of this lane
-        const bool col_ok = jc < N;               // V divides N on the vector path
+        const bool col_ok = jc < jhi;             // V divides N on the vector path
         // idle lanes (jc >= N) still issue loads, from column 0: keeps the loop free of divergence
-        const T* bcol = B + (col_ok ? jc : 0) * b_cs;
+        const T* bcol = B + (col_ok ? jc : jlo) * b_cs;
         int begin = 0;
         for (int k = 0; k < nproc; ++k) {
             const int end = s_end[k];
@@ -229,11 +243,14 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    // narrow rows of B (many lane groups): idle groups issue no load at all; wide rows: the
+                    // clamped entry is re-read (an L1 hit) and the loop stays free of divergence
+                    if (NG >= 8 && !ok[u]) continue;
                     if constexpr (TAG) {
                         const int32_t cidx = nz[u].c & 0x7fffffff;
 #ifndef MI_HIP_EMU
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        const unsigned voff = (unsigned)(((int64_t)cidx * b_rs + (col_ok ? jc : 0)) * (int64_t)sizeof(T));
+                        const unsigned voff = (unsigned)(((int64_t)cidx * b_rs + (col_ok ? jc : jlo)) * (int64_t)sizeof(T));
                         u32x4 r;
                         if (nz[u].c < 0) r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 2);  // nt
                         else r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 0);
@@ -637,43 +654,45 @@ static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, in
 template <typename T, int V, int LPN, int U>
 static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
                           int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
-                          bool use_tags)
+                          bool use_tags, int slices)
 {
     Context& c = ctx();
     const size_t per_wave = (spmm_wave_lds<T>(p.chunk) + 15) & ~size_t(15);
     const size_t lds = per_wave * SPMM_WAVES;
-    const unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
+    unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
+    if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
-    if constexpr (V * sizeof(T) == 16 && LPN >= 32) {
+    if constexpr (V * sizeof(T) == 16) {
         if (use_tags) {
             MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, true>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows,
                            m.nnz, (const int64_t*)m.ptr, (const int32_t*)p.col_tagged.as<int32_t>(), (const T*)m.val,
                            (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C,
-                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_val);
+                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_val, slices);
             return;
         }
     }
     MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, false>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz,
                    (const int64_t*)m.ptr, (const int32_t*)m.col, (const T*)m.val,
                    (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,
-                   c_cs, N, alpha, beta, beta_zero, carry_val);
+                   c_cs, N, alpha, beta, beta_zero, carry_val, slices);
 }
 
 template <typename T, int V, int LPN>
 static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
                         int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
-                        bool use_tags)
+                        bool use_tags, int slices)
 {
     // U = independent 16-byte loads in flight per lane.  The deeper variant exists for the 512-byte
     // row shapes of the headline configs only (keeps the instantiation count down).
     if constexpr (V > 1 && LPN >= 32) {
         if (options().spmm_unroll == 8) {
             launch_spmm_u<T, V, LPN, 8>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val,
-                                        use_tags);
+                                        use_tags, slices);
             return;
         }
     }
-    launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, use_tags);
+    launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, use_tags,
+                                slices);
 }
 
 static inline bool dense_bytes_below_4g(int64_t rows, int64_t ld, size_t elem)
@@ -703,17 +722,26 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         convert_layout<T>(m.rows, N, ct, ldt, 1, C, 1, ldc);
         return;
     }
+    // XCD-affine column slices (k_spmm): each set of XCDs works on N / S dense columns only
+    constexpr int V16 = 16 / (int)sizeof(T);
+    int slices = 1;
+    {
+        const int64_t want = options().spmm_slices;
+        if (layout == MI_SPARSE_LAYOUT_ROW_MAJOR && (want == 2 || want == 4 || want == 8) && N % want == 0 &&
+            (N / want) % V16 == 0 && (N / want) * (int64_t)sizeof(T) >= 64)
+            slices = (int)want;
+    }
+    const int64_t slice_bytes = N / slices * (int64_t)sizeof(T);  // bytes of one B row one XCD's L2 sees
     // hot-set budget in rows of B for this call's row width (row-major operands only)
     int64_t hot_rows = 0;
     if (layout == MI_SPARSE_LAYOUT_ROW_MAJOR && options().spmm_hot_kb > 0 &&
         (N * (int64_t)sizeof(T) >= 512 || options().spmm_hot_force))
-        hot_rows = options().spmm_hot_kb * 1024 / (N * (int64_t)sizeof(T));
+        hot_rows = options().spmm_hot_kb * 1024 / slice_bytes;
     const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk, hot_rows);
     T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)p.nchunks * (size_t)N));
     const bool row_major = (layout == MI_SPARSE_LAYOUT_ROW_MAJOR);
     const int64_t b_rs = row_major ? ldb : 1, b_cs = row_major ? 1 : ldb;
     const int64_t c_rs = row_major ? ldc : 1, c_cs = row_major ? 1 : ldc;
-    constexpr int V16 = 16 / (int)sizeof(T);
     const bool vec_ok = row_major && !options().spmm_force_generic && (N % V16 == 0) &&
                         ((ldb * (int64_t)sizeof(T)) % 16 == 0) && ((ldc * (int64_t)sizeof(T)) % 16 == 0) &&
                         ((reinterpret_cast<uintptr_t>(B) % 16) == 0) && ((reinterpret_cast<uintptr_t>(C) % 16) == 0) &&
@@ -735,7 +763,8 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     const bool use_tags = p.tagged && vec_ok && dense_bytes_below_4g(m.cols, ldb, sizeof(T));
     counters().spmm_last_tagged = use_tags ? 1.0 : 0.0;
     counters().spmm_hot_coverage = p.hot_coverage;
-#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, use_tags
+    if (!vec_ok) slices = 1;
+#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, use_tags, slices
 #ifndef MI_HIP_EMU
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool prof = options().profile_events != 0;
@@ -746,11 +775,12 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     }
 #endif
     if (vec_ok) {
-        const int64_t lanes = N / V16;  // 16-byte lanes needed for one row of B
+        const int64_t lanes = N / slices / V16;  // 16-byte lanes needed for one (slice of a) row of B
         if (lanes >= 64) launch_spmm<T, V16, 64>(MI_SPMM_ARGS);
         else if (lanes > 16) launch_spmm<T, V16, 32>(MI_SPMM_ARGS);
         else if (lanes > 8) launch_spmm<T, V16, 16>(MI_SPMM_ARGS);
-        else launch_spmm<T, V16, 8>(MI_SPMM_ARGS);
+        else if (lanes > 4 || slices == 1) launch_spmm<T, V16, 8>(MI_SPMM_ARGS);
+        else launch_spmm<T, V16, 4>(MI_SPMM_ARGS);
     } else {
         if (N > 16) launch_spmm<T, 1, 64>(MI_SPMM_ARGS);
         else if (N > 4) launch_spmm<T, 1, 16>(MI_SPMM_ARGS);
