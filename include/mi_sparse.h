@@ -370,10 +370,15 @@ mi_sparse_status_t mi_cblas_dsyrk(int layout, int uplo, int trans, int64_t n, in
 mi_sparse_status_t mi_sparse_get_version_string(char *buf, int len);
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int mi_sparse_get_device_count(void);
-/* Select the device used by the calling host thread for subsequent calls. */
+/* Select the device used by the calling host thread for subsequent calls.  A thread that never
+ * calls this works on the HIP device that is current on it at its first library call. */
 mi_sparse_status_t mi_sparse_set_device(int device);
+/* Device the calling thread's library context is bound to (-1: not bound yet). */
+int mi_sparse_get_device(void);
 /* Stream (a hipStream_t passed as void*) on which the calling thread's work is enqueued. */
 mi_sparse_status_t mi_sparse_set_stream(void *hip_stream);
+/* The stream set by mi_sparse_set_stream (NULL = the default stream), so that a caller can restore it. */
+mi_sparse_status_t mi_sparse_get_stream(void **hip_stream);
 /* Block until everything enqueued by the calling thread's stream has finished. */
 mi_sparse_status_t mi_sparse_synchronize(void);
 /* Reason for the calling thread's most recent non-zero status ("" if none). */

@@ -33,6 +33,18 @@ def mi_set_device(device):
     _check_return_value(MI.call("mi_sparse_set_device", int(device)), "mi_sparse_set_device")
 
 
+def mi_get_device():
+    """Device this thread's library context is bound to (-1 before the first device call)."""
+    return int(MI.call("mi_sparse_get_device"))
+
+
+def mi_get_stream():
+    """The hipStream_t (as an int, 0 = default stream) this thread's work is enqueued on."""
+    p = _ct.c_void_p()
+    _check_return_value(MI.call("mi_sparse_get_stream", _ct.byref(p)), "mi_sparse_get_stream")
+    return p.value or 0
+
+
 def mi_set_stream(stream_ptr):
     """Enqueue this thread's work on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
     _check_return_value(MI.call("mi_sparse_set_stream", _ct.c_void_p(stream_ptr or 0)), "mi_sparse_set_stream")

@@ -137,7 +137,9 @@ def _bind(lib):
     add("mi_sparse_get_version_string", [_ct.c_char_p, _int])
     add("mi_sparse_get_device_count", [], _int)
     add("mi_sparse_set_device", [_int])
+    add("mi_sparse_get_device", [], _int)
     add("mi_sparse_set_stream", [_vp])
+    add("mi_sparse_get_stream", [_ct.POINTER(_vp)])
     add("mi_sparse_synchronize", [])
     add("mi_sparse_last_error", [], _ct.c_char_p)
     add("mi_sparse_set_option", [_ct.c_char_p, _i64])

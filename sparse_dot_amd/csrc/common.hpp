@@ -38,6 +38,7 @@ inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t sme
 #else
     // HIP runs at most 2^32 - 1 threads per grid dimension and silently drops the rest
     if ((unsigned long long)grid.x * block.x >= (1ull << 32)) launch_too_large((unsigned long long)grid.x * block.x);
+    if (grid.y > 65535u || grid.z > 65535u) launch_too_large((unsigned long long)(grid.y > grid.z ? grid.y : grid.z));
     kernel<<<grid, block, smem, stream>>>(static_cast<KArgs>(args)...);
 #endif
 }
@@ -225,7 +226,7 @@ void pool_reset_cap();  // re-read pool_max_mb on the next release
 
 struct Context {
     bool initialised = false;
-    int device = 0;
+    int device = -1;  // -1: adopt the calling thread's current HIP device at first use (mi_sparse_set_device overrides)
     hipStream_t stream = nullptr;
     // grow-only scratch arena; kernels on one stream execute in order, so a later call may reuse
     // the arena as soon as it is enqueued behind the earlier one

@@ -828,8 +828,8 @@ __global__ void k_export_ptr(const int64_t* in, int64_t n, I* out)
 template <typename I>
 __global__ void k_export_col(const int32_t* in, int64_t n, I* out)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (I)in[i];
+    // grid-stride: grid1d_stride() caps the grid, results past 2^28 entries (SpGEMM outputs) still need every index
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (I)in[i];
 }
 
 template <typename I, typename T>

@@ -91,6 +91,13 @@ void DevBuf::alloc(size_t n)
     c.ensure();
     const size_t want = pool_round(n ? n : 16);
     const int d = c.device;
+    {
+        int cur = d;
+        if (hipGetDevice(&cur) == hipSuccess && cur != d)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE,
+                 "the calling thread's current HIP device is %d but its mi_sparse context is bound to device %d; "
+                 "call mi_sparse_set_device(%d) after switching devices", cur, d, cur);
+    }
     BlockPool& bp = pool();
     if (d >= 0 && d < POOL_MAX_DEVICES) {
         std::lock_guard<std::mutex> lk(bp.m);
@@ -177,6 +184,13 @@ void Context::ensure()
         fail(MI_SPARSE_STATUS_EXECUTION_FAILED,
              "no HIP device available (%s); libmi_sparse has no CPU path",
              e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    if (device < 0) {
+        // no mi_sparse_set_device on this thread: work on whatever device the caller made current (torch.cuda.set_device,
+        // hipSetDevice, ROCR_VISIBLE_DEVICES ...) instead of silently moving the thread to device 0
+        int cur = 0;
+        MI_HIP_CHECK(hipGetDevice(&cur));
+        device = cur;
     }
     if (device >= n) fail(MI_SPARSE_STATUS_INVALID_VALUE, "device %d out of range (%d devices)", device, n);
     MI_HIP_CHECK(hipSetDevice(device));
@@ -383,6 +397,7 @@ mi_sparse_status_t mi_sparse_get_version_string(char* buf, int len)
         if (hipGetDeviceCount(&n) == hipSuccess && n > 0) {
             hipDeviceProp_t prop;
             int d = mi::ctx().device;
+            if (d < 0 && hipGetDevice(&d) != hipSuccess) d = 0;
             if (hipGetDeviceProperties(&prop, d) == hipSuccess)
                 snprintf(dev, sizeof(dev), "%d device(s); device %d: %s (%s, %d CUs, %.0f GiB)", n, d, prop.name,
                          prop.gcnArchName, prop.multiProcessorCount,
@@ -431,6 +446,16 @@ mi_sparse_status_t mi_sparse_set_stream(void* hip_stream)
         hipStream_t s = static_cast<hipStream_t>(hip_stream);
         if (c.initialised && s != c.stream) c.sync();  // the scratch arena is ordered by ONE stream
         c.stream = s;
+    });
+}
+
+int mi_sparse_get_device(void) { return mi::ctx().initialised ? mi::ctx().device : -1; }
+
+mi_sparse_status_t mi_sparse_get_stream(void** hip_stream)
+{
+    return mi::guarded([&] {
+        if (!hip_stream) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL stream pointer");
+        *hip_stream = static_cast<void*>(mi::ctx().stream);
     });
 }
 
