@@ -1,11 +1,13 @@
 """
-Minimal ctypes binding of Intel MKL's mkl_sparse_?_mm, used ONLY by bench.py's `cpu_baseline`
-leg to time the arithmetic engine the reference itself calls, on the GPU box's host cores.
+Minimal ctypes binding of Intel MKL's mkl_sparse_?_mm / mkl_sparse_spmm / mkl_sparse_?_syrkd, used ONLY
+by bench.py's `cpu_baseline` legs to time the arithmetic engine the reference itself calls, on the GPU
+box's host cores.
 
 TEST / MEASUREMENT INFRASTRUCTURE -- never imported by the product package.  This is the build's
 own shim (the reference's Python does not travel to the GPU box); it binds the three symbols the
 reference's SpMM path uses (reference sparse_dot_mkl/_sparse_dense.py:111-123,
-_mkl_interface/_common.py:310-319, 671-680).  LP64 (32-bit index) interface.
+_mkl_interface/_common.py:310-319, 671-680), plus mkl_sparse_spmm (_sparse_sparse.py:35-40),
+mkl_sparse_?_syrkd (_gram_matrix.py:149-157) and MKL_Set_Num_Threads.  LP64 (32-bit index) interface.
 """
 import ctypes as _ct
 import ctypes.util as _ctu
@@ -90,3 +92,34 @@ class MklSpmm:
 
     def destroy(self, handle):
         self.lib.mkl_sparse_destroy(handle[0])
+
+    def set_threads(self, n):
+        """MKL_Set_Num_Threads (reference _mkl_interface/__init__.py:62-77); returns the resulting maximum."""
+        self.lib.MKL_Set_Num_Threads(_ct.c_int(int(n)))
+        return self.threads()
+
+    def spmm(self, ha, hb):
+        """C := A @ B, both sparse: mkl_sparse_spmm, then the handle is destroyed (the multiply is what is timed;
+        the reference's export adds Python-side copies on top).  Returns nothing."""
+        c = _ct.c_void_p()
+        self.lib.mkl_sparse_spmm.restype = _ct.c_int
+        st = self.lib.mkl_sparse_spmm(_ct.c_int(10), ha[0], hb[0], _ct.byref(c))
+        if st:
+            raise RuntimeError("mkl_sparse_spmm returned %d" % st)
+        self.lib.mkl_sparse_destroy(c)
+
+    def syrkd(self, handle, out):
+        """out(upper triangle) := A^T A, dense row-major: mkl_sparse_?_syrkd(op = 11)."""
+        h, letter, _keep = handle
+        fn = getattr(self.lib, "mkl_sparse_%s_syrkd" % letter)
+        ct = _ct.c_float if letter == "s" else _ct.c_double
+        fn.restype = _ct.c_int
+        fn.argtypes = [_ct.c_int, _ct.c_void_p, ct, ct, _ct.c_void_p, _ct.c_int, _ct.c_int]
+        st = fn(11, h, 1.0, 0.0, out.ctypes.data, 101, out.shape[1])
+        if st:
+            raise RuntimeError("mkl_sparse_%s_syrkd returned %d" % (letter, st))
+        return out
+
+    def order(self, handle):
+        self.lib.mkl_sparse_order.restype = _ct.c_int
+        return self.lib.mkl_sparse_order(handle[0])

@@ -7,7 +7,7 @@ import ctypes as _ct
 import numpy as _np
 
 from ._mi_interface import (MI, CBLAS_NO_TRANS, CBLAS_TRANS, LAYOUT_CODE_C, _check_return_value, _empty_output_check,
-                            _get_numpy_layout, _is_double, _mi_scalar, _out_matrix, _output_dtypes, _sanity_check,
+                            _get_numpy_layout, _is_double, _mi_beta, _mi_scalar, _out_matrix, _output_dtypes, _sanity_check,
                             _type_check, _type_letters, debug_print)
 
 
@@ -23,8 +23,8 @@ def _dense_matmul(matrix_a, matrix_b, scalar=1.0, out=None, out_scalar=None):
     # the call runs in A's layout; a B stored the other way round is the transpose of a matrix in A's layout
     op_b = CBLAS_NO_TRANS if layout_b == layout_a else CBLAS_TRANS
     order, ld_out = ("C", n) if layout_a == LAYOUT_CODE_C else ("F", m)
-    output_arr = _out_matrix((m, n), _output_dtypes[(dbl, cplx)], order=order, out_arr=out)
-    alpha, beta = _mi_scalar(scalar, cplx, dbl), _mi_scalar(out_scalar, cplx, dbl)
+    output_arr = _out_matrix((m, n), _output_dtypes[(dbl, cplx)], order=order, out_arr=out, overwritten=True)
+    alpha, beta = _mi_scalar(scalar, cplx, dbl), _mi_beta(out, out_scalar, cplx, dbl)
     if cplx:  # CBLAS convention: complex scalars by pointer
         alpha, beta = _ct.byref(alpha), _ct.byref(beta)
     name = "mi_cblas_%sgemm" % _type_letters[(dbl, cplx)]

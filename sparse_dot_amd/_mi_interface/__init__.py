@@ -9,7 +9,7 @@ from ._library import MI, matrix_descr, sparse_matrix_t, mi_library_name, Comple
 from ._checks import (  # noqa: F401
     set_debug_mode, print_mi_debug, debug_print, debug_timer, is_csr, is_csc, is_bsr,
     _is_allowed_sparse_format, sparse_output_type, _is_dense_vector, _is_double, _sanity_check,
-    _empty_output_check, _type_check, _cast_to, _mi_scalar, _get_numpy_layout, _out_matrix,
+    _empty_output_check, _type_check, _cast_to, _mi_scalar, _mi_beta, _get_numpy_layout, _out_matrix,
     _check_return_value, _output_dtypes, _type_letters, NUMPY_FLOAT_DTYPES, NUMPY_COMPLEX_DTYPES,
 )
 from ._handles import (  # noqa: F401

@@ -191,6 +191,13 @@ def _mi_scalar(scalar, complex_type, double_precision):
     return float(scalar)
 
 
+def _mi_beta(out, out_scalar, complex_type, double_precision):
+    """beta of `alpha * op(A) @ B + beta * C`: with no user `out` there is nothing to accumulate into, so
+    beta = 0 -- the library then neither uploads nor reads C (on CPU MKL `1.0 * zeros` was free, reference
+    _common.py:869-882; here it would be a C-sized PCIe transfer and a read-modify-write per call)."""
+    return _mi_scalar(0.0 if out is None else out_scalar, complex_type, double_precision)
+
+
 # ---- dense layout / output array ----------------------------------------------------------------
 def _get_numpy_layout(numpy_arr, second_arr=None):
     """(layout code, leading dimension) of a contiguous 2-d array.  An array that is both C and F
@@ -215,11 +222,12 @@ def _describe(shape, dtype, order, contiguous=True):
     return "%s %s [%s_%s]" % (tuple(shape), name, order, "CONTIGUOUS" if contiguous else "NONCONTIGUOUS")
 
 
-def _out_matrix(shape, dtype, order="C", out_arr=None, out_t=False):
-    """Fresh zero output, or the user's `out` after checking shape / dtype / order / contiguity.
-    `out_t` says the caller handed us out.T, so the message is phrased in the caller's orientation."""
+def _out_matrix(shape, dtype, order="C", out_arr=None, out_t=False, overwritten=False):
+    """Fresh output, or the user's `out` after checking shape / dtype / order / contiguity.
+    `out_t` says the caller handed us out.T, so the message is phrased in the caller's orientation.
+    `overwritten`: the executor writes every element (beta = 0 products), so a fresh array need not be zeroed."""
     if out_arr is None:
-        return _np.zeros(shape, dtype=dtype, order=order)
+        return _np.empty(shape, dtype=dtype, order=order) if overwritten else _np.zeros(shape, dtype=dtype, order=order)
     shape = tuple(shape)
     order_ok = out_arr.flags["C_CONTIGUOUS" if order == "C" else "F_CONTIGUOUS"]
     contiguous = out_arr.flags["C_CONTIGUOUS"] or out_arr.flags["F_CONTIGUOUS"]

@@ -10,7 +10,7 @@ import numpy as _np
 from scipy import sparse as _sps
 
 from ._mi_interface import (MI, LAYOUT_CODE_C, LAYOUT_CODE_F, DeviceMatrix, SparseHandle, _check_return_value,
-                            _empty_output_check, _get_numpy_layout, _is_double, _mi_scalar, _out_matrix,
+                            _empty_output_check, _get_numpy_layout, _is_double, _mi_beta, _mi_scalar, _out_matrix,
                             _output_dtypes, _sanity_check, _type_check, _type_letters, debug_print, matrix_descr)
 
 
@@ -23,13 +23,13 @@ def _sparse_dense_matmul(matrix_a, matrix_b, scalar=1.0, transpose=False, out=No
     out_shape = (out_rows, matrix_b.shape[1])
     layout_b, ld_b = _get_numpy_layout(matrix_b, second_arr=out)
     order = "C" if layout_b == LAYOUT_CODE_C else "F"
-    output_arr = _out_matrix(out_shape, _output_dtypes[(dbl, cplx)], order, out_arr=out, out_t=out_t)
+    output_arr = _out_matrix(out_shape, _output_dtypes[(dbl, cplx)], order, out_arr=out, out_t=out_t, overwritten=True)
     _, ld_out = _get_numpy_layout(output_arr, second_arr=matrix_b)
     name = "mi_sparse_%s_mm" % _type_letters[(dbl, cplx)]
 
     def run(handle):
         ret = MI.call(name, 11 if transpose else 10, _mi_scalar(scalar, cplx, dbl), handle.ptr, matrix_descr(),
-                      layout_b, matrix_b.ctypes.data, out_shape[1], ld_b, _mi_scalar(out_scalar, cplx, dbl),
+                      layout_b, matrix_b.ctypes.data, out_shape[1], ld_b, _mi_beta(out, out_scalar, cplx, dbl),
                       output_arr.ctypes.data, ld_out)
         _check_return_value(ret, name)
 

@@ -9,7 +9,7 @@ for a 2-d one.
 import numpy as _np
 
 from ._mi_interface import (MI, SparseHandle, _check_return_value, _empty_output_check, _is_allowed_sparse_format,
-                            _is_dense_vector, _is_double, _mi_scalar, _out_matrix, _output_dtypes, _sanity_check,
+                            _is_dense_vector, _is_double, _mi_beta, _mi_scalar, _out_matrix, _output_dtypes, _sanity_check,
                             _type_check, _type_letters, matrix_descr)
 
 
@@ -23,11 +23,11 @@ def _sparse_dense_vector_mult(matrix_a, vector_b, scalar=1.0, transpose=False, o
 
     dbl, cplx = _is_double(matrix_a)
     flat_b = _np.ascontiguousarray(vector_b.ravel())
-    output_arr = _out_matrix(out_shape, _output_dtypes[(dbl, cplx)], out_arr=out, out_t=out_t)
+    output_arr = _out_matrix(out_shape, _output_dtypes[(dbl, cplx)], out_arr=out, out_t=out_t, overwritten=True)
     name = "mi_sparse_%s_mv" % _type_letters[(dbl, cplx)]
     with SparseHandle.from_scipy(matrix_a) as handle:
         ret = MI.call(name, 11 if transpose else 10, _mi_scalar(scalar, cplx, dbl), handle.ptr, matrix_descr(),
-                      flat_b.ctypes.data, _mi_scalar(out_scalar, cplx, dbl), output_arr.ctypes.data)
+                      flat_b.ctypes.data, _mi_beta(out, out_scalar, cplx, dbl), output_arr.ctypes.data)
         _check_return_value(ret, name)
     return output_arr
 

@@ -56,6 +56,17 @@ namespace mi {
 
 constexpr int WAVE = 64;
 
+// register-vector types of the buffer-load / MFMA builtins (the host emulation names its own)
+#ifdef MI_HIP_EMU
+using u32x4 = mi_u32x4;
+using f32x16 = mi_f32x16;
+using f64x4 = mi_f64x4;
+#else
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // complex value type (layout-compatible with mi_complex8 / mi_complex16 and numpy complex)
 // ------------------------------------------------------------------------------------------------
@@ -275,20 +286,54 @@ struct HostExport {  // library-owned host copies handed out by export_* (valid 
     std::vector<char> ptr, col, val;
 };
 
+// Small page-locked host block + event: results of device-side analysis come back with an asynchronous copy
+// and are looked at by a LATER call (hipEventQuery), so no executor ever waits for the inspector.
+struct AsyncWord {
+    int64_t* host = nullptr;  // 8 x int64, hipHostMalloc
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    AsyncWord() = default;
+    AsyncWord(const AsyncWord&) = delete;
+    AsyncWord& operator=(const AsyncWord&) = delete;
+    ~AsyncWord();
+    void ensure();             // allocate on first use
+    void post(const void* dev_src, size_t bytes, hipStream_t s);  // enqueue D2H + event
+    bool ready();              // true once a posted copy has landed (non-blocking)
+};
+
 struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.hip)
     int chunk = 0;
     int64_t nchunks = 0;
     DevBuf chunk_row;  // int32[nchunks + 1]
     // static fix-up schedule: one task per long row that is cut across chunks -- (row, first chunk,
-    // last chunk) whose carries are added, in chunk order, to the row its owner wrote
-    int64_t n_tasks = 0;
-    DevBuf tasks;  // int32[3 * n_tasks]
+    // last chunk) whose carries are added, in chunk order, to the row its owner wrote.  Built on the
+    // device in one pass; the count stays on the device (n_tasks_dev) and reaches the host
+    // asynchronously -- until then the fix-up kernel is launched for the upper bound (nchunks).
+    DevBuf tasks;        // int32[3 * nchunks]
+    DevBuf n_tasks_dev;  // unsigned long long
+    int64_t n_tasks = -1;  // -1: not known on the host yet
+    AsyncWord n_tasks_word;
     // hot / cold column tagging (see spmm.hip): copy of the column indices with bit 31 set on
-    // entries whose column is NOT in the hot set that is meant to stay L2 resident
-    int64_t hot_rows_budget = -1;  // the budget (in B rows) the tags were computed for; -1 = never
-    bool tagged = false;           // false: matrix has no useful hot set (or tagging disabled)
+    // entries whose column is NOT in the hot set that is meant to stay L2 resident.  The analysis
+    // (sampled column histogram -> threshold -> tags) runs on the device, enqueued behind the SECOND
+    // product of a handle (a single-use handle never pays for it) and is adopted by the first later
+    // call that finds its decision word landed.
+    int64_t uses = 0;              // products executed with this plan
+    int64_t hot_rows_budget = -1;  // the budget (in B rows) the analysis ran / is running for; -1 = never
+    int hot_state = 0;             // 0 none, 1 analysis enqueued, 2 decision known
+    bool tagged = false;           // decision: use the tagged gather
     double hot_coverage = 0.0;     // fraction of nonzeros that fall on hot columns
     DevBuf col_tagged;             // int32[nnz]
+    DevBuf hot_decision;           // int64[8] on the device: {flag, thr, nhot, covered, total}
+    AsyncWord hot_word;
+    void reset_hot()
+    {
+        hot_rows_budget = -1;
+        hot_state = 0;
+        tagged = false;
+        hot_coverage = 0.0;
+        col_tagged.release();
+    }
 };
 
 }  // namespace mi
@@ -344,7 +389,7 @@ struct Options {
     int64_t spmm_force_generic = 0;
     int64_t spmm_unroll = 4;       // 4 or 8 independent B-row loads in flight per lane
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
-    int64_t spmm_slices = 1;       // XCD-affine column slices of the dense operand (1, 2, 4, 8)
+    int64_t spmm_slices = 0;       // XCD-affine column slices of the dense operand: 0 = by row width (256-byte slices), else 1, 2, 4, 8
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)
@@ -356,12 +401,16 @@ struct Options {
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory
     int64_t trace_phases = 0;      // print host wall-clock per SpGEMM phase to stderr (diagnostics; synchronises)
     int64_t profile_events = 0;    // bracket the SpMM main kernel with hipEvents (diagnostics)
+    int64_t spmm_plan_sync = 0;    // 1: run the hot / cold analysis synchronously inside the first product (tests, A/B tools)
 };
 struct Counters {
     double spmm_kernel_ms = 0.0;
     double spmm_kernel_launches = 0.0;
     double spmm_last_tagged = 0.0;    // 1 when the last SpMM used the hot / cold tagged gather
     double spmm_hot_coverage = 0.0;   // share of nonzeros on hot columns in the last SpMM's plan
+    double spmm_last_slices = 1.0;    // column slices the last SpMM ran with
+    double spmm_plan_ms = 0.0;        // host wall time spent building plans (partition + fix-up schedule), accumulated
+    double spmm_plans_built = 0.0;
 };
 Counters& counters();  // per host thread
 Options& options();

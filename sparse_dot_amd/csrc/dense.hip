@@ -21,11 +21,6 @@ namespace mi {
 constexpr int GT = 64;  // output tile
 constexpr int GK = 16;  // K step
 
-#ifndef MI_HIP_EMU
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-#endif
-
 template <typename T>
 __device__ __forceinline__ bool tri_keep(int tri, int64_t i, int64_t j)
 {
@@ -48,15 +43,9 @@ __global__ void __launch_bounds__(256)
     const int wave = tid / WAVE, lane = tid % WAVE;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;  // quadrant origin inside the tile
 
-#ifndef MI_HIP_EMU
     constexpr bool is_f32 = std::is_same<T, float>::value;
     f32x16 acc32 = {0};
     f64x4 acc64[2][2] = {{{0}, {0}}, {{0}, {0}}};
-#else
-    T acc_emu[4][4];  // emulation: each thread owns a 4x4 patch of the 64x64 tile
-    for (int a = 0; a < 4; ++a)
-        for (int b = 0; b < 4; ++b) acc_emu[a][b] = T(0);
-#endif
 
     for (int64_t k0 = 0; k0 < K; k0 += GK) {
         // stage A tile (64 x 16) and B tile (16 x 64), zero padded
@@ -69,7 +58,6 @@ __global__ void __launch_bounds__(256)
             Bs[bk][bj] = (gk2 < K && gj < N) ? B[gk2 * b_rs + gj * b_cs] : T(0);
         }
         __syncthreads();
-#ifndef MI_HIP_EMU
         if constexpr (is_f32) {
 #pragma unroll
             for (int kk = 0; kk < GK; kk += 2) {
@@ -91,12 +79,6 @@ __global__ void __launch_bounds__(256)
                 }
             }
         }
-#else
-        for (int a = 0; a < 4; ++a)
-            for (int b = 0; b < 4; ++b)
-                for (int kk = 0; kk < GK; ++kk)
-                    acc_emu[a][b] += As[(tid / 16) * 4 + a][kk] * Bs[kk][(tid % 16) * 4 + b];
-#endif
         __syncthreads();
     }
 
@@ -106,7 +88,6 @@ __global__ void __launch_bounds__(256)
             *c = beta_zero ? alpha * v : alpha * v + beta * (*c);
         }
     };
-#ifndef MI_HIP_EMU
     if constexpr (is_f32) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -123,11 +104,6 @@ __global__ void __launch_bounds__(256)
                     store(i0 + wi + ti * 16 + (lane >> 4) + 4 * r, j0 + wj + tj * 16 + (lane & 15), acc64[ti][tj][r]);
     }
     (void)wave;
-#else
-    (void)wave; (void)lane; (void)wi; (void)wj;
-    for (int a = 0; a < 4; ++a)
-        for (int b = 0; b < 4; ++b) store(i0 + (tid / 16) * 4 + a, j0 + (tid % 16) * 4 + b, acc_emu[a][b]);
-#endif
 }
 
 // complex (and any) types: one thread per output element

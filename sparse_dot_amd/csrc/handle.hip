@@ -985,9 +985,7 @@ mi_sparse_status_t mi_sparse_order(mi_sparse_matrix_t A)
         // the SpMM plans cache a hot/cold-tagged COPY of the column indices in storage order: stale once the
         // entries have moved (the row partition itself depends only on the row pointer and stays valid)
         for (mi::SpmmPlan* p : {&h->plan, &h->planT}) {
-            p->hot_rows_budget = -1;
-            p->tagged = false;
-            p->col_tagged.release();
+            p->reset_hot();
         }
         // MKL orders the caller's arrays in place; mirror that for host-created handles
         if (!was_sorted && h->user_col && h->user_val && h->origin != 'b' && primary.nnz) {

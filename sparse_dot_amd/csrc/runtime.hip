@@ -165,6 +165,41 @@ direct:
     (void)hipFree(q);
 }
 
+// ---- asynchronous device -> host words ------------------------------------------------------------
+AsyncWord::~AsyncWord()
+{
+    if (ev) (void)hipEventDestroy(ev);
+    if (host) (void)hipHostFree(host);
+}
+
+void AsyncWord::ensure()
+{
+    if (host) return;
+    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host), 8 * sizeof(int64_t), hipHostMallocDefault));
+    memset(host, 0, 8 * sizeof(int64_t));
+    MI_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+}
+
+void AsyncWord::post(const void* dev_src, size_t bytes, hipStream_t s)
+{
+    ensure();
+    MI_HIP_CHECK(hipMemcpyAsync(host, dev_src, bytes, hipMemcpyDeviceToHost, s));
+    MI_HIP_CHECK(hipEventRecord(ev, s));
+    pending = true;
+}
+
+bool AsyncWord::ready()
+{
+    if (!pending) return false;
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) {
+        pending = false;
+        return true;
+    }
+    if (e != hipErrorNotReady) (void)hipGetLastError();
+    return false;
+}
+
 // ---- context -----------------------------------------------------------------------------------
 static thread_local Context* g_ctx = nullptr;
 
@@ -482,9 +517,11 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             if (value < 0) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_hot_kb must be >= 0");
             o.spmm_hot_kb = value;
         } else if (!strcmp(name, "spmm_slices")) {
-            if (value != 1 && value != 2 && value != 4 && value != 8)
-                mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_slices must be 1, 2, 4 or 8");
+            if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+                mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_slices must be 0 (automatic), 1, 2, 4 or 8");
             o.spmm_slices = value;
+        } else if (!strcmp(name, "spmm_plan_sync")) {
+            o.spmm_plan_sync = value;
         } else if (!strcmp(name, "spmm_hot_force")) {
             o.spmm_hot_force = value;
         } else if (!strcmp(name, "spmm_force_generic")) {
@@ -535,6 +572,9 @@ mi_sparse_status_t mi_sparse_get_counter(const char* name, double* value)
         else if (!strcmp(name, "spmm_kernel_launches")) *value = k.spmm_kernel_launches;
         else if (!strcmp(name, "spmm_last_tagged")) *value = k.spmm_last_tagged;
         else if (!strcmp(name, "spmm_hot_coverage")) *value = k.spmm_hot_coverage;
+        else if (!strcmp(name, "spmm_last_slices")) *value = k.spmm_last_slices;
+        else if (!strcmp(name, "spmm_plan_ms")) *value = k.spmm_plan_ms;
+        else if (!strcmp(name, "spmm_plans_built")) *value = k.spmm_plans_built;
         else mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown counter '%s'", name);
     });
 }

@@ -244,11 +244,7 @@ __global__ void __launch_bounds__(THREADS)
 template <typename T>
 __device__ __forceinline__ T load_l2(const T* p)
 {
-#ifdef MI_HIP_EMU
-    return *p;
-#else
     return __builtin_nontemporal_load(p);
-#endif
 }
 
 // Atomics on a table that only ONE workgroup touches while it is live: workgroup scope is formally
@@ -257,22 +253,14 @@ __device__ __forceinline__ T load_l2(const T* p)
 // of magnitude slower.  The table is cleared before / read back after with L1-bypassing accesses.
 __device__ __forceinline__ int32_t cas_wg(int32_t* p, int32_t expected, int32_t desired)
 {
-#ifdef MI_HIP_EMU
-    return atomicCAS(p, expected, desired);
-#else
     __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_WORKGROUP);
     return expected;
-#endif
 }
 template <typename R>
 __device__ __forceinline__ void add_wg(R* p, R x)
 {
-#ifdef MI_HIP_EMU
-    atomicAdd(p, x);
-#else
     __hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
 }
 template <typename T>
 __device__ __forceinline__ void accum_wg(T* p, T x)

@@ -78,7 +78,8 @@ __device__ __forceinline__ int32_t spmm_trail_row(const int64_t* ptr, const int3
 }
 
 // one thread per chunk: the first chunk of every run of chunks that carry into the same row emits
-// the fix-up task (row, first chunk, last chunk)
+// the fix-up task (row, first chunk, last chunk).  Tasks are independent, so their order in the list
+// (atomic cursor) does not matter; there are at most nchunks of them (runs are disjoint).
 __global__ void k_spmm_plan_tasks(const int64_t* ptr, const int32_t* chunk_row, int64_t rows, int64_t nnz, int64_t ch,
                                   int64_t nchunks, int32_t* tasks, unsigned long long* n_tasks)
 {
@@ -90,11 +91,9 @@ __global__ void k_spmm_plan_tasks(const int64_t* ptr, const int32_t* chunk_row, 
     int64_t last = w;
     while (last + 1 < nchunks && spmm_trail_row(ptr, chunk_row, rows, nnz, ch, last + 1) == row) ++last;
     const unsigned long long t = atomicAdd(n_tasks, 1ull);
-    if (tasks) {
-        tasks[3 * t + 0] = row;
-        tasks[3 * t + 1] = (int32_t)w;
-        tasks[3 * t + 2] = (int32_t)last;
-    }
+    tasks[3 * t + 0] = row;
+    tasks[3 * t + 1] = (int32_t)w;
+    tasks[3 * t + 2] = (int32_t)last;
 }
 
 // one staged nonzero of A: column + value side by side so a lane group fetches both with ONE
@@ -215,10 +214,8 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     const int g = lane / LPN;
     const int li = lane % LPN;
     const int nproc = n_owned + has_trail;
-#ifndef MI_HIP_EMU
     __amdgpu_buffer_rsrc_t b_rsrc;
     if constexpr (TAG) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
-#endif
 
     for (int64_t j0 = jlo; j0 < jhi; j0 += (int64_t)LPN * V) {
         const int64_t jc = j0 + (int64_t)li * V;  // first column of this lane
@@ -248,16 +245,11 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
                     if (NG >= 8 && !ok[u]) continue;
                     if constexpr (TAG) {
                         const int32_t cidx = nz[u].c & 0x7fffffff;
-#ifndef MI_HIP_EMU
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         const unsigned voff = (unsigned)(((int64_t)cidx * b_rs + (col_ok ? jc : jlo)) * (int64_t)sizeof(T));
                         u32x4 r;
                         if (nz[u].c < 0) r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 2);  // nt
                         else r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 0);
                         b[u] = __builtin_bit_cast(vec<T, V>, r);
-#else
-                        b[u] = *reinterpret_cast<const vec<T, V>*>(bcol + (int64_t)cidx * b_rs);
-#endif
                     } else {
                         const T* src = bcol + (int64_t)nz[u].c * b_rs;
                         if (V > 1) {
@@ -476,13 +468,13 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
 // read-modify-write of C.  LPN lanes x V values, the shapes of the main kernel.
 template <typename T, int V, int LPN>
 __global__ void __launch_bounds__(256)
-    k_spmm_fixup(int64_t n_tasks, const int32_t* __restrict__ tasks, const T* __restrict__ carry_val, int64_t N,
-                 T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha)
+    k_spmm_fixup(const unsigned long long* __restrict__ n_tasks_dev, const int32_t* __restrict__ tasks,
+                 const T* __restrict__ carry_val, int64_t N, T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t task = t / LPN;
     const int li = (int)(t % LPN);
-    if (task >= n_tasks) return;
+    if (task >= (int64_t)*n_tasks_dev) return;  // the count lives on the device (the grid may be an upper bound)
     const int64_t row = tasks[3 * task], first = tasks[3 * task + 1], last = tasks[3 * task + 2];
     for (int64_t jc = (int64_t)li * V; jc < N; jc += (int64_t)LPN * V) {
         // eight interleaved partial sums (chunks first+g, first+g+8, ...) so that eight carry loads are
@@ -566,54 +558,147 @@ static void convert_layout(int64_t rows, int64_t cols, const T* src, int64_t s_r
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-__global__ void k_count_cols(const int32_t* __restrict__ col, int64_t nnz, unsigned* __restrict__ counts)
+// ---- hot / cold analysis, entirely on the device ---------------------------------------------------
+// (1) column histogram over a SAMPLE of the nonzeros (every `stride`-th block of 2048 consecutive ones:
+//     the hot set only needs the ranking of the heavy columns, and an exact count costs one L2 atomic per
+//     nonzero -- 3 ms at 31 M nonzeros, more than the product it serves);
+// (2) histogram of the (clamped) counts -> the count threshold whose column set fits the budget, and the
+//     share of sampled nonzeros it covers;  (3) tagged copy of the column indices.
+// Nothing is read back synchronously: the decision word travels to the host with an asynchronous copy
+// that a later call polls (AsyncWord).
+constexpr int HOT_BLOCK = 2048;   // nonzeros per sampled block
+constexpr int HOT_BINS = 4096;    // count histogram bins (counts >= HOT_BINS - 1 share the last bin)
+
+__global__ void __launch_bounds__(256)
+    k_count_cols(const int32_t* __restrict__ col, int64_t nnz, int64_t stride, unsigned* __restrict__ counts)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&counts[col[i]], 1u);
+    const int64_t base = (int64_t)blockIdx.x * stride * HOT_BLOCK;
+    const int64_t end = base + HOT_BLOCK < nnz ? base + HOT_BLOCK : nnz;
+    for (int64_t i = base + threadIdx.x; i < end; i += 256) atomicAdd(&counts[col[i]], 1u);
+}
+
+// hist[b] = columns with min(count, HOT_BINS - 1) == b;  wsum[b] = sum of their counts
+__global__ void __launch_bounds__(256)
+    k_count_hist(const unsigned* __restrict__ counts, int64_t ncols, unsigned long long* __restrict__ hist,
+                 unsigned long long* __restrict__ wsum)
+{
+    __shared__ unsigned h[HOT_BINS];
+    __shared__ unsigned long long big;  // exact sum of the counts that land in the last bin
+    for (int k = threadIdx.x; k < HOT_BINS; k += 256) h[k] = 0u;
+    if (threadIdx.x == 0) big = 0ull;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncols; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned c = counts[i];
+        if (c == 0) continue;
+        if (c >= HOT_BINS - 1) {
+            atomicAdd(&h[HOT_BINS - 1], 1u);
+            atomicAdd(&big, (unsigned long long)c);
+        } else {
+            atomicAdd(&h[c], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < HOT_BINS; k += 256) {
+        if (h[k]) {
+            atomicAdd(&hist[k], (unsigned long long)h[k]);
+            if (k < HOT_BINS - 1) atomicAdd(&wsum[k], (unsigned long long)h[k] * (unsigned long long)k);
+        }
+    }
+    if (threadIdx.x == 0 && big) atomicAdd(&wsum[HOT_BINS - 1], big);
+}
+
+// one workgroup: decision = {flag, threshold, hot columns, covered (sampled) nonzeros, sampled nonzeros}
+__global__ void __launch_bounds__(1024)
+    k_pick_threshold(const unsigned long long* __restrict__ hist, const unsigned long long* __restrict__ wsum,
+                     int64_t hot_rows, int force, int64_t* __restrict__ decision)
+{
+    __shared__ unsigned long long cnt[HOT_BINS], wt[HOT_BINS];
+    for (int k = threadIdx.x; k < HOT_BINS; k += 1024) {
+        cnt[k] = hist[k];
+        wt[k] = wsum[k];
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    unsigned long long total = 0;
+    for (int k = 1; k < HOT_BINS; ++k) total += wt[k];
+    // walk the thresholds from the top: the smallest count t whose set {count >= t} still fits the budget
+    unsigned long long n = 0, cov = 0;
+    int thr = HOT_BINS;  // nothing selected yet
+    for (int k = HOT_BINS - 1; k >= 1; --k) {
+        if (cnt[k] == 0) continue;
+        if ((int64_t)(n + cnt[k]) > hot_rows && n > 0) break;
+        n += cnt[k];
+        cov += wt[k];
+        thr = k;
+        if ((int64_t)n > hot_rows) break;  // a single over-full class (ties): judged below
+    }
+    const double share = total ? (double)cov / (double)total : 0.0;
+    // worth it only when a small set takes a real share of the gather and ties did not blow the set up
+    int flag = (thr < HOT_BINS && thr >= 2 && share >= 0.10 && (int64_t)n <= 2 * hot_rows) ? 1 : 0;
+    if (force && thr < HOT_BINS) flag = 1;
+    decision[0] = flag;
+    decision[1] = thr;
+    decision[2] = (int64_t)n;
+    decision[3] = (int64_t)cov;
+    decision[4] = (int64_t)total;
 }
 
 __global__ void k_tag_cols(const int32_t* __restrict__ col, int64_t nnz, const unsigned* __restrict__ counts,
-                           unsigned threshold, int32_t* __restrict__ tagged)
+                           const int64_t* __restrict__ decision, int32_t* __restrict__ tagged)
 {
+    if (decision[0] == 0) return;  // no useful hot set: the tagged copy is never used
+    const unsigned threshold = (unsigned)decision[1];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t c = col[i];
         tagged[i] = counts[c] >= threshold ? c : (int32_t)((unsigned)c | 0x80000000u);
     }
 }
 
-// Decide whether the matrix has a hot column set worth protecting and, if so, build the tagged
-// column array.  hot_rows = how many rows of B fit the L2 budget for this call's row width.
-static void plan_hot_cold(SpmmPlan& p, const Csr& m, int64_t hot_rows)
+// Enqueue the analysis for `hot_rows` rows of B behind whatever is already on the stream.
+static void enqueue_hot_analysis(SpmmPlan& p, const Csr& m, int64_t hot_rows)
 {
+    Context& c = ctx();
     p.hot_rows_budget = hot_rows;
     p.tagged = false;
     p.hot_coverage = 0.0;
+    p.hot_state = 2;  // "decided: untagged" unless the analysis below is launched
     const bool force = options().spmm_hot_force != 0;
     if (hot_rows <= 0 || m.nnz == 0) return;
     if (hot_rows > m.cols) hot_rows = m.cols;
     if (!force && (m.nnz < (int64_t)1 << 20 || m.cols <= 4 * hot_rows)) return;  // small / everything fits
-    Context& c = ctx();
+    const int64_t nblocks = ceil_div(m.nnz, HOT_BLOCK);
+    const int64_t stride = (m.nnz >= (int64_t)1 << 23) ? 8 : 1;  // sample 1/8 of the big ones
     unsigned* counts = static_cast<unsigned*>(c.scratch_alloc(sizeof(unsigned) * (size_t)m.cols));
+    unsigned long long* hist = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * 2 * HOT_BINS));
     MI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned) * (size_t)m.cols, c.stream));
-    MI_LAUNCH(k_count_cols, dim3((unsigned)(ceil_div(m.nnz, 256) < (1 << 20) ? ceil_div(m.nnz, 256) : (1 << 20))), dim3(256), c.stream, (const int32_t*)m.col, m.nnz,
-              counts);
-    std::vector<unsigned> hc((size_t)m.cols);
-    MI_HIP_CHECK(hipMemcpyAsync(hc.data(), counts, sizeof(unsigned) * (size_t)m.cols, hipMemcpyDeviceToHost, c.stream));
-    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-    // threshold = count of the hot_rows-th most referenced column
-    std::vector<unsigned> sel(hc);
-    std::nth_element(sel.begin(), sel.begin() + (hot_rows - 1), sel.end(), [](unsigned a, unsigned b) { return a > b; });
-    const unsigned thr = sel[(size_t)(hot_rows - 1)];
-    if (thr < 2 && !force) return;
-    int64_t covered = 0, nhot = 0;
-    for (unsigned v : hc)
-        if (v >= thr) { covered += v; ++nhot; }
-    p.hot_coverage = (double)covered / (double)m.nnz;
-    // worth it only when a small set takes a real share of the gather and ties did not blow the set up
-    if (!force && (p.hot_coverage < 0.10 || nhot > 2 * hot_rows)) return;
+    MI_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned long long) * 2 * HOT_BINS, c.stream));
+    MI_LAUNCH(k_count_cols, dim3((unsigned)ceil_div(nblocks, stride)), dim3(256), c.stream, (const int32_t*)m.col, m.nnz,
+              stride, counts);
+    const int64_t hgrid = ceil_div(m.cols, 256) < 1024 ? ceil_div(m.cols, 256) : 1024;
+    MI_LAUNCH(k_count_hist, dim3((unsigned)hgrid), dim3(256), c.stream, (const unsigned*)counts, m.cols, hist,
+              hist + HOT_BINS);
+    if (!p.hot_decision.p) p.hot_decision.alloc(sizeof(int64_t) * 8);
+    MI_LAUNCH(k_pick_threshold, dim3(1), dim3(1024), c.stream, (const unsigned long long*)hist,
+              (const unsigned long long*)(hist + HOT_BINS), hot_rows, (int)force, p.hot_decision.as<int64_t>());
     p.col_tagged.alloc(sizeof(int32_t) * (size_t)m.nnz);
-    MI_LAUNCH(k_tag_cols, dim3((unsigned)(ceil_div(m.nnz, 256) < (1 << 20) ? ceil_div(m.nnz, 256) : (1 << 20))), dim3(256), c.stream, (const int32_t*)m.col, m.nnz,
-              (const unsigned*)counts, thr, p.col_tagged.as<int32_t>());
-    p.tagged = true;
+    const int64_t tg = ceil_div(m.nnz, 256) < (1 << 16) ? ceil_div(m.nnz, 256) : (1 << 16);
+    MI_LAUNCH(k_tag_cols, dim3((unsigned)tg), dim3(256), c.stream, (const int32_t*)m.col, m.nnz, (const unsigned*)counts,
+              (const int64_t*)p.hot_decision.as<int64_t>(), p.col_tagged.as<int32_t>());
+    p.hot_word.post(p.hot_decision.p, sizeof(int64_t) * 5, c.stream);
+    p.hot_state = 1;
+}
+
+// adopt a finished analysis (non-blocking unless `wait`)
+static void poll_hot_analysis(SpmmPlan& p, bool wait)
+{
+    if (p.hot_state != 1) return;
+    if (wait) ctx().sync();
+    if (!p.hot_word.ready()) return;
+    const int64_t* d = p.hot_word.host;
+    p.tagged = d[0] != 0;
+    p.hot_coverage = d[4] ? (double)d[3] / (double)d[4] : 0.0;
+    if (!p.tagged) p.col_tagged.release();
+    p.hot_state = 2;
 }
 
 static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, int chunk, int64_t hot_rows)
@@ -622,33 +707,43 @@ static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, in
     std::lock_guard<std::mutex> lk(h->mtx);
     Context& c = ctx();
     if (!(p.chunk == chunk && p.chunk_row.p)) {
+        // the row partition and the fix-up schedule: two small kernels, nothing read back here
         const int64_t total = m.nnz + m.rows;
         p.nchunks = total > 0 ? ceil_div(total, chunk) : 1;
         p.chunk_row.alloc(sizeof(int32_t) * (size_t)(p.nchunks + 1));
         MI_LAUNCH(k_spmm_plan, dim3((unsigned)ceil_div(p.nchunks + 1, 256)), dim3(256), c.stream,
                   (const int64_t*)m.ptr, m.rows, m.nnz, (int64_t)chunk, p.nchunks, p.chunk_row.as<int32_t>());
         p.chunk = chunk;
-        // fix-up schedule: count, then fill
-        unsigned long long* d_n = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long)));
-        const dim3 tgrid((unsigned)ceil_div(p.nchunks, 256));
-        MI_HIP_CHECK(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c.stream));
-        MI_LAUNCH(k_spmm_plan_tasks, tgrid, dim3(256), c.stream, (const int64_t*)m.ptr,
+        p.tasks.alloc(sizeof(int32_t) * 3 * (size_t)(p.nchunks + 1));
+        p.n_tasks_dev.alloc(sizeof(unsigned long long));
+        MI_HIP_CHECK(hipMemsetAsync(p.n_tasks_dev.p, 0, sizeof(unsigned long long), c.stream));
+        MI_LAUNCH(k_spmm_plan_tasks, dim3((unsigned)ceil_div(p.nchunks, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
                   (const int32_t*)p.chunk_row.as<int32_t>(), m.rows, m.nnz, (int64_t)chunk, p.nchunks,
-                  (int32_t*)nullptr, d_n);
-        unsigned long long h_n = 0;
-        MI_HIP_CHECK(hipMemcpyAsync(&h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, c.stream));
-        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-        p.n_tasks = (int64_t)h_n;
-        p.tasks.alloc(sizeof(int32_t) * 3 * (size_t)(p.n_tasks + 1));
-        if (p.n_tasks) {
-            MI_HIP_CHECK(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c.stream));
-            MI_LAUNCH(k_spmm_plan_tasks, tgrid, dim3(256), c.stream, (const int64_t*)m.ptr,
-                      (const int32_t*)p.chunk_row.as<int32_t>(), m.rows, m.nnz, (int64_t)chunk, p.nchunks,
-                      p.tasks.as<int32_t>(), d_n);
-        }
+                  p.tasks.as<int32_t>(), static_cast<unsigned long long*>(p.n_tasks_dev.p));
+        p.n_tasks = -1;
+        p.n_tasks_word.post(p.n_tasks_dev.p, sizeof(unsigned long long), c.stream);
+        p.uses = 0;
+        counters().spmm_plans_built += 1.0;
     }
-    if (p.hot_rows_budget != hot_rows) plan_hot_cold(p, m, hot_rows);
+    if (p.n_tasks < 0 && p.n_tasks_word.ready()) p.n_tasks = p.n_tasks_word.host[0];
+    // hot / cold tags: analysed behind the SECOND product of a handle (a single-use handle never pays),
+    // or at once when a test / tool asks for the synchronous form
+    const bool sync_plan = options().spmm_plan_sync != 0 || options().spmm_hot_force != 0;
+    if (p.hot_rows_budget != hot_rows && (p.hot_rows_budget >= 0 || sync_plan)) {
+        p.reset_hot();  // the budget changed (another row width): analyse again, now
+        enqueue_hot_analysis(p, m, hot_rows);
+    }
+    poll_hot_analysis(p, sync_plan);
     return p;
+}
+
+// called after a product has been enqueued: count the use and start the analysis when reuse is proven
+static void plan_after_product(mi_sparse_matrix* h, bool transposed, const Csr& m, int64_t hot_rows)
+{
+    SpmmPlan& p = transposed ? h->planT : h->plan;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    ++p.uses;
+    if (p.uses == 2 && p.hot_state == 0 && p.hot_rows_budget < 0) enqueue_hot_analysis(p, m, hot_rows);
 }
 
 template <typename T, int V, int LPN, int U>
@@ -726,7 +821,15 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     constexpr int V16 = 16 / (int)sizeof(T);
     int slices = 1;
     {
-        const int64_t want = options().spmm_slices;
+        int64_t want = options().spmm_slices;
+        if (want == 0) {
+            // by row width only (never by the matrix: the column split fixes the summation order, so a handle
+            // returns the same bits on every call): 256-byte slices, 128-byte ones for 256-byte rows.  Measured on
+            // the headline matrix (profiles/r02_spmm_slices_pmc.jsonl): 512-byte rows 2.00 -> 1.79 ms with 2 slices,
+            // 1 KiB rows 4.89 -> 4.18 ms with 4; 64-byte slices double the L2 requests and lose.
+            const int64_t row_bytes = N * (int64_t)sizeof(T);
+            want = row_bytes >= 2048 ? 8 : row_bytes >= 1024 ? 4 : row_bytes >= 256 ? 2 : 1;
+        }
         if (layout == MI_SPARSE_LAYOUT_ROW_MAJOR && (want == 2 || want == 4 || want == 8) && N % want == 0 &&
             (N / want) % V16 == 0 && (N / want) * (int64_t)sizeof(T) >= 64)
             slices = (int)want;
@@ -738,6 +841,9 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         (N * (int64_t)sizeof(T) >= 512 || options().spmm_hot_force))
         hot_rows = options().spmm_hot_kb * 1024 / slice_bytes;
     const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk, hot_rows);
+    // fix-up grid: the exact task count once it has reached the host, else its upper bound
+    const int64_t fix_tasks = p.n_tasks >= 0 ? p.n_tasks : p.nchunks;
+    const unsigned long long* n_tasks_dev = static_cast<const unsigned long long*>(p.n_tasks_dev.p);
     T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)p.nchunks * (size_t)N));
     const bool row_major = (layout == MI_SPARSE_LAYOUT_ROW_MAJOR);
     const int64_t b_rs = row_major ? ldb : 1, b_cs = row_major ? 1 : ldb;
@@ -754,9 +860,10 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
                        pw * SPMM_WAVES, c.stream, m.rows, m.nnz, (const int64_t*)m.ptr, (const int32_t*)m.col,
                        (const T*)m.val, (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs,
                        C, c_rs, alpha, beta, (int)(vt<T>::is_zero(beta) ? 1 : 0), carry_val);
-        if (p.n_tasks)
-            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(p.n_tasks * 16, 256)), dim3(256), c.stream,
-                      p.n_tasks, (const int32_t*)p.tasks.as<int32_t>(), (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+        if (fix_tasks)
+            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(fix_tasks * 16, 256)), dim3(256), c.stream,
+                      n_tasks_dev, (const int32_t*)p.tasks.as<int32_t>(), (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+        plan_after_product(h, transposed, m, hot_rows);
         return;
     }
     // tagged (hot / cold) gather: needs 32-bit byte offsets into B
@@ -764,8 +871,8 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     counters().spmm_last_tagged = use_tags ? 1.0 : 0.0;
     counters().spmm_hot_coverage = p.hot_coverage;
     if (!vec_ok) slices = 1;
+    counters().spmm_last_slices = (double)slices;
 #define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, use_tags, slices
-#ifndef MI_HIP_EMU
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool prof = options().profile_events != 0;
     if (prof) {
@@ -773,7 +880,6 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         MI_HIP_CHECK(hipEventCreate(&ev1));
         MI_HIP_CHECK(hipEventRecord(ev0, c.stream));
     }
-#endif
     if (vec_ok) {
         const int64_t lanes = N / slices / V16;  // 16-byte lanes needed for one (slice of a) row of B
         if (lanes >= 64) launch_spmm<T, V16, 64>(MI_SPMM_ARGS);
@@ -787,7 +893,6 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         else launch_spmm<T, 1, 4>(MI_SPMM_ARGS);
     }
 #undef MI_SPMM_ARGS
-#ifndef MI_HIP_EMU
     if (prof) {
         MI_HIP_CHECK(hipEventRecord(ev1, c.stream));
         MI_HIP_CHECK(hipEventSynchronize(ev1));
@@ -798,21 +903,21 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         (void)hipEventDestroy(ev0);
         (void)hipEventDestroy(ev1);
     }
-#endif
-    if (p.n_tasks) {
+    if (fix_tasks) {
         const int32_t* tk = p.tasks.as<int32_t>();
         if (vec_ok) {
             if (N / V16 > 16)
-                MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)ceil_div(p.n_tasks * 32, 256)), dim3(256), c.stream,
-                          p.n_tasks, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+                MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)ceil_div(fix_tasks * 32, 256)), dim3(256), c.stream,
+                          n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
             else
-                MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)ceil_div(p.n_tasks * 8, 256)), dim3(256), c.stream,
-                          p.n_tasks, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+                MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)ceil_div(fix_tasks * 8, 256)), dim3(256), c.stream,
+                          n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         } else {
-            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(p.n_tasks * 16, 256)), dim3(256), c.stream,
-                      p.n_tasks, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(fix_tasks * 16, 256)), dim3(256), c.stream,
+                      n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         }
     }
+    plan_after_product(h, transposed, m, hot_rows);
 }
 
 template void spmm_device<float>(mi_sparse_matrix*, bool, const Csr&, int, float, int, const float*, int64_t, int64_t,

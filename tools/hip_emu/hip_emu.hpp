@@ -34,8 +34,11 @@ struct dim3 {
 #define __launch_bounds__(...)
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNoDevice = 100 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorNotReady = 600 };
 typedef void* hipStream_t;
+struct hip_emu_event { double t; };
+typedef hip_emu_event* hipEvent_t;
+enum { hipHostMallocDefault = 0, hipEventDisableTiming = 2 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
 enum hipMemoryType { hipMemoryTypeHost = 0, hipMemoryTypeDevice = 1, hipMemoryTypeManaged = 3, hipMemoryTypeUnregistered = 4 };
 struct hipPointerAttribute_t { hipMemoryType type; };
@@ -244,6 +247,15 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { s
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hip_emu_event{0.0}; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = 0.0; return hipSuccess; }  // launches are synchronous here
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p)
 {
     std::lock_guard<std::mutex> lk(hip_emu::st().alloc_m);
@@ -255,3 +267,74 @@ inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* 
     }
     return hipErrorInvalidValue;
 }
+
+// ---- gfx950 builtins the kernels use, restated for host threads ----------------------------------
+// (so that the kernel sources carry ONE code path: the emulation lives here, not in #ifdef branches)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+template <typename T>
+inline bool __hip_atomic_compare_exchange_strong(T* p, T* expected, T desired, int, int, int)
+{
+    return __atomic_compare_exchange_n(p, expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+}
+inline float __hip_atomic_fetch_add(float* p, float x, int, int) { return emu_atomic_fadd(p, x); }
+inline double __hip_atomic_fetch_add(double* p, double x, int, int) { return emu_atomic_fadd(p, x); }
+
+// buffer resource + raw 16-byte buffer load (the cache-policy immediate `aux` has no host meaning)
+struct __amdgpu_buffer_rsrc_t { const char* base; };
+typedef unsigned mi_u32x4 __attribute__((vector_size(16)));
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return __amdgpu_buffer_rsrc_t{(const char*)p}; }
+inline mi_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int)
+{
+    mi_u32x4 v;
+    std::memcpy(&v, r.base + voff + soff, 16);
+    return v;
+}
+
+// matrix-core instructions: every lane publishes its A / B operand, then computes the accumulator
+// registers it owns (fragment layouts: csrc/dense.hip header comment)
+typedef float mi_f32x16 __attribute__((vector_size(64)));
+typedef double mi_f64x4 __attribute__((vector_size(32)));
+inline mi_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, mi_f32x16 acc, int, int, int)
+{
+    hip_emu::WaveState& w = hip_emu::st().waves[hip_emu::t_tid / 64];
+    const int lane = hip_emu::t_tid % 64;
+    float ab[2] = {a, b};
+    std::memcpy(w.slot[lane], ab, sizeof(ab));
+    w.bar.arrive_and_wait();
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 31;
+        float s = acc[r];
+        for (int k = 0; k < 2; ++k) {  // A[i][k] lives in lane i + 32 k, B[k][j] in lane j + 32 k
+            float av[2], bv[2];
+            std::memcpy(av, w.slot[i + 32 * k], sizeof(av));
+            std::memcpy(bv, w.slot[j + 32 * k], sizeof(bv));
+            s = __builtin_fmaf(av[0], bv[1], s);
+        }
+        acc[r] = s;
+    }
+    w.bar.arrive_and_wait();
+    return acc;
+}
+inline mi_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, mi_f64x4 acc, int, int, int)
+{
+    hip_emu::WaveState& w = hip_emu::st().waves[hip_emu::t_tid / 64];
+    const int lane = hip_emu::t_tid % 64;
+    double ab[2] = {a, b};
+    std::memcpy(w.slot[lane], ab, sizeof(ab));
+    w.bar.arrive_and_wait();
+    for (int r = 0; r < 4; ++r) {
+        const int i = (lane >> 4) + 4 * r, j = lane & 15;
+        double s = acc[r];
+        for (int k = 0; k < 4; ++k) {  // A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k
+            double av[2], bv[2];
+            std::memcpy(av, w.slot[i + 16 * k], sizeof(av));
+            std::memcpy(bv, w.slot[j + 16 * k], sizeof(bv));
+            s = __builtin_fma(av[0], bv[1], s);
+        }
+        acc[r] = s;
+    }
+    w.bar.arrive_and_wait();
+    return acc;
+}
+
