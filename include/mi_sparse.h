@@ -334,6 +334,14 @@ mi_sparse_status_t mi_sparse_s_syrkd(int op, mi_sparse_matrix_t A, float alpha, 
                                      int layout, int64_t ldc);
 mi_sparse_status_t mi_sparse_d_syrkd(int op, mi_sparse_matrix_t A, double alpha, double beta, double *C,
                                      int layout, int64_t ldc);
+/* Row band of the same product (no MKL counterpart; the multi-GPU split of the gram path, SURVEY section 8e:
+ * "split by output rows ... needs no reduction"): only output rows [row0, row1) are produced, and C points at the
+ * (row1 - row0) x n block that holds them (row-major: ldc >= n; column-major: ldc >= row1 - row0).  Entries left of
+ * the diagonal of the full matrix (column < row) are not touched.  mi_sparse_?_syrkd == rows [0, n). */
+mi_sparse_status_t mi_sparse_s_syrkd_rows(int op, mi_sparse_matrix_t A, float alpha, float beta, float *C,
+                                          int layout, int64_t ldc, int64_t row0, int64_t row1);
+mi_sparse_status_t mi_sparse_d_syrkd_rows(int op, mi_sparse_matrix_t A, double alpha, double beta, double *C,
+                                          int layout, int64_t ldc, int64_t row0, int64_t row1);
 
 /* cblas_?gemm (reference _cfunctions.py:582-598; call site _dense_dense.py:53-66)
  *     C := alpha * op(A) * op(B) + beta * C     (the MFMA consumer; fallback path, test-sized)

@@ -54,6 +54,28 @@ def _gram_matrix_sparse_to_dense(matrix_a, aat=False, scalar=1.0, out=None, out_
     return output_arr
 
 
+def _gram_rows_dense(matrix_a, row0, row1, aat=False):
+    """Rows [row0, row1) of the dense upper-triangular gram matrix as a fresh (row1 - row0, n) array
+    (mi_sparse_?_syrkd_rows): the building block of the multi-GPU gram, which splits the OUTPUT by rows so that
+    no reduction is needed (sparse_dot_amd.distributed.sharded_gram_matrix).  Entries left of the diagonal stay 0."""
+    matrix_a = _type_check(matrix_a)
+    dbl, cplx = _is_double(matrix_a)
+    if cplx:
+        raise ValueError("gram_matrix_mkl does not support complex datatypes")
+    n = matrix_a.shape[0 if aat else 1]
+    if not (0 <= row0 <= row1 <= n):
+        raise ValueError("bad output row range [%d, %d) of %d" % (row0, row1, n))
+    output_arr = _np.zeros((row1 - row0, n), dtype=_output_dtypes[(dbl, cplx)])
+    if row1 == row0 or _empty_output_check(matrix_a, matrix_a):
+        return output_arr
+    name = "mi_sparse_%s_syrkd_rows" % _type_letters[(dbl, cplx)]
+    with SparseHandle.from_scipy(matrix_a) as ha:
+        ret = MI.call(name, _op(aat), ha.ptr, _mi_scalar(1.0, cplx, dbl), _mi_scalar(0.0, cplx, dbl),
+                      output_arr.ctypes.data, LAYOUT_CODE_C, n, row0, row1)
+        _check_return_value(ret, name)
+    return output_arr
+
+
 def _gram_matrix_dense_to_dense(matrix_a, aat=False, scalar=1.0, out=None, out_scalar=None):
     n, k = matrix_a.shape if aat else matrix_a.shape[::-1]
     layout_a, ld_a = _get_numpy_layout(matrix_a)

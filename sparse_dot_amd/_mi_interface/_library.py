@@ -122,6 +122,7 @@ def _bind(lib):
     for t in "sd":
         sc = SCALAR_CTYPE[t]
         add("mi_sparse_%s_syrkd" % t, [_int, H, sc, sc, _vp, _int, _i64])
+        add("mi_sparse_%s_syrkd_rows" % t, [_int, H, sc, sc, _vp, _int, _i64, _i64, _i64])
         add("mi_cblas_%sgemm" % t, [_int, _int, _int, _i64, _i64, _i64, sc, _vp, _i64, _vp, _i64, sc, _vp, _i64])
         add("mi_cblas_%ssyrk" % t, [_int, _int, _int, _i64, _i64, sc, _vp, _i64, sc, _vp, _i64])
     for t in "cz":

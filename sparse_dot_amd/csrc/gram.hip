@@ -28,14 +28,14 @@ constexpr int syrkd_tile() { return (int)(65536 / sizeof(T)); }  // 64 KiB of LD
 
 template <typename T>
 __global__ void __launch_bounds__(512)
-    k_syrkd_lds(int64_t n, int64_t tiles_per_row, const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol,
+    k_syrkd_lds(int64_t n, int64_t row0, int64_t tiles_per_row, const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol,
                 const T* __restrict__ tval, const int64_t* __restrict__ xptr, const int32_t* __restrict__ xcol,
                 const T* __restrict__ xval, T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta,
                 int beta_zero)
 {
     constexpr int TILE = syrkd_tile<T>();
     __shared__ T acc[TILE];
-    const int64_t i = (int64_t)blockIdx.x / tiles_per_row;
+    const int64_t i = row0 + (int64_t)blockIdx.x / tiles_per_row;  // output row (C points at row `row0`)
     const int64_t t = (int64_t)blockIdx.x % tiles_per_row;
     const int64_t j_lo = i + t * TILE;
     if (j_lo >= n) return;  // uniform for the whole workgroup
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(512)
         }
     }
     __syncthreads();
-    T* crow = C + i * c_rs;
+    T* crow = C + (i - row0) * c_rs;
     for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
         T* c = crow + j * c_cs;
         const T v = acc[j - j_lo];
@@ -100,7 +100,8 @@ __global__ void __launch_bounds__(512)
 }
 
 template <typename T>
-static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, int layout, int64_t ldc)
+static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, int layout, int64_t ldc, int64_t row0 = 0,
+                         int64_t row1 = -1)
 {
     return guarded([&] {
         mi_sparse_matrix* h = check_handle(A);
@@ -114,9 +115,12 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
             fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad layout code %d", layout);
         const bool aat = (op == MI_SPARSE_OPERATION_NON_TRANSPOSE);
         const int64_t n = aat ? h->rows : h->cols;
-        if (n == 0) return;
+        if (row1 < 0) row1 = n;
+        if (row0 < 0 || row0 > row1 || row1 > n) fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad output row range [%lld, %lld) of %lld", (long long)row0, (long long)row1, (long long)n);
+        const int64_t nr = row1 - row0;  // rows of the output block C points at
+        if (n == 0 || nr == 0) return;
         if (!C) fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL output array");
-        if (ldc < n) fail(MI_SPARSE_STATUS_INVALID_VALUE, "ldc too small");
+        if (ldc < (layout == MI_SPARSE_LAYOUT_ROW_MAJOR ? n : nr)) fail(MI_SPARSE_STATUS_INVALID_VALUE, "ldc too small");
         Context& c = ctx();
         c.scratch_reset();
         // X = A (A^T A) or A^T (A A^T);  t = CSR of X^T, x = CSR of X
@@ -126,11 +130,12 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         const int64_t c_rs = row_major ? ldc : 1, c_cs = row_major ? 1 : ldc;
         Staged sc;
         const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
-        sc.stage_in(C, sizeof(T) * (size_t)((n - 1) * ldc + n), true);  // lower triangle must survive the round trip
+        // lower triangle must survive the round trip
+        sc.stage_in(C, sizeof(T) * (size_t)(row_major ? (nr - 1) * ldc + n : (n - 1) * ldc + nr), true);
         T* dC = static_cast<T*>(sc.dev);
         const int64_t tiles_per_row = ceil_div(n, (int64_t)syrkd_tile<T>());
-        if (n * tiles_per_row > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "gram output too large for one launch");
-        MI_LAUNCH((k_syrkd_lds<T>), dim3((unsigned)(n * tiles_per_row)), dim3(512), c.stream, n, tiles_per_row,
+        if (nr * tiles_per_row > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "gram output too large for one launch");
+        MI_LAUNCH((k_syrkd_lds<T>), dim3((unsigned)(nr * tiles_per_row)), dim3(512), c.stream, n, row0, tiles_per_row,
                   (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
                   (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero);
         MI_HIP_CHECK(hipGetLastError());
@@ -151,6 +156,16 @@ mi_sparse_status_t mi_sparse_d_syrkd(int op, mi_sparse_matrix_t A, double alpha,
                                      int64_t ldc)
 {
     return mi::syrkd_generic<double>(op, A, alpha, beta, C, layout, ldc);
+}
+mi_sparse_status_t mi_sparse_s_syrkd_rows(int op, mi_sparse_matrix_t A, float alpha, float beta, float* C, int layout,
+                                          int64_t ldc, int64_t row0, int64_t row1)
+{
+    return mi::syrkd_generic<float>(op, A, alpha, beta, C, layout, ldc, row0, row1);
+}
+mi_sparse_status_t mi_sparse_d_syrkd_rows(int op, mi_sparse_matrix_t A, double alpha, double beta, double* C, int layout,
+                                          int64_t ldc, int64_t row0, int64_t row1)
+{
+    return mi::syrkd_generic<double>(op, A, alpha, beta, C, layout, ldc, row0, row1);
 }
 
 }  // extern "C"

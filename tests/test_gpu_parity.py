@@ -645,6 +645,49 @@ def test_spgemm_all_bins(gpu, oracle, dtype):
         _check_spgemm(got, want, dtype)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spgemm_signed_values_all_paths(gpu, oracle, dtype):
+    """SIGNED operands (standard normal: real cancellation) through every accumulation path -- LDS hash bins,
+    LDS bitmap + range-partitioned classes (hub rows), global-memory hash.  The accumulators are unordered
+    LDS / L2 atomics, so values are judged against the cancellation-free magnitude (|A| |B|)_ij: fp64 1e-12,
+    fp32 1e-5 of it; the structure must still be bit-exact (cancelled entries are KEPT, as MKL does)."""
+    rng = np.random.default_rng(171)
+    k, n = 3000, 5000
+    b = pos_csr(k, n, 0.004, dtype, 172)
+    b.data[:] = rng.standard_normal(b.nnz).astype(dtype)
+    lens = np.concatenate([rng.integers(0, 2, 300), rng.integers(2, 12, 300), rng.integers(20, 90, 100),
+                           [150, 170, 300, 330, 400, 900, 1500, 2500], rng.integers(0, 3, 50)])
+    m = lens.size
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    a = sps.csr_matrix((rng.standard_normal(indices.size).astype(dtype), indices, indptr), shape=(m, k))
+    want = oracle.spgemm(a.astype(np.float64), b.astype(np.float64))   # sorted rows, zeros kept
+    scale = oracle.spgemm(abs(a).astype(np.float64), abs(b).astype(np.float64))
+    assert np.array_equal(want.indices, scale.indices)
+    bar = (1e-5 if dtype == np.float32 else 1e-12) * scale.data
+
+    def check(got):
+        got = got.copy()
+        got.sort_indices()
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        assert np.all(np.abs(got.data.astype(np.float64) - want.data) <= bar)
+    check(gpu.dot_product_mkl(a, b))
+    for opt, val in (("spgemm_force_global", 1), ("spgemm_lds_parts", 0)):
+        gpu.mi_set_option(opt, val)
+        try:
+            check(gpu.dot_product_mkl(a, b))
+        finally:
+            gpu.mi_set_option(opt, 1 - val)
+    # the gram path (A^T A, upper triangle) on signed data: dense and sparse outputs
+    x = pos_csr(4000, 300, 0.05, dtype, 173)
+    x.data[:] = rng.standard_normal(x.nnz).astype(dtype)
+    ref = np.triu((x.T.astype(np.float64) @ x.astype(np.float64)).toarray())
+    mag = np.triu((abs(x).T.astype(np.float64) @ abs(x).astype(np.float64)).toarray())
+    tol_ = 1e-5 if dtype == np.float32 else 1e-12
+    assert np.all(np.abs(gpu.gram_matrix_mkl(x, dense=True) - ref) <= tol_ * mag + 1e-300)
+    assert np.all(np.abs(gpu.gram_matrix_mkl(x).toarray() - ref) <= tol_ * mag + 1e-300)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
 def test_spgemm_hub_rows_lds_bitmap_and_partitioned_classes(gpu, dtype):
     """Rows far beyond the LDS hash bins (tens of thousands of distinct columns): symbolic through the LDS

@@ -3,6 +3,8 @@
 x {sparse on the left, on the right} x {no out, out = ones with out_scalar = 3}), restated as one
 parametrised test against numpy on densified operands.  Results must have numpy's shape, the
 dispatcher's dtype / memory order, and `out` must come back as the same object."""
+import zlib
+
 import numpy as np
 import pytest
 import scipy.sparse as sps
@@ -26,7 +28,7 @@ def _mk(rng, shape, dtype, density=0.3):
 
 
 def _tol(dtype):
-    return 2e-5 if np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-12
+    return 1e-5 if np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-12  # the north_star's bars
 
 
 @pytest.mark.parametrize("use_out", [False, True])
@@ -37,7 +39,7 @@ def _tol(dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
 def test_sparse_dense_matrix(gpu, dtype, order, cls, shape, side, use_out):
     m, k, n = SHAPES[shape]
-    rng = np.random.default_rng(abs(hash((shape, side, cls))) % (2 ** 31))
+    rng = np.random.default_rng(zlib.crc32(repr((shape, side, cls)).encode()))  # stable across processes (hash() is salted)
     a_d, b_d = _mk(rng, (m, k), dtype), _mk(rng, (k, n), dtype, density=1.0)
     if side == "sparse_left":
         a = SPARSE_MAKERS[cls](a_d)

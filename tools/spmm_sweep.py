@@ -35,6 +35,7 @@ def main():
 
     dev = torch.device("cuda", 0)
     sda.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+    sda.mi_set_option("spmm_plan_sync", 1)  # A/B tool: every launch of a variant runs with its final plan
     if args.workload == "rmat":
         indptr, indices, vals, n = bench.rmat_csr(torch, args.scale, 32, 7, dev)
     else:
