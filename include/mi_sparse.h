@@ -264,6 +264,12 @@ mi_sparse_status_t mi_sparse_get_info(mi_sparse_matrix_t A, int64_t *rows, int64
  * destroyed or re-ordered (mi_sparse_order may move a library-owned result's values to a new
  * block: fetch the pointers again after it).  Lets HBM-resident callers consume spmm / syrk results
  * without a host round trip. */
+/* Copy the handle's matrix straight into CALLER-allocated arrays (host or device): indptr of rows + 1 (csc: cols + 1)
+ * entries, indices and values of nnz entries (mi_sparse_get_info), indices of `index_bytes` (4 / 8) bytes each.  The
+ * MKL-shaped mi_sparse_?_export_* calls hand out library-owned copies which the reference's Python then copies again
+ * (reference _common.py:488-491); this is the one-copy form the package's own export uses. */
+mi_sparse_status_t mi_sparse_copy_out(mi_sparse_matrix_t A, int csc, int index_bytes, void *indptr, void *indices,
+                                      void *values);
 mi_sparse_status_t mi_sparse_get_device_csr(mi_sparse_matrix_t A, void **indptr, void **col_indx,
                                             void **values);
 

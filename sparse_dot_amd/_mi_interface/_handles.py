@@ -150,28 +150,18 @@ class SparseHandle:
             return ctor((rows, cols), dtype=dtype)
         wide = index_bytes == 8 or nnz > _INT32_MAX or max(rows, cols) > _INT32_MAX
         itype = _np.int64 if wide else _np.int32
-        ctype = _ct.c_int64 if wide else _ct.c_int32
-        name = "mi_sparse_%s_export_%s%s" % (letter, fmt, "_64" if wide else "")
-        base = _ct.c_int()
-        r, c = ctype(), ctype()
-        p_start, p_end, p_idx, p_val = _ct.c_void_p(), _ct.c_void_p(), _ct.c_void_p(), _ct.c_void_p()
-        ret = MI.call(name, self.ptr, _ct.byref(base), _ct.byref(r), _ct.byref(c), _ct.byref(p_start),
-                      _ct.byref(p_end), _ct.byref(p_idx), _ct.byref(p_val))
-        _check_return_value(ret, name)
-        if base.value != 0:
-            raise ValueError("1-indexing (F-style) is not supported")
         major = rows if fmt == "csr" else cols
-
-        def view(ptr, count, np_dtype):
-            buf = (_ct.c_char * (count * _np.dtype(np_dtype).itemsize)).from_address(ptr.value)
-            return _np.frombuffer(buf, dtype=np_dtype, count=count).copy()  # library memory dies with the handle
-
-        indptr = view(p_start, major + 1, itype)  # rows_end == rows_start + 1: one contiguous indptr
+        # one copy, device -> the arrays scipy will own (the MKL-shaped export entry points hand out library-owned
+        # buffers that would have to be copied a second time, as the reference does in _common.py:488-491)
+        indptr = _np.empty(major + 1, dtype=itype)
+        indices = _np.empty(nnz, dtype=itype)
+        data = _np.empty(nnz, dtype=dtype)
+        ret = MI.call("mi_sparse_copy_out", self.ptr, 1 if fmt == "csc" else 0, 8 if wide else 4, indptr.ctypes.data,
+                      indices.ctypes.data, data.ctypes.data)
+        _check_return_value(ret, "mi_sparse_copy_out")
         total = int(indptr[-1] - indptr[0])
-        if total < 0 or total > rows * cols:
+        if total != nnz or total < 0 or total > rows * cols:
             raise ValueError("Matrix (%d x %d) is attempting to index %d elements" % (rows, cols, total))
-        indices = view(p_idx, total, itype)
-        data = view(p_val, total, dtype)
         return ctor((data, indices, indptr), shape=(rows, cols))
 
 

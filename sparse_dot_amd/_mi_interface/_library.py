@@ -134,6 +134,7 @@ def _bind(lib):
     add("mi_sparse_syrk", [_int, H, HP])
     add("mi_sparse_get_info", [H, _ct.POINTER(_i64), _ct.POINTER(_i64), _ct.POINTER(_i64), _ct.c_char_p,
                                _ct.POINTER(_int)])
+    add("mi_sparse_copy_out", [H, _int, _int, _vp, _vp, _vp])
     add("mi_sparse_get_device_csr", [H, _ct.POINTER(_vp), _ct.POINTER(_vp), _ct.POINTER(_vp)])
     add("mi_sparse_get_version_string", [_ct.c_char_p, _int])
     add("mi_sparse_get_device_count", [], _int)

@@ -613,16 +613,14 @@ static void build_csr(Csr& out, int base, int64_t nrows, int64_t ncols, const I*
             out.col = out.col_own.as<int32_t>();
             if (cloc == Loc::Host && std::is_same<I, int32_t>::value && base == 0) {
                 if (nnz)
-                    MI_HIP_CHECK(hipMemcpyAsync(out.col, col_indx, sizeof(int32_t) * (size_t)nnz,
-                                                hipMemcpyHostToDevice, c.stream));
+                    copy_h2d(out.col, col_indx, sizeof(int32_t) * (size_t)nnz);
             } else {
                 const I* dcol = col_indx;
                 DevBuf ctmp;
                 if (cloc == Loc::Host) {
                     ctmp.alloc(sizeof(I) * (size_t)nnz);
                     if (nnz)
-                        MI_HIP_CHECK(hipMemcpyAsync(ctmp.p, col_indx, sizeof(I) * (size_t)nnz,
-                                                    hipMemcpyHostToDevice, c.stream));
+                        copy_h2d(ctmp.p, col_indx, sizeof(I) * (size_t)nnz);
                     dcol = ctmp.as<I>();
                 }
                 if (nnz)
@@ -639,9 +637,7 @@ static void build_csr(Csr& out, int base, int64_t nrows, int64_t ncols, const I*
         } else {
             out.val_own.alloc(sizeof(T) * (size_t)nnz);
             out.val = out.val_own.p;
-            if (nnz)
-                MI_HIP_CHECK(hipMemcpyAsync(out.val, values, sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice,
-                                            c.stream));
+            if (nnz) copy_h2d(out.val, values, sizeof(T) * (size_t)nnz);
             if (user_val) *user_val = const_cast<T*>(values);
         }
         MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // tmp (indptr staging) is released here
@@ -856,13 +852,13 @@ static int export_generic(mi_sparse_matrix_t A, bool csc, int* base, I* rows, I*
         MI_HIP_CHECK(hipMemcpyAsync(e.ptr.data(), dptr, sizeof(I) * (size_t)(m.rows + 1), hipMemcpyDeviceToHost, c.stream));
         if (m.nnz) {
             if (sizeof(I) == 4) {
-                MI_HIP_CHECK(hipMemcpyAsync(e.col.data(), m.col, sizeof(int32_t) * (size_t)m.nnz, hipMemcpyDeviceToHost, c.stream));
+                copy_d2h(e.col.data(), m.col, sizeof(int32_t) * (size_t)m.nnz);
             } else {
                 I* dcol = static_cast<I*>(c.scratch_alloc(sizeof(I) * (size_t)m.nnz));
                 MI_LAUNCH((k_export_col<I>), grid1d_stride(m.nnz, 256), dim3(256), c.stream, (const int32_t*)m.col, m.nnz, dcol);
-                MI_HIP_CHECK(hipMemcpyAsync(e.col.data(), dcol, sizeof(I) * (size_t)m.nnz, hipMemcpyDeviceToHost, c.stream));
+                copy_d2h(e.col.data(), dcol, sizeof(I) * (size_t)m.nnz);
             }
-            MI_HIP_CHECK(hipMemcpyAsync(e.val.data(), m.val, sizeof(T) * (size_t)m.nnz, hipMemcpyDeviceToHost, c.stream));
+            copy_d2h(e.val.data(), m.val, sizeof(T) * (size_t)m.nnz);
         }
         c.sync();
         if (base) *base = 0;
@@ -1072,6 +1068,43 @@ mi_sparse_status_t mi_sparse_get_info(mi_sparse_matrix_t A, int64_t* rows, int64
         if (nnz) *nnz = h->csr.valid ? h->csr.nnz : h->csrT.nnz;
         if (value_type) *value_type = h->vtype;
         if (index_bytes) *index_bytes = h->index_bytes;
+    });
+}
+
+mi_sparse_status_t mi_sparse_copy_out(mi_sparse_matrix_t A, int csc, int index_bytes, void* indptr, void* indices,
+                                      void* values)
+{
+    return mi::guarded([&] {
+        mi_sparse_matrix* h = mi::check_handle(A);
+        if (index_bytes != 4 && index_bytes != 8) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "index_bytes must be 4 or 8");
+        mi::Context& c = mi::ctx();
+        c.scratch_reset();
+        mi::Csr& m = csc ? mi::need_csrT(h) : mi::need_csr(h);
+        if (index_bytes == 4 && (m.nnz > INT32_MAX || h->rows > INT32_MAX || h->cols > INT32_MAX))
+            mi::fail(MI_SPARSE_STATUS_ALLOC_FAILED, "matrix with %lld entries does not fit 32-bit indices", (long long)m.nnz);
+        if (!indptr || (m.nnz && (!indices || !values))) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL output array");
+        const size_t vb = mi::value_bytes(h->vtype);
+        auto out = [&](void* dst, const void* src, size_t n) {
+            if (mi::locate(dst) == mi::Loc::Device) MI_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c.stream));
+            else mi::copy_d2h(dst, src, n);
+        };
+        if (index_bytes == 4) {
+            int32_t* dptr = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(m.rows + 1)));
+            MI_LAUNCH((mi::k_export_ptr<int32_t>), mi::grid1d(m.rows + 1, 256), dim3(256), c.stream, (const int64_t*)m.ptr,
+                      m.rows + 1, dptr);
+            out(indptr, dptr, sizeof(int32_t) * (size_t)(m.rows + 1));
+            if (m.nnz) out(indices, m.col, sizeof(int32_t) * (size_t)m.nnz);
+        } else {
+            out(indptr, m.ptr, sizeof(int64_t) * (size_t)(m.rows + 1));
+            if (m.nnz) {
+                int64_t* dcol = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)m.nnz));
+                MI_LAUNCH((mi::k_export_col<int64_t>), mi::grid1d_stride(m.nnz, 256), dim3(256), c.stream,
+                          (const int32_t*)m.col, m.nnz, dcol);
+                out(indices, dcol, sizeof(int64_t) * (size_t)m.nnz);
+            }
+        }
+        if (m.nnz) out(values, m.val, vb * (size_t)m.nnz);
+        c.sync();
     });
 }
 

@@ -1,6 +1,9 @@
 // runtime.hip -- errors, per-thread context, device memory, service entry points, scan.
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <map>
+#include <thread>
 
 #include "common.hpp"
 
@@ -258,6 +261,213 @@ void Context::sync()
     retired.clear();
 }
 
+// ---- parallel staged copies of pageable host memory ------------------------------------------------
+namespace {
+#ifndef MI_HIP_EMU
+class CopyEngine {
+public:
+    static constexpr size_t CHUNK = size_t(4) << 20;
+    static CopyEngine& get()
+    {
+        static CopyEngine* e = new CopyEngine();  // leaked on purpose (worker threads outlive static destruction)
+        return *e;
+    }
+    // kind 0: host -> device, 1: device -> host.  Blocks until every chunk has been handed to / taken from the DMA.
+    void run(int kind, char* host, char* dev, size_t n, int device, hipStream_t user_stream)
+    {
+        std::lock_guard<std::mutex> serial(api_);  // one transfer at a time: the slots belong to it
+        start_workers();
+        hipEvent_t after = nullptr;
+        if (kind == 1) {  // the data is produced by work enqueued on the caller's stream
+            MI_HIP_CHECK(hipEventCreateWithFlags(&after, hipEventDisableTiming));
+            MI_HIP_CHECK(hipEventRecord(after, user_stream));
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = Job{kind, host, dev, n, device, after};
+            next_chunk_.store(0);
+            nchunks_ = (n + CHUNK - 1) / CHUNK;
+            pending_ = (int)workers_.size();
+            failed_ = false;
+            ++generation_;
+        }
+        cv_.notify_all();
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            done_cv_.wait(lk, [&] { return pending_ == 0; });
+        }
+        if (after) (void)hipEventDestroy(after);
+        if (failed_) fail(MI_SPARSE_STATUS_EXECUTION_FAILED, "staged host/device copy failed: %s", err_);
+        if (kind == 0)  // order the caller's stream behind every worker's last transfer
+            for (auto& w : workers_)
+                if (w->last_valid) MI_HIP_CHECK(hipStreamWaitEvent(user_stream, w->last, 0));
+    }
+
+private:
+    struct Job {
+        int kind;
+        char* host;
+        char* dev;
+        size_t n;
+        int device;
+        hipEvent_t after;
+    };
+    struct Worker {
+        std::thread th;
+        int device = -1;
+        hipStream_t s = nullptr;
+        void* slot[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipEvent_t last = nullptr;
+        bool last_valid = false;
+    };
+    std::mutex api_, m_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<Worker*> workers_;
+    Job job_{};
+    std::atomic<size_t> next_chunk_{0};
+    size_t nchunks_ = 0;
+    int pending_ = 0;
+    unsigned long long generation_ = 0;
+    bool failed_ = false;
+    char err_[160] = {0};
+
+    void start_workers()
+    {
+        if (!workers_.empty()) return;
+        unsigned hw = std::thread::hardware_concurrency();
+        int nw = (int)(hw / 4);
+        if (nw < 2) nw = 2;
+        if (nw > 8) nw = 8;
+        for (int i = 0; i < nw; ++i) {
+            Worker* w = new Worker();
+            workers_.push_back(w);
+            w->th = std::thread([this, w] { loop(w); });
+            w->th.detach();
+        }
+    }
+    bool prepare(Worker* w, int device)
+    {
+        if (hipSetDevice(device) != hipSuccess) return false;
+        if (w->device == device) return true;
+        if (w->s) {  // moved to another device: rebuild the stream / events (slots are host memory, reusable)
+            (void)hipStreamDestroy(w->s);
+            for (int k = 0; k < 2; ++k) (void)hipEventDestroy(w->ev[k]);
+            (void)hipEventDestroy(w->last);
+        }
+        if (hipStreamCreateWithFlags(&w->s, hipStreamNonBlocking) != hipSuccess) return false;
+        for (int k = 0; k < 2; ++k) {
+            if (!w->slot[k] && hipHostMalloc(&w->slot[k], CHUNK, hipHostMallocDefault) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&w->ev[k], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        if (hipEventCreateWithFlags(&w->last, hipEventDisableTiming) != hipSuccess) return false;
+        w->device = device;
+        return true;
+    }
+    bool work(Worker* w, const Job& j)
+    {
+        if (!prepare(w, j.device)) return false;
+        w->last_valid = false;
+        if (j.kind == 1 && hipStreamWaitEvent(w->s, j.after, 0) != hipSuccess) return false;
+        size_t prev_off = 0, prev_len = 0;
+        int prev_k = -1, i = 0;
+        bool used[2] = {false, false};
+        for (;;) {
+            const size_t c = next_chunk_.fetch_add(1);
+            if (c >= nchunks_) break;
+            const size_t off = c * CHUNK, len = (off + CHUNK <= j.n) ? CHUNK : j.n - off;
+            const int k = i++ & 1;
+            if (j.kind == 0) {
+                if (used[k] && hipEventSynchronize(w->ev[k]) != hipSuccess) return false;  // slot free again?
+                memcpy(w->slot[k], j.host + off, len);
+                if (hipMemcpyAsync(j.dev + off, w->slot[k], len, hipMemcpyHostToDevice, w->s) != hipSuccess) return false;
+                if (hipEventRecord(w->ev[k], w->s) != hipSuccess) return false;
+                used[k] = true;
+            } else {
+                if (hipMemcpyAsync(w->slot[k], j.dev + off, len, hipMemcpyDeviceToHost, w->s) != hipSuccess) return false;
+                if (hipEventRecord(w->ev[k], w->s) != hipSuccess) return false;
+                if (prev_k >= 0) {  // drain the previous chunk while this one is in flight
+                    if (hipEventSynchronize(w->ev[prev_k]) != hipSuccess) return false;
+                    memcpy(j.host + prev_off, w->slot[prev_k], prev_len);
+                }
+                prev_k = k;
+                prev_off = off;
+                prev_len = len;
+            }
+        }
+        if (j.kind == 0) {
+            if (i) {
+                if (hipEventRecord(w->last, w->s) != hipSuccess) return false;
+                w->last_valid = true;
+            }
+        } else if (prev_k >= 0) {
+            if (hipEventSynchronize(w->ev[prev_k]) != hipSuccess) return false;
+            memcpy(j.host + prev_off, w->slot[prev_k], prev_len);
+        }
+        return true;
+    }
+    void loop(Worker* w)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                j = job_;
+            }
+            const bool ok = work(w, j);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!ok) {
+                    failed_ = true;
+                    snprintf(err_, sizeof(err_), "%s", hipGetErrorString(hipGetLastError()));
+                }
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+};
+#endif
+constexpr size_t STAGED_COPY_MIN = size_t(8) << 20;  // below this a plain (driver-staged) copy is as fast
+}  // namespace
+
+void copy_h2d(void* dst_dev, const void* src_host, size_t n)
+{
+    if (!n) return;
+    Context& c = ctx();
+    c.ensure();
+#ifndef MI_HIP_EMU
+    if (n >= STAGED_COPY_MIN && options().staged_copies) {
+        CopyEngine::get().run(0, const_cast<char*>(static_cast<const char*>(src_host)), static_cast<char*>(dst_dev), n,
+                              c.device, c.stream);
+        return;
+    }
+#endif
+    MI_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, n, hipMemcpyHostToDevice, c.stream));
+}
+
+void copy_d2h(void* dst_host, const void* src_dev, size_t n)
+{
+    Context& c = ctx();
+    c.ensure();
+    if (!n) {
+        c.sync();
+        return;
+    }
+#ifndef MI_HIP_EMU
+    if (n >= STAGED_COPY_MIN && options().staged_copies) {
+        CopyEngine::get().run(1, static_cast<char*>(dst_host), const_cast<char*>(static_cast<const char*>(src_dev)), n,
+                              c.device, c.stream);
+        c.sync();  // same post-condition as the plain path: the caller's stream is idle, retired arenas can go
+        return;
+    }
+#endif
+    MI_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, n, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+}
+
 // ---- pointer location --------------------------------------------------------------------------
 Loc locate(const void* p)
 {
@@ -292,14 +502,13 @@ void Staged::stage_in(const void* p, size_t n, bool copy_contents)
     host = const_cast<void*>(p);
     own.alloc(n);
     dev = own.p;
-    if (copy_contents && n) MI_HIP_CHECK(hipMemcpyAsync(dev, p, n, hipMemcpyHostToDevice, ctx().stream));
+    if (copy_contents && n) copy_h2d(dev, p, n);
 }
 
 void Staged::copy_back()
 {
     if (!host) return;
-    if (bytes) MI_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx().stream));
-    ctx().sync();
+    copy_d2h(host, dev, bytes);
 }
 
 Options& options()
@@ -520,6 +729,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
                 mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_slices must be 0 (automatic), 1, 2, 4 or 8");
             o.spmm_slices = value;
+        } else if (!strcmp(name, "staged_copies")) {
+            o.staged_copies = value;
         } else if (!strcmp(name, "spmm_plan_sync")) {
             o.spmm_plan_sync = value;
         } else if (!strcmp(name, "spmm_hot_force")) {
