@@ -28,17 +28,22 @@ constexpr int syrkd_tile() { return (int)(65536 / sizeof(T)); }  // 64 KiB of LD
 
 template <typename T>
 __global__ void __launch_bounds__(512)
-    k_syrkd_lds(int64_t n, int64_t row0, int64_t tiles_per_row, const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol,
+    k_syrkd_lds(int64_t n, int64_t row0, int64_t row_end, int64_t tiles_per_row, const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol,
                 const T* __restrict__ tval, const int64_t* __restrict__ xptr, const int32_t* __restrict__ xcol,
                 const T* __restrict__ xval, T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta,
                 int beta_zero)
 {
     constexpr int TILE = syrkd_tile<T>();
     __shared__ T acc[TILE];
-    const int64_t i = row0 + (int64_t)blockIdx.x / tiles_per_row;  // output row (C points at row `row0`)
-    const int64_t t = (int64_t)blockIdx.x % tiles_per_row;
+    // XCD-affine order: workgroup b runs on XCD b % 8 (observed; speed only).  All column tiles of one output row go
+    // to the SAME XCD, back to back, so the rows of X that the row's nonzeros select (the same for every tile) are
+    // fetched from HBM once and then served by that XCD's L2 -- with one tile per XCD in round-robin order every
+    // tile missed (rocprof: FETCH = 100 x the matrix at the literal configs[3]).
+    const int64_t q = (int64_t)(blockIdx.x >> 3);
+    const int64_t i = row0 + (q / tiles_per_row) * 8 + (int64_t)(blockIdx.x & 7u);  // output row (C points at row `row0`)
+    const int64_t t = q % tiles_per_row;
     const int64_t j_lo = i + t * TILE;
-    if (j_lo >= n) return;  // uniform for the whole workgroup
+    if (i >= row_end || j_lo >= n) return;  // uniform for the whole workgroup
     const int64_t j_hi = (j_lo + TILE < n) ? j_lo + TILE : n;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     for (int k = tid; k < (int)(j_hi - j_lo); k += nthreads) acc[k] = vt<T>::zero();
@@ -134,8 +139,9 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         sc.stage_in(C, sizeof(T) * (size_t)(row_major ? (nr - 1) * ldc + n : (n - 1) * ldc + nr), true);
         T* dC = static_cast<T*>(sc.dev);
         const int64_t tiles_per_row = ceil_div(n, (int64_t)syrkd_tile<T>());
-        if (nr * tiles_per_row > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "gram output too large for one launch");
-        MI_LAUNCH((k_syrkd_lds<T>), dim3((unsigned)(nr * tiles_per_row)), dim3(512), c.stream, n, row0, tiles_per_row,
+        const int64_t nblocks = ceil_div(nr, 8) * 8 * tiles_per_row;  // 8 rows (one per XCD) x all their tiles per group
+        if (nblocks > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "gram output too large for one launch");
+        MI_LAUNCH((k_syrkd_lds<T>), dim3((unsigned)nblocks), dim3(512), c.stream, n, row0, row1, tiles_per_row,
                   (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
                   (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero);
         MI_HIP_CHECK(hipGetLastError());

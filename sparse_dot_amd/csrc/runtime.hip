@@ -169,16 +169,50 @@ direct:
 }
 
 // ---- asynchronous device -> host words ------------------------------------------------------------
+namespace {
+// page-locked 64-byte slots carved out of one hipHostMalloc'd slab per 1024 slots: pinning host memory costs
+// ~1 ms per call, far too much to pay per plan
+struct PinnedSlots {
+    std::mutex m;
+    std::vector<int64_t*> free_list;
+    int64_t* take()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (free_list.empty()) {
+            void* slab = nullptr;
+            MI_HIP_CHECK(hipHostMalloc(&slab, 1024 * 64, hipHostMallocDefault));
+            for (int i = 0; i < 1024; ++i) free_list.push_back(reinterpret_cast<int64_t*>(static_cast<char*>(slab) + 64 * i));
+        }
+        int64_t* p = free_list.back();
+        free_list.pop_back();
+        return p;
+    }
+    void give(int64_t* p)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        free_list.push_back(p);
+    }
+};
+PinnedSlots& pinned_slots()
+{
+    static PinnedSlots* s = new PinnedSlots();  // leaked on purpose (HIP may be gone at static destruction)
+    return *s;
+}
+}  // namespace
+
 AsyncWord::~AsyncWord()
 {
-    if (ev) (void)hipEventDestroy(ev);
-    if (host) (void)hipHostFree(host);
+    if (ev) {
+        if (pending) (void)hipEventSynchronize(ev);  // the copy must not land in a slot that has been handed on
+        (void)hipEventDestroy(ev);
+    }
+    if (host) pinned_slots().give(host);
 }
 
 void AsyncWord::ensure()
 {
     if (host) return;
-    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host), 8 * sizeof(int64_t), hipHostMallocDefault));
+    host = pinned_slots().take();
     memset(host, 0, 8 * sizeof(int64_t));
     MI_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 }

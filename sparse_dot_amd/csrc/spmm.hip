@@ -612,26 +612,63 @@ __global__ void __launch_bounds__(1024)
     k_pick_threshold(const unsigned long long* __restrict__ hist, const unsigned long long* __restrict__ wsum,
                      int64_t hot_rows, int force, int64_t* __restrict__ decision)
 {
+    // suffix sums over the bins (4 bins per thread, then a block scan of the thread totals): N(k) = columns with
+    // count >= k, W(k) = nonzeros on them.  The threshold is the smallest k >= 1 whose set still fits the budget.
     __shared__ unsigned long long cnt[HOT_BINS], wt[HOT_BINS];
-    for (int k = threadIdx.x; k < HOT_BINS; k += 1024) {
-        cnt[k] = hist[k];
-        wt[k] = wsum[k];
+    __shared__ unsigned long long tn[1024], tw[1024];
+    __shared__ int best;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < HOT_BINS; k += 1024) {
+        cnt[k] = k ? hist[k] : 0ull;
+        wt[k] = k ? wsum[k] : 0ull;
+    }
+    if (tid == 0) best = HOT_BINS;
+    __syncthreads();
+    constexpr int PER = HOT_BINS / 1024;
+    // thread t owns bins [HOT_BINS - PER (t + 1), HOT_BINS - PER t): thread 0 the highest counts
+    unsigned long long ln = 0, lw = 0;
+    for (int u = 0; u < PER; ++u) {
+        const int k = HOT_BINS - 1 - (tid * PER + u);
+        ln += cnt[k];
+        lw += wt[k];
+    }
+    tn[tid] = ln;
+    tw[tid] = lw;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan: totals of the threads holding higher counts
+        unsigned long long a = 0, b = 0;
+        if (tid >= off) {
+            a = tn[tid - off];
+            b = tw[tid - off];
+        }
+        __syncthreads();
+        tn[tid] += a;
+        tw[tid] += b;
+        __syncthreads();
+    }
+    const unsigned long long total = tw[1023];
+    unsigned long long n_run = tn[tid] - ln, w_run = tw[tid] - lw;  // everything above this thread's bins
+    for (int u = 0; u < PER; ++u) {
+        const int k = HOT_BINS - 1 - (tid * PER + u);
+        n_run += cnt[k];
+        w_run += wt[k];
+        cnt[k] = n_run;  // now N(k)
+        wt[k] = w_run;   // now W(k)
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    unsigned long long total = 0;
-    for (int k = 1; k < HOT_BINS; ++k) total += wt[k];
-    // walk the thresholds from the top: the smallest count t whose set {count >= t} still fits the budget
-    unsigned long long n = 0, cov = 0;
-    int thr = HOT_BINS;  // nothing selected yet
-    for (int k = HOT_BINS - 1; k >= 1; --k) {
-        if (cnt[k] == 0) continue;
-        if ((int64_t)(n + cnt[k]) > hot_rows && n > 0) break;
-        n += cnt[k];
-        cov += wt[k];
-        thr = k;
-        if ((int64_t)n > hot_rows) break;  // a single over-full class (ties): judged below
+    // N is non-increasing in k: candidates are the k with a non-empty bin whose set fits; take the smallest.  A single
+    // over-full top class (ties) is accepted here and judged by the "2 x budget" rule below.
+    for (int u = 0; u < PER; ++u) {
+        const int k = HOT_BINS - 1 - (tid * PER + u);
+        if (k < 1) continue;
+        const unsigned long long above = (k + 1 < HOT_BINS) ? cnt[k + 1] : 0ull;
+        const bool nonempty = cnt[k] != above;
+        if (nonempty && ((int64_t)cnt[k] <= hot_rows || above == 0)) atomicMin(&best, k);
     }
+    __syncthreads();
+    if (tid != 0) return;
+    const int thr = best;
+    const unsigned long long n = thr < HOT_BINS ? cnt[thr] : 0ull, cov = thr < HOT_BINS ? wt[thr] : 0ull;
     const double share = total ? (double)cov / (double)total : 0.0;
     // worth it only when a small set takes a real share of the gather and ties did not blow the set up
     int flag = (thr < HOT_BINS && thr >= 2 && share >= 0.10 && (int64_t)n <= 2 * hot_rows) ? 1 : 0;

@@ -200,6 +200,12 @@ inline int atomicCAS(int* p, int cmp, int val)
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int atomicMin(int* p, int v)
+{
+    int old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return old;
+}
 inline long long atomicMax(long long* p, long long v)
 {
     long long old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
