@@ -64,13 +64,25 @@ typedef int mi_sparse_status_t;
 #define MI_SPARSE_INDEX_BASE_ZERO 0
 #define MI_SPARSE_INDEX_BASE_ONE 1
 #define MI_SPARSE_MATRIX_TYPE_GENERAL 20
+#define MI_SPARSE_MATRIX_TYPE_SYMMETRIC 21
+#define MI_SPARSE_FILL_MODE_LOWER 40
+#define MI_SPARSE_FILL_MODE_UPPER 41
+#define MI_SPARSE_DIAG_NON_UNIT 50
+/* stages of the two-stage product (== MKL sparse_request_t; reference _constants.py:49-53) */
+#define MI_SPARSE_STAGE_FULL_MULT 90
+#define MI_SPARSE_STAGE_NNZ_COUNT 91
+#define MI_SPARSE_STAGE_FINALIZE_MULT 92
+#define MI_SPARSE_STAGE_FULL_MULT_NO_VAL 93
+#define MI_SPARSE_STAGE_FINALIZE_MULT_NO_VAL 94
 
 /* opaque handle (== MKL sparse_matrix_t; reference _structs.py:5-9) */
 struct mi_sparse_matrix;
 typedef struct mi_sparse_matrix *mi_sparse_matrix_t;
 
 /* == MKL struct matrix_descr, passed BY VALUE (reference _structs.py:13-30).  Only
- * {type = GENERAL(20), mode = 0, diag = 0} -- what the reference always passes -- is accepted. */
+ * {type = GENERAL(20), mode = 0, diag = 0} -- what the reference always passes on the hot path -- is accepted
+ * there; mi_sparse_sypr takes {SYMMETRIC(21), FILL_MODE_UPPER(41), DIAG_NON_UNIT(50)} for B
+ * (reference _sparse_sypr.py:104-108). */
 struct mi_matrix_descr {
     int type;
     int mode;
@@ -315,6 +327,37 @@ mi_sparse_status_t mi_sparse_z_mv(int op, mi_complex16 alpha, mi_sparse_matrix_t
  * value cancels to 0.0 are kept, as MKL keeps them.  A and B must hold the same value type.
  * op must be 10 (the only value the reference passes). */
 mi_sparse_status_t mi_sparse_spmm(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, mi_sparse_matrix_t *C);
+
+/* mkl_sparse_sp2m (the two-stage API; MKL signature
+ *   mkl_sparse_sp2m(opA, descrA, A, opB, descrB, B, request, *C)):   C := op(A) * op(B)   with the symbolic and the
+ * numeric phase of the two-phase hash SpGEMM callable separately, so that a pattern is analysed once and reused:
+ *   request = NNZ_COUNT (91)              symbolic phase: *C is created, its row pointer and nnz are final
+ *             FINALIZE_MULT (92)          numeric phase on the *C of an earlier NNZ_COUNT: column indices + values;
+ *                                         may be repeated after mi_sparse_?_set_values on A / B (same patterns)
+ *             FINALIZE_MULT_NO_VAL (94)   as 92 (the indices come out of the same pass as the values here)
+ *             FULL_MULT (90), FULL_MULT_NO_VAL (93)   both phases, == mi_sparse_spmm for op = 10
+ * op = 10 / 11 (12 for real types); descriptors must be GENERAL.  A and B must be the same handles in every stage. */
+mi_sparse_status_t mi_sparse_sp2m(int op_a, struct mi_matrix_descr descr_a, mi_sparse_matrix_t A, int op_b,
+                                  struct mi_matrix_descr descr_b, mi_sparse_matrix_t B, int request,
+                                  mi_sparse_matrix_t *C);
+/* mkl_sparse_sypr (reference _sparse_sypr.py:87-135, dead upstream):  C := triu(op(A) * B * op(A)^T), B symmetric,
+ * given by its upper triangle (descr_b = {21, 41, 50}; entries below the diagonal are ignored), real types,
+ * request = FULL_MULT (90).  C is a new handle (sparse CSR, rows unsorted). */
+mi_sparse_status_t mi_sparse_sypr(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, struct mi_matrix_descr descr_b,
+                                  mi_sparse_matrix_t *C, int request);
+/* mkl_sparse_?_syprd (reference _sparse_sypr.py:29-84):  C := alpha * op(A) * B * op(A)^T + beta * C with a DENSE
+ * symmetric B (upper triangle referenced) and dense C; only the upper triangle of C is read or written. */
+mi_sparse_status_t mi_sparse_s_syprd(int op, mi_sparse_matrix_t A, const float *B, int layout_b, int64_t ldb,
+                                     float alpha, float beta, float *C, int layout_c, int64_t ldc);
+mi_sparse_status_t mi_sparse_d_syprd(int op, mi_sparse_matrix_t A, const double *B, int layout_b, int64_t ldb,
+                                     double alpha, double beta, double *C, int layout_c, int64_t ldc);
+/* Replace ALL values of a handle (storage order of the arrays it was created from; host or device pointer), keeping
+ * its pattern and its plans -- the analogue of updating the aliased value array in place under MKL
+ * (mkl_sparse_?_update_values): what makes NNZ_COUNT once / FINALIZE_MULT many times useful. */
+mi_sparse_status_t mi_sparse_s_set_values(mi_sparse_matrix_t A, const float *values);
+mi_sparse_status_t mi_sparse_d_set_values(mi_sparse_matrix_t A, const double *values);
+mi_sparse_status_t mi_sparse_c_set_values(mi_sparse_matrix_t A, const mi_complex8 *values);
+mi_sparse_status_t mi_sparse_z_set_values(mi_sparse_matrix_t A, const mi_complex16 *values);
 
 /* mkl_sparse_?_spmmd (reference _cfunctions.py:601-609; call site _sparse_sparse.py:94-101)
  *     dense C := op(A) * B (C is overwritten; there is no beta). */

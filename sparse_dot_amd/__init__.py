@@ -16,4 +16,7 @@ from ._mi_interface import (  # noqa: F401
     mi_get_counter, mi_interface_integer_dtype, DeviceMatrix, to_device,
 )
 
+from ._sparse_sypr import _sparse_sypr as sparse_sypr  # noqa: F401,E402  (reference _sparse_sypr.py, dead upstream)
+from ._sparse_staged import StagedProduct  # noqa: F401,E402
+
 get_version_string = mi_get_version_string

@@ -119,9 +119,11 @@ def _bind(lib):
         add("mi_sparse_%s_mm" % t, [_int, sc, H, matrix_descr, _int, _vp, _i64, _i64, sc, _vp, _i64])
         add("mi_sparse_%s_mv" % t, [_int, sc, H, matrix_descr, _vp, sc, _vp])
         add("mi_sparse_%s_spmmd" % t, [_int, H, H, _int, _vp, _i64])
+        add("mi_sparse_%s_set_values" % t, [H, _vp])
     for t in "sd":
         sc = SCALAR_CTYPE[t]
         add("mi_sparse_%s_syrkd" % t, [_int, H, sc, sc, _vp, _int, _i64])
+        add("mi_sparse_%s_syprd" % t, [_int, H, _vp, _int, _i64, sc, sc, _vp, _int, _i64])
         add("mi_sparse_%s_syrkd_rows" % t, [_int, H, sc, sc, _vp, _int, _i64, _i64, _i64])
         add("mi_cblas_%sgemm" % t, [_int, _int, _int, _i64, _i64, _i64, sc, _vp, _i64, _vp, _i64, sc, _vp, _i64])
         add("mi_cblas_%ssyrk" % t, [_int, _int, _int, _i64, _i64, sc, _vp, _i64, sc, _vp, _i64])
@@ -132,6 +134,8 @@ def _bind(lib):
     add("mi_sparse_convert_csr", [H, _int, HP])
     add("mi_sparse_spmm", [_int, H, H, HP])
     add("mi_sparse_syrk", [_int, H, HP])
+    add("mi_sparse_sp2m", [_int, matrix_descr, H, _int, matrix_descr, H, _int, HP])
+    add("mi_sparse_sypr", [_int, H, H, matrix_descr, HP, _int])
     add("mi_sparse_get_info", [H, _ct.POINTER(_i64), _ct.POINTER(_i64), _ct.POINTER(_i64), _ct.c_char_p,
                                _ct.POINTER(_int)])
     add("mi_sparse_copy_out", [H, _int, _int, _vp, _vp, _vp])

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -361,6 +362,7 @@ struct mi_sparse_matrix {
     int user_base = 0;
     mi::SpmmPlan plan, planT;
     mi::HostExport exp_csr, exp_csc;
+    std::shared_ptr<void> staged;  // result handles of the staged product (mi_sparse_sp2m): symbolic-phase state
     std::mutex mtx;  // guards lazy derivation of csr / csrT / plans
 };
 

@@ -1065,7 +1065,7 @@ mi_sparse_status_t mi_sparse_get_info(mi_sparse_matrix_t A, int64_t* rows, int64
         mi_sparse_matrix* h = mi::check_handle(A);
         if (rows) *rows = h->rows;
         if (cols) *cols = h->cols;
-        if (nnz) *nnz = h->csr.valid ? h->csr.nnz : h->csrT.nnz;
+        if (nnz) *nnz = (h->csr.valid || h->staged) ? h->csr.nnz : h->csrT.nnz;  // staged: nnz is final after NNZ_COUNT
         if (value_type) *value_type = h->vtype;
         if (index_bytes) *index_bytes = h->index_bytes;
     });

@@ -354,6 +354,7 @@ private:
         hipEvent_t ev[2] = {nullptr, nullptr};
         hipEvent_t last = nullptr;
         bool last_valid = false;
+        bool busy[2] = {false, false};  // an H2D transfer out of the slot has been enqueued and not yet waited for
     };
     std::mutex api_, m_;
     std::condition_variable cv_, done_cv_;
@@ -385,6 +386,8 @@ private:
         if (hipSetDevice(device) != hipSuccess) return false;
         if (w->device == device) return true;
         if (w->s) {  // moved to another device: rebuild the stream / events (slots are host memory, reusable)
+            (void)hipStreamSynchronize(w->s);
+            w->busy[0] = w->busy[1] = false;
             (void)hipStreamDestroy(w->s);
             for (int k = 0; k < 2; ++k) (void)hipEventDestroy(w->ev[k]);
             (void)hipEventDestroy(w->last);
@@ -405,18 +408,21 @@ private:
         if (j.kind == 1 && hipStreamWaitEvent(w->s, j.after, 0) != hipSuccess) return false;
         size_t prev_off = 0, prev_len = 0;
         int prev_k = -1, i = 0;
-        bool used[2] = {false, false};
         for (;;) {
             const size_t c = next_chunk_.fetch_add(1);
             if (c >= nchunks_) break;
             const size_t off = c * CHUNK, len = (off + CHUNK <= j.n) ? CHUNK : j.n - off;
             const int k = i++ & 1;
+            // the slot may still feed a transfer of THIS or of an EARLIER job (H2D jobs return once enqueued)
+            if (w->busy[k]) {
+                if (hipEventSynchronize(w->ev[k]) != hipSuccess) return false;
+                w->busy[k] = false;
+            }
             if (j.kind == 0) {
-                if (used[k] && hipEventSynchronize(w->ev[k]) != hipSuccess) return false;  // slot free again?
                 memcpy(w->slot[k], j.host + off, len);
                 if (hipMemcpyAsync(j.dev + off, w->slot[k], len, hipMemcpyHostToDevice, w->s) != hipSuccess) return false;
                 if (hipEventRecord(w->ev[k], w->s) != hipSuccess) return false;
-                used[k] = true;
+                w->busy[k] = true;
             } else {
                 if (hipMemcpyAsync(w->slot[k], j.dev + off, len, hipMemcpyDeviceToHost, w->s) != hipSuccess) return false;
                 if (hipEventRecord(w->ev[k], w->s) != hipSuccess) return false;

@@ -15,6 +15,7 @@
 // Entries that cancel to 0.0 stay (MKL keeps them; scipy prunes -- SURVEY section 8 a3).
 #include "common.hpp"
 #include <chrono>
+#include <memory>
 
 namespace mi {
 
@@ -1279,9 +1280,19 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
     MI_HIP_CHECK(hipGetLastError());
 }
 
-// C := A * B (or its upper triangle).  C's storage is allocated here.
+// What the symbolic phase computes and the numeric phase consumes.  Kept on the result handle by the staged
+// (sp2m-style) API so that the numeric phase can be repeated for new values on an unchanged pattern.
+struct SpgemmSymbolic {
+    BigRows big;
+    DevBuf row_nnz;        // int64[rows + 1]: exact length of every row of C
+    int upper_mode = 0;
+    int64_t max_nnz = 0;   // longest row of C
+    bool done = false;
+};
+
+// Phase 1: row pointer of C (C.ptr, C.nnz) -- upper bounds, binning, symbolic hash / bitmap kernels, scan.
 template <typename T>
-static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
+static void spgemm_symbolic(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st)
 {
     Context& c = ctx();
     const bool trace = options().trace_phases != 0;
@@ -1298,9 +1309,10 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
              (long long)A.cols, (long long)B.rows, (long long)B.cols);
     // upper triangle of a product with sorted B rows: the part of every B row left of the diagonal is skipped
     // by a search instead of being read and dropped (half of the products of a gram matrix)
-    BigRows big;
+    BigRows& big = st.big;
+    big = BigRows();
     big.b_sorted = rows_sorted(B);
-    const int upper_mode = upper ? (big.b_sorted ? 2 : 1) : 0;
+    st.upper_mode = upper ? (big.b_sorted ? 2 : 1) : 0;
     // table of the numeric big-row kernel: 2048 slots (1024 for complex double) give the best occupancy on wide
     // power-law products; a narrow B (dense-ish result rows, few ranges per row) is better off with twice that
     big.log2s = (sizeof(T) >= 16 ? 10 : 11) + (B.cols <= 65536 ? 1 : 0) + (int)options().spgemm_part_log2s_bias;
@@ -1312,34 +1324,132 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
     C.ptr_own.alloc(sizeof(int64_t) * (size_t)(C.rows + 1));
     C.ptr = C.ptr_own.as<int64_t>();
     int64_t* ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
-    int64_t* row_nnz = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
+    st.row_nnz.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
+    int64_t* row_nnz = st.row_nnz.as<int64_t>();
     MI_HIP_CHECK(hipMemsetAsync(row_nnz, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
     if (A.rows > 0)
         MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows,
-                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, upper_mode, ub);
+                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, ub);
     const int64_t max_ub = device_max(ub, A.rows);
     mark("row upper bounds");
-    run_phase<T, false>(A, B, upper_mode, ub, max_ub, row_nnz, nullptr, nullptr, nullptr, big);
+    run_phase<T, false>(A, B, st.upper_mode, ub, max_ub, row_nnz, nullptr, nullptr, nullptr, big);
     mark("symbolic");
-    const int64_t nnz = exclusive_scan_i64(row_nnz, C.ptr, C.rows);
-    C.nnz = nnz;
-    C.col_own.alloc(sizeof(int32_t) * (size_t)nnz);
-    C.val_own.alloc(sizeof(T) * (size_t)nnz);
+    C.nnz = exclusive_scan_i64(row_nnz, C.ptr, C.rows);
+    st.max_nnz = C.nnz > 0 ? device_max(row_nnz, A.rows) : 0;
+    C.col = nullptr;
+    C.val = nullptr;
+    C.valid = false;
+    st.done = true;
+    mark("scan");
+}
+
+// Phase 2: column indices and values of C (storage allocated on the first run; repeatable).
+template <typename T>
+static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st)
+{
+    Context& c = ctx();
+    if (!st.done) fail(MI_SPARSE_STATUS_INVALID_VALUE, "numeric SpGEMM phase requested before the symbolic one");
+    if (!C.col_own.p || C.col_own.bytes < sizeof(int32_t) * (size_t)C.nnz) C.col_own.alloc(sizeof(int32_t) * (size_t)C.nnz);
+    if (!C.val_own.p || C.val_own.bytes < sizeof(T) * (size_t)C.nnz) C.val_own.alloc(sizeof(T) * (size_t)C.nnz);
     C.col = C.col_own.as<int32_t>();
     C.val = C.val_own.p;
-    mark("scan + allocate C");
-    if (nnz > 0) {
-        const int64_t max_nnz = device_max(row_nnz, A.rows);
-        run_phase<T, true>(A, B, upper_mode, row_nnz, max_nnz, nullptr, C.ptr, C.col, static_cast<T*>(C.val), big);
+    if (C.nnz > 0)
+        run_phase<T, true>(A, B, st.upper_mode, st.row_nnz.as<int64_t>(), st.max_nnz, nullptr, C.ptr, C.col,
+                           static_cast<T*>(C.val), st.big);
+    if (options().trace_phases) {
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+        fprintf(stderr, "[mi_sparse spgemm] numeric done\n");
     }
-    mark("numeric");
     C.valid = true;
     C.sorted = false;
+}
+
+// C := A * B (or its upper triangle).  C's storage is allocated here.
+template <typename T>
+static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
+{
+    SpgemmSymbolic st;
+    spgemm_symbolic<T>(A, B, upper, C, st);
+    spgemm_numeric<T>(A, B, C, st);
 }
 
 void spgemm(char vtype, const Csr& A, const Csr& B, bool upper, Csr& C)
 {
     by_type(vtype, [&](auto tag) { spgemm_typed<decltype(tag)>(A, B, upper, C); });
+}
+
+// ---- staged product (mkl_sparse_sp2m analogue) -------------------------------------------------------------
+// request codes are MKL's (reference _constants.py:49-53)
+constexpr int STAGE_FULL_MULT = 90, STAGE_NNZ_COUNT = 91, STAGE_FINALIZE_MULT = 92, STAGE_FULL_MULT_NO_VAL = 93,
+              STAGE_FINALIZE_MULT_NO_VAL = 94;
+
+struct Sp2mState {
+    SpgemmSymbolic sym;
+    const mi_sparse_matrix* a = nullptr;  // operands the pattern was computed for (identity check only)
+    const mi_sparse_matrix* b = nullptr;
+    int op_a = 0, op_b = 0;
+    bool upper = false;
+};
+
+static Csr& operand_csr(mi_sparse_matrix* h, int op)
+{
+    if (op == MI_SPARSE_OPERATION_NON_TRANSPOSE) return need_csr(h);
+    if (op == MI_SPARSE_OPERATION_TRANSPOSE || (op == MI_SPARSE_OPERATION_CONJUGATE_TRANSPOSE && h->vtype != 'c' && h->vtype != 'z'))
+        return need_csrT(h);
+    fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "operation code %d is not supported for this value type", op);
+}
+
+// Runs the stages `request` asks for on result handle *C (created here for the stages that start a product).
+static void sp2m_run(int op_a, mi_sparse_matrix* ha, int op_b, mi_sparse_matrix* hb, bool upper, int request,
+                     mi_sparse_matrix_t* C)
+{
+    if (ha->vtype != hb->vtype) fail(MI_SPARSE_STATUS_INVALID_VALUE, "operands hold different value types");
+    const bool starts = request == STAGE_FULL_MULT || request == STAGE_NNZ_COUNT || request == STAGE_FULL_MULT_NO_VAL;
+    const bool finishes = request != STAGE_NNZ_COUNT;
+    if (!starts && request != STAGE_FINALIZE_MULT && request != STAGE_FINALIZE_MULT_NO_VAL)
+        fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad request code %d", request);
+    ctx().scratch_reset();
+    Csr& a = operand_csr(ha, op_a);
+    Csr& b = operand_csr(hb, op_b);
+    mi_sparse_matrix* r = nullptr;
+    std::shared_ptr<Sp2mState> st;
+    bool created = false;
+    if (starts) {
+        const int ib = ha->index_bytes > hb->index_bytes ? ha->index_bytes : hb->index_bytes;
+        r = new_result_handle(ha->vtype, ib, a.rows, b.cols);
+        created = true;
+        st = std::make_shared<Sp2mState>();
+        st->a = ha;
+        st->b = hb;
+        st->op_a = op_a;
+        st->op_b = op_b;
+        st->upper = upper;
+        r->staged = st;
+    } else {
+        r = check_handle(*C);
+        st = std::static_pointer_cast<Sp2mState>(r->staged);
+        if (!st || !st->sym.done)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "FINALIZE requested on a handle that did not go through NNZ_COUNT");
+        if (st->a != ha || st->b != hb || st->op_a != op_a || st->op_b != op_b)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "FINALIZE requested with other operands than NNZ_COUNT");
+        if (a.rows != r->rows || b.cols != r->cols || a.cols != b.rows)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "operand shapes changed since NNZ_COUNT");
+    }
+    try {
+        by_type(ha->vtype, [&](auto tag) {
+            using T = decltype(tag);
+            if (starts) spgemm_symbolic<T>(a, b, upper, r->csr, st->sym);
+            if (finishes) spgemm_numeric<T>(a, b, r->csr, st->sym);
+        });
+        ctx().sync();
+    } catch (...) {
+        if (created) {
+            r->magic = 0;
+            delete r;
+        }
+        throw;
+    }
+    *C = r;
 }
 
 template <typename T>
@@ -1376,6 +1486,169 @@ static int spmmd_generic(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, int
                   (const T*)b.val, static_cast<T*>(sc.dev), c_rs, c_cs);
         MI_HIP_CHECK(hipGetLastError());
         sc.copy_back();
+    });
+}
+
+// ---- A B A^T with symmetric B (mkl_sparse_sypr analogue) -----------------------------------------------------
+// Only the UPPER triangle of B is referenced (descr: symmetric, fill mode upper).  The full symmetric matrix is
+// laid out once -- row i = { B^T[i, k] : k < i } followed by { B[i, j] : j >= i } (sorted when B's rows are) --
+// and the product is two SpGEMMs, the second one restricted to the upper triangle.
+__global__ void k_sym_count(int64_t n, const int64_t* __restrict__ uptr, const int32_t* __restrict__ ucol,
+                            const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol, int64_t* __restrict__ len)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t c = 0;
+    for (int64_t p = uptr[i]; p < uptr[i + 1]; ++p) c += ucol[p] >= i;
+    for (int64_t p = tptr[i]; p < tptr[i + 1]; ++p) c += tcol[p] < i;
+    len[i] = c;
+}
+template <typename T>
+__global__ void k_sym_fill(int64_t n, const int64_t* __restrict__ uptr, const int32_t* __restrict__ ucol,
+                           const T* __restrict__ uval, const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol,
+                           const T* __restrict__ tval, const int64_t* __restrict__ optr, int32_t* __restrict__ ocol,
+                           T* __restrict__ oval)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t o = optr[i];
+    for (int64_t p = tptr[i]; p < tptr[i + 1]; ++p)
+        if (tcol[p] < i) {
+            ocol[o] = tcol[p];
+            oval[o++] = tval[p];
+        }
+    for (int64_t p = uptr[i]; p < uptr[i + 1]; ++p)
+        if (ucol[p] >= i) {
+            ocol[o] = ucol[p];
+            oval[o++] = uval[p];
+        }
+}
+
+template <typename T>
+static void symmetric_expand(const Csr& u, const Csr& ut, Csr& out)
+{
+    Context& c = ctx();
+    const int64_t n = u.rows;
+    out.rows = out.cols = n;
+    out.ptr_own.alloc(sizeof(int64_t) * (size_t)(n + 1));
+    out.ptr = out.ptr_own.as<int64_t>();
+    int64_t* len = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n + 1)));
+    if (n)
+        MI_LAUNCH(k_sym_count, dim3((unsigned)ceil_div(n, 256)), dim3(256), c.stream, n, (const int64_t*)u.ptr,
+                  (const int32_t*)u.col, (const int64_t*)ut.ptr, (const int32_t*)ut.col, len);
+    out.nnz = exclusive_scan_i64(len, out.ptr, n);
+    out.col_own.alloc(sizeof(int32_t) * (size_t)out.nnz);
+    out.val_own.alloc(sizeof(T) * (size_t)out.nnz);
+    out.col = out.col_own.as<int32_t>();
+    out.val = out.val_own.p;
+    if (n)
+        MI_LAUNCH((k_sym_fill<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), c.stream, n, (const int64_t*)u.ptr,
+                  (const int32_t*)u.col, (const T*)u.val, (const int64_t*)ut.ptr, (const int32_t*)ut.col, (const T*)ut.val,
+                  (const int64_t*)out.ptr, out.col, static_cast<T*>(out.val));
+    out.valid = true;
+    out.sorted = u.sorted && ut.sorted;
+}
+
+// dense symmetric operand given by its upper triangle -> full square, row-major, ld = n
+template <typename T>
+__global__ void k_sym_dense(int64_t n, const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n) return;
+    const int64_t i = t / n, j = t % n;
+    out[t] = (j >= i) ? B[i * b_rs + j * b_cs] : B[j * b_rs + i * b_cs];
+}
+// C(upper) := alpha * P + beta * C(upper);  P full n x n row-major, ld = n
+template <typename T>
+__global__ void k_axpby_upper(int64_t n, const T* __restrict__ P, T alpha, T beta, int beta_zero, T* __restrict__ C,
+                              int64_t c_rs, int64_t c_cs)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n) return;
+    const int64_t i = t / n, j = t % n;
+    if (j < i) return;
+    T* c = C + i * c_rs + j * c_cs;
+    *c = beta_zero ? alpha * P[t] : alpha * P[t] + beta * (*c);
+}
+
+template <typename T>
+void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a, T alpha, int layout, const T* B,
+                 int64_t N, int64_t ldb, T beta, T* C, int64_t ldc);  // spmm.hip
+
+template <typename T>
+static int syprd_generic(int op, mi_sparse_matrix_t A, const T* B, int layout_b, int64_t ldb, T alpha, T beta, T* C,
+                         int layout_c, int64_t ldc)
+{
+    return guarded([&] {
+        mi_sparse_matrix* h = check_handle(A);
+        if (h->vtype != type_char<T>::value)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "handle holds '%c' values but the '%c' routine was called", h->vtype,
+                 type_char<T>::value);
+        if (op != MI_SPARSE_OPERATION_NON_TRANSPOSE && op != MI_SPARSE_OPERATION_TRANSPOSE)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad operation code %d", op);
+        for (int l : {layout_b, layout_c})
+            if (l != MI_SPARSE_LAYOUT_ROW_MAJOR && l != MI_SPARSE_LAYOUT_COLUMN_MAJOR)
+                fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad layout code %d", l);
+        const bool trans = op == MI_SPARSE_OPERATION_TRANSPOSE;
+        const int64_t m = trans ? h->cols : h->rows, k = trans ? h->rows : h->cols;  // op(A) is m x k, B k x k, C m x m
+        if (m == 0) return;
+        if (!C || (!B && k > 0)) fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL dense operand");
+        if (ldb < k || ldc < m) fail(MI_SPARSE_STATUS_INVALID_VALUE, "leading dimension too small");
+        Context& c = ctx();
+        c.scratch_reset();
+        Csr& a = trans ? need_csrT(h) : need_csr(h);  // CSR of op(A)
+        const bool brm = layout_b == MI_SPARSE_LAYOUT_ROW_MAJOR, crm = layout_c == MI_SPARSE_LAYOUT_ROW_MAJOR;
+        Staged sb, sc;
+        sb.stage_in(B, sizeof(T) * (size_t)(k ? (k - 1) * ldb + k : 0), true);
+        sc.stage_in(C, sizeof(T) * (size_t)((m - 1) * ldc + m), true);
+        T* bs = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)(k * k + 1)));
+        T* y = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)(m * k + 1)));
+        T* p = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)(m * m + 1)));
+        if (k)
+            MI_LAUNCH((k_sym_dense<T>), dim3((unsigned)ceil_div(k * k, 256)), dim3(256), c.stream, k,
+                      static_cast<const T*>(sb.dev), brm ? ldb : (int64_t)1, brm ? (int64_t)1 : ldb, bs);
+        // Y = op(A) Bsym  (m x k, row-major);  P = op(A) Y^T: Y read as a k x m column-major operand, P written
+        // column-major (= its own transpose, P is symmetric)
+        spmm_device<T>(h, trans, a, 0, vt<T>::one(), MI_SPARSE_LAYOUT_ROW_MAJOR, bs, k, k, vt<T>::zero(), y, k);
+        if (k == 0) MI_HIP_CHECK(hipMemsetAsync(p, 0, sizeof(T) * (size_t)(m * m), c.stream));
+        else spmm_device<T>(h, trans, a, 0, vt<T>::one(), MI_SPARSE_LAYOUT_COLUMN_MAJOR, y, m, k, vt<T>::zero(), p, m);
+        MI_LAUNCH((k_axpby_upper<T>), dim3((unsigned)ceil_div(m * m, 256)), dim3(256), c.stream, m, (const T*)p, alpha, beta,
+                  (int)(vt<T>::is_zero(beta) ? 1 : 0), static_cast<T*>(sc.dev), crm ? ldc : (int64_t)1,
+                  crm ? (int64_t)1 : ldc);
+        MI_HIP_CHECK(hipGetLastError());
+        if (sb.host) c.sync();
+        sc.copy_back();
+    });
+}
+
+template <typename T>
+static int set_values_generic(mi_sparse_matrix_t A, const T* values)
+{
+    return guarded([&] {
+        mi_sparse_matrix* h = check_handle(A);
+        if (h->vtype != type_char<T>::value)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "handle holds '%c' values but the '%c' routine was called", h->vtype,
+                 type_char<T>::value);
+        if (!values) fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL value array");
+        Context& c = ctx();
+        c.scratch_reset();
+        const bool created_csc = (h->origin == 'c');
+        Csr& primary = created_csc ? need_csrT(h) : need_csr(h);
+        if (h->origin == 'b') fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "set_values on a handle created from BSR arrays");
+        if (!primary.val_own.p) {  // values were aliased from caller memory: take ownership of a copy first
+            primary.val_own.alloc(sizeof(T) * (size_t)primary.nnz);
+            primary.val = primary.val_own.p;
+        }
+        if (primary.nnz) {
+            if (locate(values) == Loc::Device)
+                MI_HIP_CHECK(hipMemcpyAsync(primary.val, values, sizeof(T) * (size_t)primary.nnz, hipMemcpyDeviceToDevice, c.stream));
+            else
+                copy_h2d(primary.val, values, sizeof(T) * (size_t)primary.nnz);
+        }
+        // the derived representation (and nothing else: plans depend on the pattern only) is stale
+        Csr& other = created_csc ? h->csr : h->csrT;
+        other = Csr();
+        c.sync();
     });
 }
 
@@ -1463,6 +1736,84 @@ mi_sparse_status_t mi_sparse_z_spmmd(int op, mi_sparse_matrix_t A, mi_sparse_mat
                                      int64_t ldc)
 {
     return mi::spmmd_generic<cdouble>(op, A, B, layout, (cdouble*)C, ldc);
+}
+
+mi_sparse_status_t mi_sparse_sp2m(int op_a, struct mi_matrix_descr descr_a, mi_sparse_matrix_t A, int op_b,
+                                  struct mi_matrix_descr descr_b, mi_sparse_matrix_t B, int request, mi_sparse_matrix_t* C)
+{
+    return mi::guarded([&] {
+        if (!C) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL output handle pointer");
+        if (descr_a.type != MI_SPARSE_MATRIX_TYPE_GENERAL || descr_b.type != MI_SPARSE_MATRIX_TYPE_GENERAL)
+            mi::fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "sp2m supports SPARSE_MATRIX_TYPE_GENERAL descriptors only");
+        mi::sp2m_run(op_a, mi::check_handle(A), op_b, mi::check_handle(B), false, request, C);
+    });
+}
+
+mi_sparse_status_t mi_sparse_sypr(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, struct mi_matrix_descr descr_b,
+                                  mi_sparse_matrix_t* C, int request)
+{
+    return mi::guarded([&] {
+        if (!C) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL output handle pointer");
+        *C = nullptr;
+        mi_sparse_matrix* ha = mi::check_handle(A);
+        mi_sparse_matrix* hb = mi::check_handle(B);
+        if (request != mi::STAGE_FULL_MULT) mi::fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "sypr supports SPARSE_STAGE_FULL_MULT only");
+        if (descr_b.type != MI_SPARSE_MATRIX_TYPE_SYMMETRIC || descr_b.mode != MI_SPARSE_FILL_MODE_UPPER)
+            mi::fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "sypr needs B described as symmetric with the upper triangle stored");
+        if (op != MI_SPARSE_OPERATION_NON_TRANSPOSE && op != MI_SPARSE_OPERATION_TRANSPOSE)
+            mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "bad operation code %d", op);
+        if (ha->vtype != hb->vtype) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "operands hold different value types");
+        if (ha->vtype == 'c' || ha->vtype == 'z') mi::fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "sypr supports real values only");
+        const bool trans = op == MI_SPARSE_OPERATION_TRANSPOSE;
+        if (hb->rows != hb->cols || (trans ? ha->rows : ha->cols) != hb->rows)
+            mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "dimension mismatch: op(A) is %lld x %lld, B is %lld x %lld",
+                     (long long)(trans ? ha->cols : ha->rows), (long long)(trans ? ha->rows : ha->cols),
+                     (long long)hb->rows, (long long)hb->cols);
+        mi::ctx().scratch_reset();
+        mi::Csr& x = trans ? mi::need_csrT(ha) : mi::need_csr(ha);   // op(A)
+        mi::Csr& xt = trans ? mi::need_csr(ha) : mi::need_csrT(ha);  // op(A)^T
+        mi::Csr& u = mi::need_csr(hb);
+        mi::Csr& ut = mi::need_csrT(hb);
+        const int64_t m = x.rows;
+        mi_sparse_matrix* r = mi::new_result_handle(ha->vtype, ha->index_bytes, m, m);
+        try {
+            mi::Csr full, t;
+            mi::by_type(ha->vtype, [&](auto tag) {
+                using T = decltype(tag);
+                if constexpr (!mi::vt<T>::is_complex) mi::symmetric_expand<T>(u, ut, full);
+            });
+            mi::spgemm(ha->vtype, x, full, false, t);        // T = op(A) Bsym
+            mi::spgemm(ha->vtype, t, xt, true, r->csr);      // C = triu(T op(A)^T)
+            mi::ctx().sync();
+        } catch (...) {
+            r->magic = 0;
+            delete r;
+            throw;
+        }
+        *C = r;
+    });
+}
+
+mi_sparse_status_t mi_sparse_s_syprd(int op, mi_sparse_matrix_t A, const float* B, int layout_b, int64_t ldb, float alpha,
+                                     float beta, float* C, int layout_c, int64_t ldc)
+{
+    return mi::syprd_generic<float>(op, A, B, layout_b, ldb, alpha, beta, C, layout_c, ldc);
+}
+mi_sparse_status_t mi_sparse_d_syprd(int op, mi_sparse_matrix_t A, const double* B, int layout_b, int64_t ldb, double alpha,
+                                     double beta, double* C, int layout_c, int64_t ldc)
+{
+    return mi::syprd_generic<double>(op, A, B, layout_b, ldb, alpha, beta, C, layout_c, ldc);
+}
+
+mi_sparse_status_t mi_sparse_s_set_values(mi_sparse_matrix_t A, const float* values) { return mi::set_values_generic<float>(A, values); }
+mi_sparse_status_t mi_sparse_d_set_values(mi_sparse_matrix_t A, const double* values) { return mi::set_values_generic<double>(A, values); }
+mi_sparse_status_t mi_sparse_c_set_values(mi_sparse_matrix_t A, const mi_complex8* values)
+{
+    return mi::set_values_generic<cfloat>(A, (const cfloat*)values);
+}
+mi_sparse_status_t mi_sparse_z_set_values(mi_sparse_matrix_t A, const mi_complex16* values)
+{
+    return mi::set_values_generic<cdouble>(A, (const cdouble*)values);
 }
 
 }  // extern "C"

@@ -1,0 +1,108 @@
+"""GPU: SURVEY section 8 f4 -- the two-stage (symbolic / numeric) product mi_sparse_sp2m with pattern reuse, and the
+symmetric triple products mi_sparse_sypr / mi_sparse_?_syprd (reference _sparse_sypr.py, dead upstream: the oracle
+here is scipy / numpy on the same operands, structure bit-exact after ordering)."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(dtype):
+    return 1e-5 if np.dtype(dtype) == np.float32 else 1e-12
+
+
+def _pos(m, n, density, dtype, seed):
+    a = sps.random(m, n, density=density, format="csr", dtype=np.float64, random_state=seed)
+    a.data[:] = np.random.default_rng(seed + 7).uniform(0.5, 1.5, a.nnz)
+    return a.astype(dtype)
+
+
+def _same(got, want, dtype):
+    want = want.tocsr()
+    want.sort_indices()
+    got = got.tocsr()
+    assert got.shape == want.shape and np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+    assert np.allclose(got.data, want.data, rtol=_tol(dtype), atol=0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex128])
+def test_staged_product_pattern_reuse(gpu, dtype):
+    """NNZ_COUNT once, FINALIZE_MULT for several value sets; hub rows so that the bitmap / range-partitioned path and
+    its stored range table are reused too."""
+    rng = np.random.default_rng(3)
+    a = _pos(1500, 1200, 0.01, dtype, 1)
+    hub = _pos(3, 1200, 0.6, dtype, 2)
+    a = sps.vstack([a[:700], hub, a[700:]]).tocsr()
+    b = _pos(1200, 9000, 0.01, dtype, 4)
+    with gpu.StagedProduct(a, b, reorder_output=True) as p:
+        nnz = p.count()
+        ref = (a.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64) @ b).tocsr()
+        assert nnz == ref.nnz
+        _same(p.finalize(), ref, dtype)
+        for k in range(2):
+            a2, b2 = a.copy(), b.copy()
+            a2.data[:] = rng.uniform(0.5, 1.5, a.nnz).astype(dtype)
+            b2.data[:] = rng.uniform(0.5, 1.5, b.nnz).astype(dtype)
+            p.set_values(a=a2.data, b=b2.data if k else None)
+            want = a2.astype(ref.dtype) @ (b2 if k else b).astype(ref.dtype)
+            _same(p.finalize(), want, dtype)
+        _same(p.full(), want, dtype)
+    # transposed operands and a CSC input
+    with gpu.StagedProduct(a, a.tocsc(), transpose_b=True, reorder_output=True) as p:
+        _same(p.finalize(), a.astype(ref.dtype) @ a.astype(ref.dtype).T, dtype)
+
+
+def test_staged_product_errors(gpu):
+    import ctypes as ct
+    from sparse_dot_amd._mi_interface import MI, SparseHandle, matrix_descr, sparse_matrix_t
+    a = _pos(50, 40, 0.1, np.float64, 1)
+    b = _pos(40, 30, 0.1, np.float64, 2)
+    with SparseHandle.from_scipy(a) as ha, SparseHandle.from_scipy(b) as hb, SparseHandle.from_scipy(a) as other:
+        c = sparse_matrix_t()
+        assert MI.call("mi_sparse_sp2m", 10, matrix_descr(), ha.ptr, 10, matrix_descr(), hb.ptr, 91, ct.byref(c)) == 0
+        hc = SparseHandle(c, "d")
+        # FINALIZE with other operands than NNZ_COUNT, a bad request, mismatched shapes
+        assert MI.call("mi_sparse_sp2m", 10, matrix_descr(), other.ptr, 10, matrix_descr(), hb.ptr, 92, ct.byref(c)) == 3
+        assert MI.call("mi_sparse_sp2m", 10, matrix_descr(), ha.ptr, 10, matrix_descr(), hb.ptr, 77, ct.byref(c)) == 3
+        assert MI.call("mi_sparse_sp2m", 10, matrix_descr(), ha.ptr, 10, matrix_descr(), ha.ptr, 90, ct.byref(sparse_matrix_t())) == 3
+        assert MI.call("mi_sparse_sp2m", 10, matrix_descr(), ha.ptr, 10, matrix_descr(), hb.ptr, 92, ct.byref(c)) == 0
+        hc.destroy()
+        # FINALIZE on a handle that never went through NNZ_COUNT
+        plain = ha.ptr
+        assert MI.call("mi_sparse_sp2m", 10, matrix_descr(), ha.ptr, 10, matrix_descr(), hb.ptr, 92, ct.byref(plain)) == 3
+
+
+@pytest.mark.parametrize("transpose_a", [False, True])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sypr_sparse_and_dense(gpu, dtype, transpose_a):
+    x = _pos(300, 200, 0.05, dtype, 3)
+    k = x.shape[0] if transpose_a else x.shape[1]
+    s0 = _pos(k, k, 0.05, dtype, 4)
+    sym = (s0 + s0.T).tocsr()
+    bu = sps.triu(sym).tocsr()
+    opx = (x.T if transpose_a else x).astype(np.float64)
+    ref = np.triu((opx @ sym.astype(np.float64) @ opx.T).toarray())
+    got = gpu.sparse_sypr(x, bu, transpose_a=transpose_a)
+    assert isinstance(got, sps.csr_matrix) and got.dtype == dtype
+    assert np.allclose(got.toarray(), ref, rtol=10 * _tol(dtype), atol=0)
+    g2 = got.copy()
+    g2.sort_indices()
+    want = sps.csr_matrix(ref)
+    assert np.array_equal(g2.indices, want.indices)  # no entry below the diagonal, none missing
+    # entries of B below the diagonal must be ignored (descr: symmetric, upper)
+    dirty = (bu + sps.tril(_pos(k, k, 0.05, dtype, 9), -1)).tocsr()
+    assert np.allclose(gpu.sparse_sypr(x, dirty, transpose_a=transpose_a).toarray(), ref, rtol=10 * _tol(dtype), atol=0)
+    # dense B (syprd): upper triangle referenced; out / scalars; both orders
+    bd = np.triu(sym.toarray()).astype(dtype) + np.tril(np.full((k, k), 99.0, dtype=dtype), -1)
+    for order in ("C", "F"):
+        got = gpu.sparse_sypr(x, np.asarray(bd, order=order), transpose_a=transpose_a)
+        assert got.dtype == dtype and np.allclose(np.triu(got), ref, rtol=10 * _tol(dtype), atol=0)
+        out = np.asarray(np.ones(ref.shape, dtype=dtype), order=order)
+        res = gpu.sparse_sypr(x, np.asarray(bd, order=order), transpose_a=transpose_a, out=out, out_scalar=2.0, scalar=3.0)
+        assert res is out and np.allclose(np.triu(out), np.triu(3 * ref + 2), rtol=10 * _tol(dtype), atol=0)
+        assert np.all(np.tril(out, -1) == 1.0)  # strict lower triangle untouched
+    with pytest.raises(ValueError):
+        gpu.sparse_sypr(x.tocsc(), bu)
+    with pytest.raises(ValueError):
+        gpu.sparse_sypr(x.astype(np.complex128), bu.astype(np.complex128))
