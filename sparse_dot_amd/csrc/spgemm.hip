@@ -646,13 +646,14 @@ __global__ void k_part_items(const int32_t* __restrict__ row_list, const int64_t
 // Slice table for the numeric big-row kernel: for big row t with na nonzeros and P ranges,
 //   bnd[slice_base[t] + p * na + e] = first position (absolute, in B's arrays) of B row acol[e] whose
 // column is >= the start of range p (p = 0..P-1), and the end of that B row for p = P.
-// One thread per (big row, nonzero of A): the P boundaries of one B row are found left to right by
-// galloping from the previous one, with every thread of the GPU busy -- inside k_spgemm_part the same
-// searches would be dependent loads in a workgroup-synchronous phase (measured: the dominant cost).
-#ifndef MI_SLICE_PASSES
-#define MI_SLICE_PASSES 8
-#endif
-constexpr int SLICE_PASSES = MI_SLICE_PASSES;  // range starts found by one thread of k_part_slices (first by bisection, rest by galloping)
+// One WAVE per (big row, block of 32 nonzeros of A, block of up to 64 range starts): the lanes hold the range
+// starts and search the SAME sorted B row together, one nonzero after the other, so the row's cache lines are
+// fetched once and every further probe is an L1 hit; the results go through an LDS tile so that the table is
+// written along e (coalesced), the order k_spgemm_part reads it in.  (The first version gave every thread its
+// own B row -- a bisection plus galloping per thread, 5+ private cache lines each: 54 ms and ~200 GB of fetches
+// for the literal configs[2]; inside k_spgemm_part the same searches are dependent loads in a
+// workgroup-synchronous phase, which is slower still.)
+constexpr int SLICE_EB = 32;  // nonzeros of A per wave
 
 __global__ void k_part_slice_sizes(const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off,
                                    const int64_t* __restrict__ aptr, int64_t nb, int64_t* __restrict__ n_work,
@@ -663,7 +664,7 @@ __global__ void k_part_slice_sizes(const int32_t* __restrict__ row_list, const i
     const int32_t row = row_list[t];
     const int64_t na = aptr[row + 1] - aptr[row];
     const int64_t P = item_off[t + 1] - item_off[t];
-    n_work[t] = na * ((P + SLICE_PASSES - 1) / SLICE_PASSES);
+    n_work[t] = ((na + SLICE_EB - 1) / SLICE_EB) * ((P + 1 + 63) / 64);  // waves
     n_slice[t] = na * (P + 1);
 }
 
@@ -676,23 +677,14 @@ __global__ void __launch_bounds__(256)
                   const int32_t* __restrict__ bcol, int upper, const int64_t* __restrict__ slice_base,
                   int32_t* __restrict__ bnd)
 {
-    // row of this work item: largest t with work_off[t] <= g.  The first and the last thread of the workgroup
-    // search the whole table, the others only between those two results (usually the same row).
-    __shared__ int64_t t_edge[2];
+    __shared__ int32_t tile_all[4][64][SLICE_EB + 1];  // [wave][range lane][nonzero]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int32_t (*tile)[SLICE_EB + 1] = tile_all[wave];
     const int64_t total = work_off[nb];
-    const int64_t g = (block_base + blockIdx.x) * blockDim.x + threadIdx.x;
-    if (threadIdx.x == 0 || threadIdx.x == blockDim.x - 1) {
-        const int64_t ge = g < total ? g : total - 1;
-        int64_t lo = 0, hi = nb;
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (work_off[mid] <= ge) lo = mid; else hi = mid;
-        }
-        t_edge[threadIdx.x ? 1 : 0] = lo;
-    }
-    __syncthreads();
-    if (g >= total) return;
-    int64_t lo = t_edge[0], hi = t_edge[1] + 1;
+    const int64_t g = (block_base + blockIdx.x) * 4 + wave;  // wave index = work item
+    if (g >= total) return;  // whole wave
+    // row of this work item: largest t with work_off[t] <= g (same search in every lane: broadcast loads)
+    int64_t lo = 0, hi = nb;
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
         if (work_off[mid] <= g) lo = mid; else hi = mid;
@@ -701,39 +693,49 @@ __global__ void __launch_bounds__(256)
     const int32_t row = row_list[t];
     const int64_t a0 = aptr[row], na = aptr[row + 1] - a0;
     const int64_t P = item_off[t + 1] - item_off[t];
+    const int64_t npb = (P + 1 + 63) / 64;
     const int64_t local = g - work_off[t];
-    int64_t chunk;  // 64-bit integer division is a long software loop on the GPU: take the 32-bit one when it fits
-    if ((uint64_t)local < (1ull << 32) && (uint64_t)na < (1ull << 32)) chunk = (int64_t)((uint32_t)local / (uint32_t)na);
-    else chunk = local / na;
-    const int64_t e = local - chunk * na, p0 = chunk * SLICE_PASSES;
-    const int64_t p1 = p0 + SLICE_PASSES < P ? p0 + SLICE_PASSES : P;
-    const int32_t kk = acol[a0 + e];
-    const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
-    int32_t* out = bnd + slice_base[t] + e;
+    const int64_t eb = local / npb, pb = local - eb * npb;  // range block fastest: neighbouring waves share B rows
+    const int64_t e0 = eb * SLICE_EB;
+    const int ne = (int)(na - e0 < SLICE_EB ? na - e0 : SLICE_EB);
+    const int64_t p0 = pb * 64;
+    const int np = (int)(P + 1 - p0 < 64 ? P + 1 - p0 : 64);  // range starts p0 .. p0 + np - 1 (p == P: end of the row)
+    // lanes = (nonzero sub-index, range): few ranges -> several nonzeros per step
+    int pl_n = 1;
+    while (pl_n < np) pl_n <<= 1;
+    const int el_n = 64 / pl_n;
+    const int pl = lane % pl_n, el = lane / pl_n;
     const int32_t* rb = bounds + boff_by_row[row];
-    int64_t cur = b0;
-    for (int64_t p = p0; p < p1; ++p) {
-        int32_t x = rb[p];
+    int32_t x = 0;
+    const bool p_ok = pl < np;
+    const bool is_end = p_ok && (p0 + pl == P);
+    if (p_ok && !is_end) {
+        x = rb[p0 + pl];
         if (upper && x < row) x = row;
-        if (p == p0 && p0 > 0) {
-            cur = lower_bound_col(bcol, b0, b1, x);  // first range start of this thread: bisect the whole row
-        } else if (x > 0 && cur < b1 && bcol[cur] < x) {
-            // gallop: double the step while the column is still below x, then bisect the last step
-            int64_t step = 1, prev = cur;
-            while (prev + step < b1 && bcol[prev + step] < x) {
-                prev += step;
-                step <<= 1;
-            }
-            int64_t l = prev + 1, h = prev + step < b1 ? prev + step : b1;  // bcol[prev] < x; answer in (prev, h]
-            while (l < h) {
-                const int64_t mid = (l + h) >> 1;
-                if (bcol[mid] < x) l = mid + 1; else h = mid;
-            }
-            cur = l;
-        }
-        out[p * na] = (int32_t)cur;
     }
-    if (p1 == P) out[P * na] = (int32_t)b1;
+    for (int eo = 0; eo < ne; eo += el_n) {
+        const int e = eo + el;
+        if (e < ne && p_ok) {
+            const int32_t kk = acol[a0 + e0 + e];
+            const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
+            int64_t pos;
+            if (is_end) pos = b1;
+            else if (x <= 0) pos = b0;
+            else pos = lower_bound_col(bcol, b0, b1, x);
+            tile[pl][e] = (int32_t)pos;
+        }
+    }
+    // LDS is only shared inside the wave: lanes run in lockstep, a compiler / LDS fence is all that is needed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // write out along e: lane -> (range sub-index, nonzero)
+    int32_t* out = bnd + slice_base[t] + e0;
+    const int wl = lane % SLICE_EB, wp = lane / SLICE_EB;  // 2 ranges x 32 nonzeros per step
+    for (int po = 0; po < np; po += 64 / SLICE_EB) {
+        const int pp = po + wp;
+        if (pp < np && wl < ne) out[(p0 + pp) * na + wl] = tile[pp][wl];
+    }
 }
 
 // Everything a (row, range) workgroup needs about its row in ONE 64-byte load, and the row of every work
@@ -1147,7 +1149,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                 int32_t* bnd = nullptr;
                 if (pre) {
                     bnd = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(total_slices + 1)));
-                    launch_batched(ceil_div(total_work, 256), 256, [&](int64_t off, int64_t nblk) {
+                    launch_batched(ceil_div(total_work, 4), 256, [&](int64_t off, int64_t nblk) {  // total_work = waves
                         MI_LAUNCH(k_part_slices, dim3((unsigned)nblk), dim3(256), c.stream, off, (const int32_t*)big_list, nbig,
                                   (const int64_t*)work_off, (const int64_t*)item_off, bounds, brow, (const int64_t*)A.ptr,
                                   (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, upper,

@@ -3,12 +3,14 @@
 set -e
 cd "$(dirname "$0")/../sparse_dot_amd/csrc"
 mkdir -p build/var
-for spec in "sp2:-DMI_SLICE_PASSES=2" "sp4:-DMI_SLICE_PASSES=4" "sp16:-DMI_SLICE_PASSES=16"; do
-  tag=${spec%%:*}; def=${spec#*:}
+SPECS="pu4:-DMI_PART_UNROLL=4 bu8:-DMI_BITMAP_UNROLL=8 pu4bu8:-DMI_PART_UNROLL=4@-DMI_BITMAP_UNROLL=8 pt1024:-DMI_PART_THREADS=1024 lu4:-DMI_LDS_UNROLL=4"
+for spec in $SPECS; do
+  tag=${spec%%:*}; def=$(echo ${spec#*:} | tr '@' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $def -c spgemm.hip -o build/var/spgemm_$tag.o &
 done
 wait
-for tag in sp2 sp4 sp16; do
+for spec in $SPECS; do
+  tag=${spec%%:*}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/var/libmi_sparse_$tag.so build/runtime.o build/handle.o build/spmm.o build/var/spgemm_$tag.o build/gram.o build/dense.o
 done
-ls -la build/var/*.so
+ls build/var/*.so

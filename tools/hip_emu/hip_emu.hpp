@@ -274,6 +274,10 @@ inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* 
     return hipErrorInvalidValue;
 }
 
+// wave-scope fence / barrier: lanes are free-running host threads here, so the barrier is a real one
+inline void __builtin_amdgcn_fence(int, const char*) { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __builtin_amdgcn_wave_barrier() { hip_emu::st().waves[hip_emu::t_tid / 64].bar.arrive_and_wait(); }
+
 // ---- gfx950 builtins the kernels use, restated for host threads ----------------------------------
 // (so that the kernel sources carry ONE code path: the emulation lives here, not in #ifdef branches)
 #define __builtin_nontemporal_load(p) (*(p))
