@@ -142,6 +142,14 @@ struct alignas(V * sizeof(T) >= 16 ? 16 : V * sizeof(T)) vec {
     T v[V];
 };
 
+// streaming (touched-once) loads: non-temporal for the types the builtin takes, plain for the complex structs
+template <typename T>
+__device__ __forceinline__ T nt_load(const T* p)
+{
+    if constexpr (std::is_arithmetic<T>::value) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
 // atomic accumulate (LDS or global).  Real types map to the hardware float / double atomic add
 // (-munsafe-fp-atomics); complex does the two components independently.
 template <typename T>
@@ -401,6 +409,7 @@ struct Options {
     int64_t spmm_unroll = 4;       // 4 or 8 independent B-row loads in flight per lane
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_slices = 0;       // XCD-affine column slices of the dense operand: 0 = by row width (256-byte slices), else 1, 2, 4, 8
+    int64_t spmm_flat = 1;         // narrow slices (<= 16 lanes per row of B): the flat, software-pipelined kernel (0: k_spmm)
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)

@@ -771,6 +771,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.spmm_slices = value;
         } else if (!strcmp(name, "staged_copies")) {
             o.staged_copies = value;
+        } else if (!strcmp(name, "spmm_flat")) {
+            o.spmm_flat = value;
         } else if (!strcmp(name, "spmm_plan_sync")) {
             o.spmm_plan_sync = value;
         } else if (!strcmp(name, "spmm_hot_force")) {

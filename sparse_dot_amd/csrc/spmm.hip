@@ -315,6 +315,259 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
 }
 
 // ------------------------------------------------------------------------------------------------
+// Flat variant for NARROW (slices of) rows of B: LPN <= 16 lanes cover the slice, so a wave has NG = 64 / LPN >= 4
+// lane groups.  k_spmm lets all groups work on one output row at a time and combines them with shuffles at every
+// row end: with 8 or 16 groups and ~30 nonzeros per row that is one round trip to memory per row, idle slots
+// for short rows and a drained load queue at every row end.  Here the chunk's nonzeros are one flat list cut into
+// NG CONTIGUOUS pieces, one per lane group.  A group walks its piece with U loads in flight that never drain
+// (software pipelined across row ends); rows that lie inside one piece are finished and stored by that group
+// alone; a row that crosses piece boundaries leaves a tail partial in every earlier group and a head partial in
+// the group where it ends, which that group sums in piece order after the walk (deterministic).  Same partition,
+// ownership rules, carries and fix-up as k_spmm; empty rows are written by a separate short pass.
+// The A stream and the C stores use the non-temporal policy: both are touched once and should not evict B rows.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V, int LPN, bool TAG>
+__global__ void __launch_bounds__(SPMM_WAVES* WAVE, (sizeof(T) <= 8) ? 5 : 1)  // ~94 VGPRs without spills: 5 waves / SIMD
+    k_spmm_flat(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
+                const T* __restrict__ B, int64_t b_rs, T* __restrict__ C, int64_t c_rs, int64_t N, T alpha, T beta,
+                int beta_zero, T* __restrict__ carry_val, int slices)
+{
+    MI_DYN_SMEM(smem);
+    constexpr int NG = WAVE / LPN;
+    constexpr int U = 4;
+    static_assert(V * sizeof(T) == 16, "flat kernel is the 16-byte vector path");
+    const int wave_in_block = threadIdx.x / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    int64_t cb = blockIdx.x;
+    int64_t jlo = 0, jhi = N;
+    if (slices > 1) {  // XCD-affine column slices, see k_spmm
+        const int xcd = (int)(blockIdx.x & 7u);
+        const int per = 8 / slices;
+        cb = (int64_t)(blockIdx.x >> 3) * per + (xcd % per);
+        const int64_t ns = N / slices;
+        jlo = (xcd / per) * ns;
+        jhi = jlo + ns;
+    }
+    const int64_t w = cb * SPMM_WAVES + wave_in_block;
+    const bool active = w < nchunks;
+    const size_t per_wave = (spmm_wave_lds<T>(ch) + 15) & ~size_t(15);
+    char* base = smem + per_wave * wave_in_block;
+    SpEntry<T>* s_nz = reinterpret_cast<SpEntry<T>*>(base);
+    int32_t* s_end = reinterpret_cast<int32_t*>(base + sizeof(SpEntry<T>) * (size_t)(ch + SPMM_SPLIT));
+
+    int64_t r0 = 0, P0 = 0;
+    int n_owned = 0, has_trail = 0, len = 0;
+    if (active) {  // identical partition logic to k_spmm (see there for the ownership rules)
+        const int64_t total = nnz + rows;
+        const int64_t s = w * ch;
+        const int64_t e = (s + ch < total) ? s + ch : total;
+        const int64_t ra = chunk_row[w];
+        const int64_t rb = chunk_row[w + 1];
+        {
+            const int64_t pa = ptr[ra], pa1 = ptr[ra + 1];
+            const bool before = (pa + ra) < s;
+            const bool is_long = (pa1 - pa + 1) > SPMM_SPLIT;
+            if (before && !is_long) {
+                r0 = ra + 1;
+                P0 = pa1;
+            } else {
+                r0 = ra;
+                P0 = before ? s - ra : pa;
+            }
+        }
+        int64_t r_stop, P1;
+        if (rb < rows && (ptr[rb] + rb) < e) {
+            const int64_t pb = ptr[rb], pb1 = ptr[rb + 1];
+            r_stop = rb + 1;
+            if ((pb1 - pb + 1) > SPMM_SPLIT) {
+                P1 = (e - rb < pb1) ? e - rb : pb1;
+                has_trail = 1;
+            } else {
+                P1 = pb1;
+            }
+        } else {
+            r_stop = rb;
+            P1 = (rb < rows) ? ptr[rb] : nnz;
+        }
+        if (r_stop < r0) r_stop = r0;
+        const int nproc = (int)(r_stop - r0);
+        n_owned = nproc - has_trail;
+        for (int k = lane; k < nproc; k += WAVE) {
+            int64_t en = ptr[r0 + k + 1];
+            if (k == nproc - 1) en = P1;
+            s_end[k] = (int32_t)(en - P0);
+        }
+        len = (int)(P1 - P0);
+        if (len < 0) len = 0;
+        for (int k = lane; k < len; k += WAVE) {
+            const T a = nt_load(val + P0 + k);
+            SpEntry<T> en;
+            en.c = nt_load(col + P0 + k);
+            en.v = conj_a ? vt<T>::conj(a) : a;
+            s_nz[k] = en;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    const int g = lane / LPN;
+    const int li = lane % LPN;
+    const int nproc = n_owned + has_trail;
+    __amdgpu_buffer_rsrc_t b_rsrc;
+    if constexpr (TAG) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+
+    // write one finished row (or the raw partial of the cut row into the carry buffer)
+    auto emit = [&](int k, const T (&acc)[V], int64_t jc) {
+        vec<T, V> out;
+        if (k < n_owned) {
+            T* crow = C + (r0 + k) * c_rs + jc;
+            if (beta_zero) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) out.v[v] = vt<T>::mul(alpha, acc[v]);
+            } else {
+                const vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(crow);
+#pragma unroll
+                for (int v = 0; v < V; ++v) out.v[v] = vt<T>::fma(alpha, acc[v], vt<T>::mul(beta, old.v[v]));
+            }
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, out), reinterpret_cast<u32x4*>(crow));
+        } else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) out.v[v] = acc[v];
+            *reinterpret_cast<vec<T, V>*>(carry_val + w * N + jc) = out;
+        }
+    };
+
+    for (int64_t j0 = jlo; j0 < jhi; j0 += (int64_t)LPN * V) {
+        const int64_t jc = j0 + (int64_t)li * V;
+        const bool col_ok = jc < jhi;
+        const int64_t jcc = col_ok ? jc : jlo;
+        // ---- empty rows: nothing is accumulated for them, they are written here --------------------------------
+        for (int k = g; k < nproc; k += NG) {
+            const int b0 = k ? s_end[k - 1] : 0;
+            if (s_end[k] == b0 && col_ok) {
+                T z[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) z[v] = vt<T>::zero();
+                emit(k, z, jc);
+            }
+        }
+        if (len == 0) continue;
+        // ---- this group's piece [gs, ge) of the flat list --------------------------------------------------------
+        const int L = (len + NG - 1) / NG;
+        const int gs = g * L;
+        const int ge = (gs + L < len) ? gs + L : len;
+        const bool has_piece = gs < len;
+        int k = 0, row_end = 0x7fffffff;
+        bool started_before = false;
+        if (has_piece) {
+            int lo = 0, hi = nproc - 1;  // smallest k with s_end[k] > gs (exists: s_end[nproc - 1] == len > gs)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_end[mid] > gs) hi = mid; else lo = mid + 1;
+            }
+            k = lo;
+            row_end = s_end[k];
+            started_before = (k ? s_end[k - 1] : 0) < gs;
+        }
+        T acc[V], head[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = head[v] = vt<T>::zero();
+        int head_row = -1;
+        SpEntry<T> nz[U];
+        vec<T, V> b[U];
+        auto fetch = [&](int u, int pp) {  // entry pp of this group's piece -> registers, its row of B on the way
+            if (pp < ge) {
+                nz[u] = s_nz[pp];
+                if constexpr (TAG) {
+                    const int32_t cidx = nz[u].c & 0x7fffffff;
+                    const unsigned voff = (unsigned)(((int64_t)cidx * b_rs + jcc) * (int64_t)sizeof(T));
+                    u32x4 r;
+                    if (nz[u].c < 0) r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 2);  // nt
+                    else r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 0);
+                    b[u] = __builtin_bit_cast(vec<T, V>, r);
+                } else {
+                    b[u] = *reinterpret_cast<const vec<T, V>*>(B + (int64_t)nz[u].c * b_rs + jcc);
+                }
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(u, gs + u);
+        for (int p = gs; p < gs + L; p += U) {  // same trip count in every group
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pp = p + u;
+                if (pp < ge) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[v] = vt<T>::fma(nz[u].v, b[u].v[v], acc[v]);
+                    if (pp + 1 == row_end) {  // row k ends inside this piece
+                        if (started_before) {
+#pragma unroll
+                            for (int v = 0; v < V; ++v) head[v] = acc[v];
+                            head_row = k;
+                        } else if (col_ok) {
+                            emit(k, acc, jc);
+                        }
+#pragma unroll
+                        for (int v = 0; v < V; ++v) acc[v] = vt<T>::zero();
+                        started_before = false;
+                        do { ++k; } while (k < nproc && s_end[k] == pp + 1);  // skip the empty rows that follow
+                        row_end = (k < nproc) ? s_end[k] : 0x7fffffff;
+                    }
+                }
+                fetch(u, pp + U);
+            }
+        }
+        const int tail_row = (has_piece && k < nproc && row_end != 0x7fffffff && (k ? s_end[k - 1] : 0) < ge && row_end > ge) ? k : -1;
+        // ---- rows that cross piece boundaries: partials through LDS (the staged nonzeros are no longer needed) ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        T* s_tail = reinterpret_cast<T*>(base);                        // [NG][LPN * V]
+        int32_t* s_trow = reinterpret_cast<int32_t*>(s_tail + NG * LPN * V);  // [NG]
+        {
+            vec<T, V> t;
+#pragma unroll
+            for (int v = 0; v < V; ++v) t.v[v] = acc[v];
+            *reinterpret_cast<vec<T, V>*>(s_tail + (g * LPN + li) * V) = t;
+            if (li == 0) s_trow[g] = tail_row;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (head_row >= 0) {
+            T sum[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) sum[v] = vt<T>::zero();
+            for (int gg = 0; gg < g; ++gg) {  // earlier pieces of the same row, in piece order
+                if (s_trow[gg] == head_row) {
+                    const vec<T, V> t = *reinterpret_cast<const vec<T, V>*>(s_tail + (gg * LPN + li) * V);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], t.v[v]);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], head[v]);
+            if (col_ok) emit(head_row, sum, jc);
+        }
+        if (j0 + (int64_t)LPN * V < jhi) {  // another column tile follows: the staged nonzeros must come back
+            // (only when the slice is wider than LPN * V values, which the dispatcher avoids)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int kk = lane; kk < len; kk += WAVE) {
+                const T a = val[P0 + kk];
+                SpEntry<T> en;
+                en.c = col[P0 + kk];
+                en.v = conj_a ? vt<T>::conj(a) : a;
+                s_nz[kk] = en;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // SpMV (N = 1): y := alpha * A x + beta * y  -- the lanes span NONZEROS instead of dense columns.
 // Same work partition, ownership rules and carry / fix-up machinery as k_spmm.  A wave multiplies
 // its chunk's nonzeros by the gathered x entries with fully coalesced (col, val) loads, parks the
@@ -794,6 +1047,22 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
     unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
     if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
+    if constexpr (V * sizeof(T) == 16 && LPN <= 16 && U == 4) {
+        // narrow (slices of) rows: the flat kernel (row-major operands only: the vector path guarantees b_cs == c_cs == 1)
+        if (options().spmm_flat && b_cs == 1 && c_cs == 1) {
+            if (use_tags)
+                MI_LAUNCH_SMEM((k_spmm_flat<T, V, LPN, true>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows,
+                               m.nnz, (const int64_t*)m.ptr, (const int32_t*)p.col_tagged.as<int32_t>(), (const T*)m.val,
+                               (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, C, c_rs, N,
+                               alpha, beta, beta_zero, carry_val, slices);
+            else
+                MI_LAUNCH_SMEM((k_spmm_flat<T, V, LPN, false>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows,
+                               m.nnz, (const int64_t*)m.ptr, (const int32_t*)m.col, (const T*)m.val,
+                               (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, C, c_rs, N,
+                               alpha, beta, beta_zero, carry_val, slices);
+            return;
+        }
+    }
     if constexpr (V * sizeof(T) == 16) {
         if (use_tags) {
             MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, true>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows,

@@ -28,11 +28,17 @@ def run(label, a, b, reps=20, **kw):
 rng = np.random.default_rng(0)
 a = sps.random(10000, 10000, density=0.001, format="csr", random_state=1, dtype=np.float64)
 b = rng.standard_normal((10000, 64))
-run("cfg1 SpMM 10k x 10k (1e5 nnz) fp64 x 64", a, b)
 n2 = 1 << 18   # built directly: scipy.sparse.random samples without replacement from m*n and needs far too much memory here
 ind = np.sort(rng.integers(0, n2, (n2, 32)), axis=1).astype(np.int32).ravel()
 a2 = sps.csr_matrix((rng.standard_normal(ind.size).astype(np.float32), ind, np.arange(0, ind.size + 1, 32)), shape=(n2, n2))
 b2 = rng.standard_normal((1 << 18, 128)).astype(np.float32)
-run("SpMM 2^18 (8.4M nnz) fp32 x 128", a2, b2, reps=5)
-run("SpGEMM 10k x 10k (1e5 nnz) fp64 squared", a, a)
-run("SpMV 2^18 fp32", a2, b2[:, 0].copy(), reps=10)
+import os
+for staged in ((1, 0) if not os.environ.get("ONLY_STAGED") else (1,)):
+  sda.mi_set_option("staged_copies", staged)
+  print("#### staged_copies =", staged)
+  run("cfg1 SpMM 10k x 10k (1e5 nnz) fp64 x 64", a, b)
+  run("SpMM 2^18 (8.4M nnz) fp32 x 128", a2, b2, reps=5)
+  out2 = np.empty((n2, 128), dtype=np.float32)
+  run("SpMM 2^18 (8.4M nnz) fp32 x 128, preallocated out (out_scalar=0)", a2, b2, reps=5, out=out2, out_scalar=0.0)
+  run("SpGEMM 10k x 10k (1e5 nnz) fp64 squared", a, a)
+  run("SpMV 2^18 fp32", a2, b2[:, 0].copy(), reps=10)

@@ -281,6 +281,7 @@ inline void __builtin_amdgcn_wave_barrier() { hip_emu::st().waves[hip_emu::t_tid
 // ---- gfx950 builtins the kernels use, restated for host threads ----------------------------------
 // (so that the kernel sources carry ONE code path: the emulation lives here, not in #ifdef branches)
 #define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 template <typename T>
 inline bool __hip_atomic_compare_exchange_strong(T* p, T* expected, T desired, int, int, int)

@@ -3,7 +3,7 @@
 
     python tools/spmm_sweep.py [--workload rmat|uniform] [--launches K] [--variants "S:hot_kb:chunk,..."]
 
-Every variant = (spmm_slices, spmm_hot_kb, spmm_chunk).  For each one the plan is rebuilt (untimed), the
+Every variant = (spmm_slices, spmm_hot_kb, spmm_chunk[, spmm_flat]).  For each one the plan is rebuilt (untimed), the
 product is checked against the first variant's result, and K launches are timed with the hipEvents the
 library records around the main kernel (profile_events).  Under `rocprofv3 --kernel-trace --pmc ...` the same
 script gives per-dispatch counters: the k_spmm dispatches appear in the order printed here, K + 1 per
@@ -57,7 +57,10 @@ def main():
     ref = None
     print(json.dumps({"workload": args.workload, "n": n, "nnz": nnz, "N": N, "dtype": args.dtype,
                       "launches_per_variant": args.launches + 1, "algorithmic_bytes": alg}), flush=True)
-    for (s, hot, chunk) in variants:
+    for var in variants:
+        s, hot, chunk = var[:3]
+        flat = var[3] if len(var) > 3 else 1
+        sda.mi_set_option("spmm_flat", flat)
         sda.mi_set_option("spmm_slices", s)
         sda.mi_set_option("spmm_hot_kb", hot)
         sda.mi_set_option("spmm_chunk", chunk)
@@ -88,7 +91,7 @@ def main():
         torch.cuda.synchronize()
         k_ms = sda.mi_get_counter("spmm_kernel_ms") / max(1.0, sda.mi_get_counter("spmm_kernel_launches"))
         sda.mi_set_option("profile_events", 0)
-        print(json.dumps({"slices": s, "hot_kb": hot, "chunk": chunk, "kernel_ms": round(k_ms, 4),
+        print(json.dumps({"slices": s, "hot_kb": hot, "chunk": chunk, "flat": flat, "kernel_ms": round(k_ms, 4),
                           "step_ms_with_event_sync": round(e0.elapsed_time(e1) / args.launches, 4),
                           "tagged": bool(sda.mi_get_counter("spmm_last_tagged")),
                           "hot_coverage": round(sda.mi_get_counter("spmm_hot_coverage"), 4),
