@@ -300,6 +300,17 @@ struct Csr {
     bool sorted = false;  // column indices known to be ascending inside every row
 };
 
+// block form kept next to the CSR expansion on handles created from BSR arrays: the SpMM block kernel (bsr.hip) reads it
+struct Bsr {
+    int64_t brows = 0, bcols = 0, bs = 0, nblocks = 0;
+    int layout = MI_SPARSE_LAYOUT_ROW_MAJOR;  // storage order INSIDE a block
+    int64_t* ptr = nullptr;                   // brows + 1
+    int32_t* col = nullptr;                   // nblocks (block column)
+    void* val = nullptr;                      // nblocks * bs * bs
+    DevBuf ptr_own, col_own, val_own;
+    bool valid = false;
+};
+
 struct HostExport {  // library-owned host copies handed out by export_* (valid until destroy)
     std::vector<char> ptr, col, val;
 };
@@ -364,6 +375,7 @@ struct mi_sparse_matrix {
     char origin = 'r';      // 'r' created as CSR, 'c' as CSC, 'b' as BSR, 'l' library result
     mi::Csr csr;            // CSR of A
     mi::Csr csrT;           // CSR of A^T  (== the CSC arrays of A)
+    mi::Bsr bsr;            // block form (origin 'b' only)
     // caller's HOST arrays, kept for mi_sparse_order's write-back (nullptr when device / result)
     void* user_col = nullptr;
     void* user_val = nullptr;
@@ -409,7 +421,8 @@ struct Options {
     int64_t spmm_unroll = 4;       // 4 or 8 independent B-row loads in flight per lane
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_slices = 0;       // XCD-affine column slices of the dense operand: 0 = by row width (256-byte slices), else 1, 2, 4, 8
-    int64_t spmm_flat = 1;         // narrow slices (<= 16 lanes per row of B): the flat, software-pipelined kernel (0: k_spmm)
+    int64_t spmm_flat = 0;         // 1: narrow slices (<= 16 lanes per row of B) through the flat, software-pipelined kernel
+                                   // (measured 25-30 % SLOWER than k_spmm on the headline matrix, profiles/r02_spmm_flat_ab.log: kept as an A/B option)
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)
@@ -420,6 +433,7 @@ struct Options {
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory
     int64_t trace_phases = 0;      // print host wall-clock per SpGEMM phase to stderr (diagnostics; synchronises)
+    int64_t bsr_native = 1;        // BSR handles x row-major dense: the block kernel (0: always the CSR expansion)
     int64_t staged_copies = 1;     // large pageable host <-> device copies through the parallel pinned stager (0: plain hipMemcpy)
     int64_t profile_events = 0;    // bracket the SpMM main kernel with hipEvents (diagnostics)
     int64_t spmm_plan_sync = 0;    // 1: run the hot / cold analysis synchronously inside the first product (tests, A/B tools)
@@ -432,8 +446,15 @@ struct Counters {
     double spmm_last_slices = 1.0;    // column slices the last SpMM ran with
     double spmm_plan_ms = 0.0;        // host wall time spent building plans (partition + fix-up schedule), accumulated
     double spmm_plans_built = 0.0;
+    double bsr_native_calls = 0.0;    // products served by the BSR block kernel
 };
 Counters& counters();  // per host thread
+
+// bsr.hip
+template <typename T>
+bool bsr_spmm_applicable(const Bsr& b, int layout, const T* B, int64_t N, int64_t ldb, const T* C, int64_t ldc);
+template <typename T>
+void bsr_spmm_device(const Bsr& b, T alpha, const T* B, int64_t N, int64_t ldb, T beta, T* C, int64_t ldc);
 Options& options();
 
 }  // namespace mi

@@ -804,6 +804,25 @@ static int create_bsr_generic(mi_sparse_matrix_t* A, int base, int block_layout,
             }
             MI_HIP_CHECK(hipStreamSynchronize(c.stream));
             o.valid = true;
+            // keep the block form for the SpMM block kernel (bsr.hip): structure from `blk`, values owned
+            // (staged copy of host values) or aliased (device values, like CSR handles alias device arrays)
+            Bsr& bb = h->bsr;
+            bb.brows = brows;
+            bb.bcols = bcols;
+            bb.bs = bs;
+            bb.nblocks = nblocks;
+            bb.layout = block_layout;
+            bb.ptr = blk.ptr;
+            bb.col = blk.col;
+            bb.ptr_own = std::move(blk.ptr_own);
+            bb.col_own = std::move(blk.col_own);
+            if (vtmp.p) {
+                bb.val = vtmp.p;
+                bb.val_own = std::move(vtmp);
+            } else {
+                bb.val = const_cast<T*>(dval);
+            }
+            bb.valid = true;
         } catch (...) {
             h->magic = 0;
             delete h;

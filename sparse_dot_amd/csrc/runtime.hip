@@ -769,6 +769,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
                 mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_slices must be 0 (automatic), 1, 2, 4 or 8");
             o.spmm_slices = value;
+        } else if (!strcmp(name, "bsr_native")) {
+            o.bsr_native = value;
         } else if (!strcmp(name, "staged_copies")) {
             o.staged_copies = value;
         } else if (!strcmp(name, "spmm_flat")) {
@@ -828,6 +830,7 @@ mi_sparse_status_t mi_sparse_get_counter(const char* name, double* value)
         else if (!strcmp(name, "spmm_last_slices")) *value = k.spmm_last_slices;
         else if (!strcmp(name, "spmm_plan_ms")) *value = k.spmm_plan_ms;
         else if (!strcmp(name, "spmm_plans_built")) *value = k.spmm_plans_built;
+        else if (!strcmp(name, "bsr_native_calls")) *value = k.bsr_native_calls;
         else mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown counter '%s'", name);
     });
 }

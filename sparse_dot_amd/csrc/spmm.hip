@@ -1270,13 +1270,19 @@ static int mm_generic(int op, T alpha, mi_sparse_matrix_t A, struct mi_matrix_de
         if (!C || (!B && brows > 0)) fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL dense operand");
         Context& c = ctx();
         c.scratch_reset();
-        Csr& m = trans ? need_csrT(h) : need_csr(h);
         const int conj_a = (op == MI_SPARSE_OPERATION_CONJUGATE_TRANSPOSE && vt<T>::is_complex) ? 1 : 0;
         Staged sb, sc;
         sb.stage_in(B, sizeof(T) * dense_extent(layout, brows, columns, ldb), true);
         sc.stage_in(C, sizeof(T) * dense_extent(layout, crows, columns, ldc), !vt<T>::is_zero(beta));
-        spmm_device<T>(h, trans, m, conj_a, alpha, layout, static_cast<const T*>(sb.dev), columns, ldb, beta,
-                       static_cast<T*>(sc.dev), ldc);
+        if (!trans && bsr_spmm_applicable<T>(h->bsr, layout, static_cast<const T*>(sb.dev), columns, ldb,
+                                             static_cast<const T*>(sc.dev), ldc)) {
+            // handle created from BSR arrays: the block kernel on the block form (no CSR index traffic)
+            bsr_spmm_device<T>(h->bsr, alpha, static_cast<const T*>(sb.dev), columns, ldb, beta, static_cast<T*>(sc.dev), ldc);
+        } else {
+            Csr& m = trans ? need_csrT(h) : need_csr(h);
+            spmm_device<T>(h, trans, m, conj_a, alpha, layout, static_cast<const T*>(sb.dev), columns, ldb, beta,
+                           static_cast<T*>(sc.dev), ldc);
+        }
         MI_HIP_CHECK(hipGetLastError());
         if (sb.host) c.sync();  // staged B is freed when `sb` goes out of scope
         sc.copy_back();

@@ -11,6 +11,6 @@ done
 wait
 for spec in $SPECS; do
   tag=${spec%%:*}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/var/libmi_sparse_$tag.so build/runtime.o build/handle.o build/spmm.o build/var/spgemm_$tag.o build/gram.o build/dense.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/var/libmi_sparse_$tag.so build/runtime.o build/handle.o build/spmm.o build/var/spgemm_$tag.o build/gram.o build/dense.o build/bsr.o
 done
 ls build/var/*.so
