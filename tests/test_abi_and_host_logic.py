@@ -40,6 +40,41 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+# every symbol the reference binds when it is imported (reference _mkl_interface/_cfunctions.py:43-168): a library
+# selected through $MKL_RT must export all of them or the import dies with AttributeError
+MKL_NAMES_BOUND_BY_THE_REFERENCE = (
+    ["mkl_sparse_%s_%s" % (t, f) for t in "sdcz" for f in
+     ("create_csr", "create_csc", "create_bsr", "export_csr", "export_csc", "export_bsr", "mm", "mv", "spmmd", "syrkd")]
+    + ["mkl_sparse_spmm", "mkl_sparse_syrk", "mkl_sparse_order", "mkl_sparse_destroy", "mkl_sparse_convert_csr",
+       "mkl_sparse_qr_reorder", "mkl_sparse_s_qr_factorize", "mkl_sparse_d_qr_factorize", "mkl_sparse_s_qr_solve",
+       "mkl_sparse_d_qr_solve"]
+    + ["cblas_%s%s" % (t, f) for t in "sdcz" for f in ("gemm", "syrk")]
+    + ["MKL_Set_Interface_Layer", "MKL_Get_Max_Threads", "MKL_Set_Num_Threads", "MKL_Set_Num_Threads_Local",
+       "MKL_Get_Version", "MKL_Get_Version_String", "mkl_free_buffers", "pardiso", "pardisoinit"]
+    + ["%s%s" % (s, f) for s in ("dcg", "dcgmrhs", "dfgmres") for f in ("", "_init", "_check", "_get")])
+
+
+def test_mkl_alias_library_exports_what_the_reference_binds():
+    """libmi_mkl_rt.so (csrc/mkl_alias.cpp): the MKL-named face of the backend, so that the UNMODIFIED reference can be
+    pointed at it with $MKL_RT.  Import-level check here; tools/hip_emu/check_mkl_alias.sh runs the
+    reference's own test-suite through it on the host-emulated kernels (log under profiles/)."""
+    path = os.path.join(ROOT, "sparse_dot_amd", "libmi_mkl_rt.so")
+    assert os.path.exists(path), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    from sparse_dot_amd._mi_interface import _library  # loads torch's HIP runtime first when there is one
+    assert _library is not None
+    lib = ctypes.CDLL(path)
+    missing = [s for s in MKL_NAMES_BOUND_BY_THE_REFERENCE + ["mkl_sparse_sp2m", "mkl_sparse_sypr", "mkl_sparse_d_syprd"]
+               if not hasattr(lib, s)]
+    assert not missing, missing
+    # service calls work without a device
+    lib.MKL_Set_Interface_Layer.restype = ctypes.c_int
+    assert lib.MKL_Set_Interface_Layer(1) == 1 and lib.MKL_Set_Interface_Layer(0) == 0
+    buf = ctypes.create_string_buffer(256)
+    lib.MKL_Get_Version_String(buf, 256)
+    assert b"mi_sparse" in buf.value
+    assert lib.MKL_Get_Max_Threads() == 1
+
+
 def test_library_has_gfx950_code_object():
     """The shipped .so must carry device code for gfx950 (and nothing is CPU-only)."""
     out = subprocess.run(["strings", "-a", LIB], capture_output=True, text=True).stdout
