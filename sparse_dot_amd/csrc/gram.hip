@@ -23,17 +23,20 @@ __device__ __forceinline__ T shfl_bcast(T v, int src)
     return __shfl(v, src);
 }
 
-template <typename T>
-constexpr int syrkd_tile() { return (int)(65536 / sizeof(T)); }  // 64 KiB of LDS per workgroup
+// LDS tile of one workgroup: TKB KiB of accumulators.  64 KiB (two 512-thread workgroups per CU) or 128 KiB (one
+// 1024-thread workgroup per CU): a wider tile halves the number of passes over the row's nonzeros when the output row
+// is wider than one tile (every pass re-reads all of them and keeps ~tile / n of the entries).
+template <typename T, int TKB>
+constexpr int syrkd_tile() { return (int)(TKB * 1024 / sizeof(T)); }
 
-template <typename T>
-__global__ void __launch_bounds__(512)
+template <typename T, int TKB>
+__global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     k_syrkd_lds(int64_t n, int64_t row0, int64_t row_end, int64_t tiles_per_row, const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol,
                 const T* __restrict__ tval, const int64_t* __restrict__ xptr, const int32_t* __restrict__ xcol,
                 const T* __restrict__ xval, T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta,
                 int beta_zero)
 {
-    constexpr int TILE = syrkd_tile<T>();
+    constexpr int TILE = syrkd_tile<T, TKB>();
     __shared__ T acc[TILE];
     // XCD-affine order: workgroup b runs on XCD b % 8 (observed; speed only).  All column tiles of one output row go
     // to the SAME XCD, back to back, so the rows of X that the row's nonzeros select (the same for every tile) are
@@ -138,12 +141,20 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         // lower triangle must survive the round trip
         sc.stage_in(C, sizeof(T) * (size_t)(row_major ? (nr - 1) * ldc + n : (n - 1) * ldc + nr), true);
         T* dC = static_cast<T*>(sc.dev);
-        const int64_t tiles_per_row = ceil_div(n, (int64_t)syrkd_tile<T>());
+        // wide outputs (more than one 64 KiB tile per row): 128 KiB tiles, one workgroup per CU
+        const bool wide = n > (int64_t)syrkd_tile<T, 64>() && options().gram_tile_kb != 64;
+        const int64_t tile = wide ? syrkd_tile<T, 128>() : syrkd_tile<T, 64>();
+        const int64_t tiles_per_row = ceil_div(n, tile);
         const int64_t nblocks = ceil_div(nr, 8) * 8 * tiles_per_row;  // 8 rows (one per XCD) x all their tiles per group
         if (nblocks > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "gram output too large for one launch");
-        MI_LAUNCH((k_syrkd_lds<T>), dim3((unsigned)nblocks), dim3(512), c.stream, n, row0, row1, tiles_per_row,
-                  (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
-                  (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero);
+        if (wide)
+            MI_LAUNCH((k_syrkd_lds<T, 128>), dim3((unsigned)nblocks), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
+                      (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
+                      (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero);
+        else
+            MI_LAUNCH((k_syrkd_lds<T, 64>), dim3((unsigned)nblocks), dim3(512), c.stream, n, row0, row1, tiles_per_row,
+                      (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
+                      (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero);
         MI_HIP_CHECK(hipGetLastError());
         sc.copy_back();
     });

@@ -240,11 +240,13 @@ def test_config5_shape_single_gpu(gpu):
         for _ in range(3):  # the third call runs with the hot / cold tags adopted (same results required)
             mm(B, C)
             torch.cuda.synchronize()
-        rowsum = torch.zeros(n, device=dev, dtype=torch.float64)
-        rowsum.index_add_(0, torch.repeat_interleave(torch.arange(n, device=dev), lens), vals.double())
-        err = ((C[:, 0].double() - rowsum).abs() / rowsum.clamp(min=1e-30))[rowsum > 0].max().item()
+        # row sums of A as differences of an fp64 running sum (an index_add_ of 5e8 sorted fp64 atomics takes minutes)
+        cs = torch.cat([torch.zeros(1, device=dev, dtype=torch.float64), torch.cumsum(vals.double(), 0)])
+        rowsum = cs[ip[1:]] - cs[ip[:-1]]
+        del cs
+        err = ((C[:, 0].double() - rowsum).abs() / rowsum.clamp(min=1e-30))[lens > 0].max().item()
         assert err <= F32_TOL, err
-        assert (C[rowsum == 0] == 0).all()
+        assert (C[lens == 0] == 0).all()
         assert torch.equal(C[:, :1].expand(-1, N), C)
         g = torch.Generator(device=dev)
         g.manual_seed(1)
