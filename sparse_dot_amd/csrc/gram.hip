@@ -65,37 +65,51 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         const int64_t q0 = valid ? xptr[r] : 0;
         const int64_t q1 = valid ? xptr[r + 1] : 0;
         const int cnt = (t1 - base < WAVE) ? (int)(t1 - base) : WAVE;
-        for (int e0 = 0; e0 < cnt; e0 += 4) {
-            int64_t qs[4], qe[4];
-            T ae[4];
-            int32_t jj[4];
-            T xv[4];
+        // R rows per step, two steps in flight: the loads of step s + 1 are issued before the LDS atomics of step s,
+        // so the walk is a pipeline of independent loads instead of one dependent round trip per step
+        constexpr int R = 4;
+        struct Step {
+            int64_t qs[R], qe[R];
+            T ae[R], xv[R];
+            int32_t jj[R];
+        };
+        auto issue = [&](int e0, Step& st) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = (e0 + u < cnt) ? e0 + u : e0;  // clamp: duplicates are masked out below
-                qs[u] = shfl_bcast(q0, e);
-                qe[u] = (e0 + u < cnt) ? shfl_bcast(q1, e) : qs[u];
-                ae[u] = shfl_bcast(a, e);
+            for (int u = 0; u < R; ++u) {
+                const int e = (e0 + u < cnt) ? e0 + u : (e0 < cnt ? e0 : 0);  // clamp: duplicates are masked out below
+                st.qs[u] = shfl_bcast(q0, e);
+                st.qe[u] = (e0 + u < cnt) ? shfl_bcast(q1, e) : st.qs[u];
+                st.ae[u] = shfl_bcast(a, e);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {  // first 64 entries of each of the four rows: loads issued together
-                const int64_t q = qs[u] + lane;
-                const bool ok = q < qe[u];
-                jj[u] = ok ? xcol[q] : -1;
-                xv[u] = ok ? xval[q] : vt<T>::zero();
+            for (int u = 0; u < R; ++u) {  // first 64 entries of each row: loads issued together
+                const int64_t q = st.qs[u] + lane;
+                const bool ok = q < st.qe[u];
+                st.jj[u] = ok ? xcol[q] : -1;
+                st.xv[u] = ok ? xval[q] : vt<T>::zero();
+            }
+        };
+        auto consume = [&](const Step& st) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int64_t j = st.jj[u];
+                if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(st.ae[u], st.xv[u]));
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t j = jj[u];
-                if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(ae[u], xv[u]));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {  // rows longer than one wave
-                for (int64_t q = qs[u] + WAVE + lane; q < qe[u]; q += WAVE) {
+            for (int u = 0; u < R; ++u) {  // rows longer than one wave
+                for (int64_t q = st.qs[u] + WAVE + lane; q < st.qe[u]; q += WAVE) {
                     const int64_t j = xcol[q];
-                    if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(ae[u], xval[q]));
+                    if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(st.ae[u], xval[q]));
                 }
             }
+        };
+        Step s0, s1;
+        issue(0, s0);
+        for (int e0 = 0; e0 < cnt; e0 += 2 * R) {
+            issue(e0 + R, s1);       // past the end: every row is clamped to an empty extent
+            consume(s0);
+            issue(e0 + 2 * R, s0);
+            consume(s1);
         }
     }
     __syncthreads();
