@@ -783,7 +783,7 @@ __global__ void __launch_bounds__(256)
 {
     __shared__ T tile[32][33];  // [j local][i local]
     const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;  // 32 x 8
-    const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+    const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;  // the long (row) dimension on grid.x: grid.y stops at 65535
     for (int k = 0; k < 4; ++k) {
         const int a = tx, b = ty + 8 * k;
         const int il = (s_rs == 1) ? a : b, jl = (s_rs == 1) ? b : a;
@@ -804,7 +804,7 @@ static void convert_layout(int64_t rows, int64_t cols, const T* src, int64_t s_r
                            int64_t d_cs)
 {
     if (rows == 0 || cols == 0) return;
-    MI_LAUNCH((k_convert_layout<T>), dim3((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32)), dim3(256),
+    MI_LAUNCH((k_convert_layout<T>), dim3((unsigned)ceil_div(rows, 32), (unsigned)ceil_div(cols, 32)), dim3(256),
               ctx().stream, rows, cols, src, s_rs, s_cs, dst, d_rs, d_cs);
 }
 

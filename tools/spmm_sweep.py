@@ -59,7 +59,7 @@ def main():
                       "launches_per_variant": args.launches + 1, "algorithmic_bytes": alg}), flush=True)
     for var in variants:
         s, hot, chunk = var[:3]
-        flat = var[3] if len(var) > 3 else 1
+        flat = var[3] if len(var) > 3 else 0
         sda.mi_set_option("spmm_flat", flat)
         sda.mi_set_option("spmm_slices", s)
         sda.mi_set_option("spmm_hot_kb", hot)
