@@ -250,6 +250,15 @@ __global__ void __launch_bounds__(THREADS)
 // inserted, the loads for row i + 1 (B row extents), i + 2 (A's columns), i + 3 (A's row pointers) and i + 4 (row id)
 // are in flight -- one exposed round trip per row instead of five.  Same hash / flat-walk / compaction as
 // k_spgemm_lds (64 threads); rows of A with more than 64 nonzeros take the remaining ones the unpipelined way.
+// The workgroup is ONE wave: its LDS traffic is ordered by the hardware (DS operations of a wave execute in order), so a
+// compiler-level fence is all the synchronisation it needs.  __syncthreads() would also wait for every outstanding
+// GLOBAL load (vmcnt(0)) -- exactly the prefetches this kernel wants to keep in flight.
+#define MI_WAVE_SYNC()                                        \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 template <typename T, int LOG2S, bool NUMERIC>
 __global__ void __launch_bounds__(64)
     k_spgemm_lds_pipe(const int32_t* __restrict__ row_list, int64_t nlist, const int64_t* __restrict__ aptr,
@@ -265,7 +274,6 @@ __global__ void __launch_bounds__(64)
     __shared__ int64_t qlo[NT];
     __shared__ T a_s[NUMERIC ? NT : 1];
     __shared__ int inc[NT];
-    __shared__ int wave_tot[1];
     __shared__ int counter;
     const int tid = threadIdx.x;
     const int64_t stride = gridDim.x;
@@ -347,7 +355,7 @@ __global__ void __launch_bounds__(64)
             if (NUMERIC) vals[k] = vt<T>::zero();
         }
         if (tid == 0) counter = 0;
-        __syncthreads();
+        MI_WAVE_SYNC();
         int local = 0;
         for (int64_t base = a0; base < a1; base += NT) {
             int len = 0;
@@ -366,7 +374,16 @@ __global__ void __launch_bounds__(64)
                 if (NUMERIC) a_s[tid] = av;
                 len = (int)(b1 - b0);
             }
-            block_scan_inclusive<NT>(len, inc, wave_tot, tid);
+            {  // inclusive scan of the slice lengths inside the wave
+                int sc = len;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int up = __shfl_up(sc, d);
+                    if (tid >= d) sc += up;
+                }
+                inc[tid] = sc;
+            }
+            MI_WAVE_SYNC();
             const int total = inc[NT - 1];
             for (int f0 = tid; f0 < total; f0 += NT * LDS_UNROLL) {
                 int32_t j[LDS_UNROLL];
@@ -397,11 +414,11 @@ __global__ void __launch_bounds__(64)
                     }
                 }
             }
-            __syncthreads();
+            MI_WAVE_SYNC();
         }
         if (!NUMERIC) {
             if (local) atomicAdd(&counter, local);
-            __syncthreads();
+            MI_WAVE_SYNC();
             if (tid == 0) row_nnz[row] = counter;
         } else {
             for (int k = tid; k < S; k += NT) {
@@ -413,9 +430,11 @@ __global__ void __launch_bounds__(64)
                 }
             }
         }
-        __syncthreads();  // the table is cleared for the next row at the top of the loop
+        MI_WAVE_SYNC();  // the table is cleared for the next row at the top of the loop
     }
 }
+
+#undef MI_WAVE_SYNC
 
 // ---- global-memory hash kernel: persistent workgroups, one slab each ------------------------------
 template <typename T>
