@@ -424,7 +424,6 @@ struct Options {
     int64_t spmm_flat = 0;         // 1: narrow slices (<= 16 lanes per row of B) through the flat, software-pipelined kernel
                                    // (measured 25-30 % SLOWER than k_spmm on the headline matrix, profiles/r02_spmm_flat_ab.log: kept as an A/B option)
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
-    int64_t spgemm_pipe = 1;       // small rows (<= 256 products): the row-pipelined persistent kernel (0: one workgroup per row)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)
     int64_t spgemm_part_log2s_bias = 0;  // tuning: +1 / -1 forces the larger / smaller table of the numeric big-row kernel

@@ -784,8 +784,6 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.spmm_hot_force = value;
         } else if (!strcmp(name, "spmm_force_generic")) {
             o.spmm_force_generic = value;
-        } else if (!strcmp(name, "spgemm_pipe")) {
-            o.spgemm_pipe = value;
         } else if (!strcmp(name, "spgemm_force_global")) {
             o.spgemm_force_global = value;
         } else if (!strcmp(name, "spgemm_part_log2s_bias")) {

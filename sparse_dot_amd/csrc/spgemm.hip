@@ -241,201 +241,6 @@ __global__ void __launch_bounds__(THREADS)
     }
 }
 
-// ---- small rows, one wave per row, PIPELINED over rows ---------------------------------------------
-// The life of a small row in k_spgemm_lds is a chain of five dependent loads (row list -> row pointers of A ->
-// columns of A -> row pointers of B -> entries of B) in front of a few hundred LDS operations; with one wave per
-// row and 21-32 rows in flight per CU (LDS tables / wave slots) the kernel runs at rows / (rows in flight) x chain
-// latency, not at the memory system's speed.  Here a wave is persistent and walks its share of the row list with the
-// first four links of the chain running AHEAD of the product walk: while row i's products are loaded and
-// inserted, the loads for row i + 1 (B row extents), i + 2 (A's columns), i + 3 (A's row pointers) and i + 4 (row id)
-// are in flight -- one exposed round trip per row instead of five.  Same hash / flat-walk / compaction as
-// k_spgemm_lds (64 threads); rows of A with more than 64 nonzeros take the remaining ones the unpipelined way.
-// The workgroup is ONE wave: its LDS traffic is ordered by the hardware (DS operations of a wave execute in order), so a
-// compiler-level fence is all the synchronisation it needs.  __syncthreads() would also wait for every outstanding
-// GLOBAL load (vmcnt(0)) -- exactly the prefetches this kernel wants to keep in flight.
-#define MI_WAVE_SYNC()                                        \
-    do {                                                      \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                      \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
-template <typename T, int LOG2S, bool NUMERIC>
-__global__ void __launch_bounds__(64)
-    k_spgemm_lds_pipe(const int32_t* __restrict__ row_list, int64_t nlist, const int64_t* __restrict__ aptr,
-                      const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
-                      const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
-                      int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
-                      T* __restrict__ cval)
-{
-    constexpr int S = 1 << LOG2S;
-    constexpr int NT = 64;
-    __shared__ int32_t keys[S];
-    __shared__ T vals[NUMERIC ? S : 1];
-    __shared__ int64_t qlo[NT];
-    __shared__ T a_s[NUMERIC ? NT : 1];
-    __shared__ int inc[NT];
-    __shared__ int counter;
-    const int tid = threadIdx.x;
-    const int64_t stride = gridDim.x;
-    // ---- pipeline registers: suffix = how many rows ahead of the one being processed -------------------------
-    int32_t rid4 = 0;                                     // S1: row id
-    int32_t rid3 = 0;
-    int64_t a0_3 = 0, a1_3 = 0, out0_3 = 0;               // S2: A row extent (+ C offset)
-    int32_t rid2 = 0;
-    int64_t a0_2 = 0, a1_2 = 0, out0_2 = 0;
-    int32_t kk2 = 0;                                      // S3: this lane's nonzero of A
-    T av2 = vt<T>::zero();
-    int32_t rid1 = 0;
-    int64_t a0_1 = 0, a1_1 = 0, out0_1 = 0;
-    T av1 = vt<T>::zero();
-    int64_t b0_1 = 0, b1_1 = 0;                           // S4: extent of the selected B row
-    auto s1 = [&](int64_t j) -> int32_t { return j < nlist ? row_list[j] : -1; };
-    auto s2 = [&](int32_t rid, int64_t& a0, int64_t& a1, int64_t& out0) {
-        a0 = a1 = out0 = 0;
-        if (rid >= 0) {
-            a0 = aptr[rid];
-            a1 = aptr[rid + 1];
-            if (NUMERIC) out0 = cptr[rid];
-        }
-    };
-    auto s3 = [&](int64_t a0, int64_t a1, int32_t& kk, T& av) {
-        kk = -1;
-        av = vt<T>::zero();
-        if (a0 + tid < a1) {
-            kk = acol[a0 + tid];
-            if (NUMERIC) av = aval[a0 + tid];
-        }
-    };
-    auto s4 = [&](int32_t kk, int64_t& b0, int64_t& b1) {
-        b0 = b1 = 0;
-        if (kk >= 0) {
-            b0 = bptr[kk];
-            b1 = bptr[kk + 1];
-        }
-    };
-    // ---- fill the pipeline ------------------------------------------------------------------------------------
-    const int64_t i0 = blockIdx.x;
-    {
-        const int32_t r0 = s1(i0), r1 = s1(i0 + stride), r2 = s1(i0 + 2 * stride);
-        rid4 = s1(i0 + 3 * stride);
-        rid1 = r0;
-        rid2 = r1;
-        rid3 = r2;
-        s2(rid1, a0_1, a1_1, out0_1);
-        s2(rid2, a0_2, a1_2, out0_2);
-        s2(rid3, a0_3, a1_3, out0_3);
-        int32_t kk1;
-        s3(a0_1, a1_1, kk1, av1);
-        s3(a0_2, a1_2, kk2, av2);
-        s4(kk1, b0_1, b1_1);
-    }
-    for (int64_t i = i0; i < nlist; i += stride) {
-        // the row to process now = what was one row ahead
-        const int32_t row = rid1;
-        const int64_t a0 = a0_1, a1 = a1_1, out0 = out0_1;
-        int64_t b0 = b0_1, b1 = b1_1;
-        T av = av1;
-        // ---- advance every stage by one row: all of these loads are independent of each other and of the walk below
-        {
-            const int32_t n_rid4 = s1(i + 4 * stride);
-            int64_t n_a0, n_a1, n_out0;
-            s2(rid4, n_a0, n_a1, n_out0);
-            int32_t n_kk;
-            T n_av;
-            s3(a0_3, a1_3, n_kk, n_av);
-            s4(kk2, b0_1, b1_1);  // -> stage 4 of row i + 1
-            rid1 = rid2; a0_1 = a0_2; a1_1 = a1_2; out0_1 = out0_2; av1 = av2;
-            rid2 = rid3; a0_2 = a0_3; a1_2 = a1_3; out0_2 = out0_3; kk2 = n_kk; av2 = n_av;
-            rid3 = rid4; a0_3 = n_a0; a1_3 = n_a1; out0_3 = n_out0;
-            rid4 = n_rid4;
-        }
-        // ---- row `row`: clear the table, walk the products, count / compact -----------------------------------
-        for (int k = tid; k < S; k += NT) {
-            keys[k] = HASH_EMPTY;
-            if (NUMERIC) vals[k] = vt<T>::zero();
-        }
-        if (tid == 0) counter = 0;
-        MI_WAVE_SYNC();
-        int local = 0;
-        for (int64_t base = a0; base < a1; base += NT) {
-            int len = 0;
-            if (base != a0) {  // nonzeros 64.. of a longer row of A: not prefetched
-                b0 = b1 = 0;
-                if (base + tid < a1) {
-                    const int32_t kk = acol[base + tid];
-                    b0 = bptr[kk];
-                    b1 = bptr[kk + 1];
-                    if (NUMERIC) av = aval[base + tid];
-                }
-            }
-            if (base + tid < a1) {
-                if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, row);  // sorted B: skip the lower triangle
-                qlo[tid] = b0;
-                if (NUMERIC) a_s[tid] = av;
-                len = (int)(b1 - b0);
-            }
-            {  // inclusive scan of the slice lengths inside the wave
-                int sc = len;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int up = __shfl_up(sc, d);
-                    if (tid >= d) sc += up;
-                }
-                inc[tid] = sc;
-            }
-            MI_WAVE_SYNC();
-            const int total = inc[NT - 1];
-            for (int f0 = tid; f0 < total; f0 += NT * LDS_UNROLL) {
-                int32_t j[LDS_UNROLL];
-                T v[LDS_UNROLL];
-#pragma unroll
-                for (int u = 0; u < LDS_UNROLL; ++u) {
-                    const int f = f0 + u * NT;
-                    j[u] = -1;
-                    if (f < total) {
-                        const int l = flat_find<NT>(inc, f);
-                        const int64_t q = qlo[l] + (f - (l ? inc[l - 1] : 0));
-                        j[u] = bcol[q];
-                        if (NUMERIC) v[u] = vt<T>::mul(a_s[l], bval[q]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < LDS_UNROLL; ++u) {
-                    if (j[u] < 0 || (upper && j[u] < row)) continue;
-                    uint32_t h = hash_col(j[u], LOG2S);
-                    for (;;) {
-                        const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, j[u]);
-                        if (old == HASH_EMPTY || old == j[u]) {
-                            if (NUMERIC) atomic_accum(&vals[h], v[u]);
-                            else if (old == HASH_EMPTY) ++local;
-                            break;
-                        }
-                        h = (h + 1) & (S - 1);
-                    }
-                }
-            }
-            MI_WAVE_SYNC();
-        }
-        if (!NUMERIC) {
-            if (local) atomicAdd(&counter, local);
-            MI_WAVE_SYNC();
-            if (tid == 0) row_nnz[row] = counter;
-        } else {
-            for (int k = tid; k < S; k += NT) {
-                const int32_t key = keys[k];
-                if (key != HASH_EMPTY) {
-                    const int pos = atomicAdd(&counter, 1);
-                    ccol[out0 + pos] = key;
-                    cval[out0 + pos] = vals[k];
-                }
-            }
-        }
-        MI_WAVE_SYNC();  // the table is cleared for the next row at the top of the loop
-    }
-}
-
-#undef MI_WAVE_SYNC
-
 // ---- global-memory hash kernel: persistent workgroups, one slab each ------------------------------
 template <typename T>
 __device__ __forceinline__ T load_l2(const T* p)
@@ -1256,24 +1061,6 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
         });                                                                                                        \
         b.n[k] = 0;                                                                                                \
     }
-        // bins 0-3 (<= 256 products): one persistent wave per row with the dependent-load chain pipelined over rows
-#define MI_SPGEMM_PIPE(k, LOG2S)                                                                                    \
-    if (b.n[k] && options().spgemm_pipe) {                                                                          \
-        const int64_t per_cu = (int64_t)(150 * 1024) / (int64_t)(sizeof(int32_t) * (1 << LOG2S) +                  \
-                                                                (NUMERIC ? sizeof(T) * (1 << LOG2S) + 64 * sizeof(T) : 0) + 1100); \
-        int64_t nblk = 256 * (per_cu < 32 ? per_cu : 32);                                                           \
-        if (nblk > b.n[k]) nblk = b.n[k];                                                                           \
-        MI_LAUNCH((k_spgemm_lds_pipe<T, LOG2S, NUMERIC>), dim3((unsigned)nblk), dim3(64), c.stream,                   \
-                  (const int32_t*)b.list[k], b.n[k], (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val,   \
-                  (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val, (int)upper, row_nnz, cptr, ccol,     \
-                  cval);                                                                                            \
-        b.n[k] = 0;                                                                                                 \
-    }
-        MI_SPGEMM_PIPE(0, 6)
-        MI_SPGEMM_PIPE(1, 7)
-        MI_SPGEMM_PIPE(2, 8)
-        MI_SPGEMM_PIPE(3, 9)
-#undef MI_SPGEMM_PIPE
         MI_SPGEMM_BIN(0, 6, 64, gw64)
         MI_SPGEMM_BIN(1, 7, 64, gw64)
         MI_SPGEMM_BIN(2, 8, 64, gw64)
