@@ -276,6 +276,35 @@ mi_sparse_status_t mi_sparse_get_info(mi_sparse_matrix_t A, int64_t *rows, int64
  * destroyed or re-ordered (mi_sparse_order may move a library-owned result's values to a new
  * block: fetch the pointers again after it).  Lets HBM-resident callers consume spmm / syrk results
  * without a host round trip. */
+/* mkl_sparse_?_export_bsr (reference _cfunctions.py:567-579; call site _common.py:540-551): the handle's matrix
+ * re-blocked with the block size it was created with (create_bsr) or produced with (mi_sparse_spmm of two BSR handles
+ * of one block size); blocks row-major (*block_layout = 101), library-owned host arrays valid until destroy.
+ * rows / cols / block_size are in BLOCKS.  Handles without a block size: NOT_SUPPORTED. */
+mi_sparse_status_t mi_sparse_s_export_bsr(mi_sparse_matrix_t A, int *base, int *block_layout, int32_t *rows,
+                                            int32_t *cols, int32_t *block_size, int32_t **rows_start,
+                                            int32_t **rows_end, int32_t **col_indx, float **values);
+mi_sparse_status_t mi_sparse_s_export_bsr_64(mi_sparse_matrix_t A, int *base, int *block_layout, int64_t *rows,
+                                               int64_t *cols, int64_t *block_size, int64_t **rows_start,
+                                               int64_t **rows_end, int64_t **col_indx, float **values);
+mi_sparse_status_t mi_sparse_d_export_bsr(mi_sparse_matrix_t A, int *base, int *block_layout, int32_t *rows,
+                                            int32_t *cols, int32_t *block_size, int32_t **rows_start,
+                                            int32_t **rows_end, int32_t **col_indx, double **values);
+mi_sparse_status_t mi_sparse_d_export_bsr_64(mi_sparse_matrix_t A, int *base, int *block_layout, int64_t *rows,
+                                               int64_t *cols, int64_t *block_size, int64_t **rows_start,
+                                               int64_t **rows_end, int64_t **col_indx, double **values);
+mi_sparse_status_t mi_sparse_c_export_bsr(mi_sparse_matrix_t A, int *base, int *block_layout, int32_t *rows,
+                                            int32_t *cols, int32_t *block_size, int32_t **rows_start,
+                                            int32_t **rows_end, int32_t **col_indx, mi_complex8 **values);
+mi_sparse_status_t mi_sparse_c_export_bsr_64(mi_sparse_matrix_t A, int *base, int *block_layout, int64_t *rows,
+                                               int64_t *cols, int64_t *block_size, int64_t **rows_start,
+                                               int64_t **rows_end, int64_t **col_indx, mi_complex8 **values);
+mi_sparse_status_t mi_sparse_z_export_bsr(mi_sparse_matrix_t A, int *base, int *block_layout, int32_t *rows,
+                                            int32_t *cols, int32_t *block_size, int32_t **rows_start,
+                                            int32_t **rows_end, int32_t **col_indx, mi_complex16 **values);
+mi_sparse_status_t mi_sparse_z_export_bsr_64(mi_sparse_matrix_t A, int *base, int *block_layout, int64_t *rows,
+                                               int64_t *cols, int64_t *block_size, int64_t **rows_start,
+                                               int64_t **rows_end, int64_t **col_indx, mi_complex16 **values);
+
 /* Copy the handle's matrix straight into CALLER-allocated arrays (host or device): indptr of rows + 1 (csc: cols + 1)
  * entries, indices and values of nnz entries (mi_sparse_get_info), indices of `index_bytes` (4 / 8) bytes each.  The
  * MKL-shaped mi_sparse_?_export_* calls hand out library-owned copies which the reference's Python then copies again

@@ -112,6 +112,9 @@ def _bind(lib):
             add("mi_sparse_%s_create_csr%s" % (t, sfx), [HP, _int, _i64, _i64, _vp, _vp, _vp, _vp])
             add("mi_sparse_%s_create_csc%s" % (t, sfx), [HP, _int, _i64, _i64, _vp, _vp, _vp, _vp])
             add("mi_sparse_%s_create_bsr%s" % (t, sfx), [HP, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp])
+            add("mi_sparse_%s_export_bsr%s" % (t, sfx),
+                [H, _ct.POINTER(_int), _ct.POINTER(_int), _vp, _vp, _vp, _ct.POINTER(_vp), _ct.POINTER(_vp), _ct.POINTER(_vp),
+                 _ct.POINTER(_vp)])
             for fmt in ("csr", "csc"):
                 add("mi_sparse_%s_export_%s%s" % (t, fmt, sfx),
                     [H, _ct.POINTER(_int), _vp, _vp, _ct.POINTER(_vp), _ct.POINTER(_vp), _ct.POINTER(_vp),

@@ -381,7 +381,8 @@ struct mi_sparse_matrix {
     void* user_val = nullptr;
     int user_base = 0;
     mi::SpmmPlan plan, planT;
-    mi::HostExport exp_csr, exp_csc;
+    mi::HostExport exp_csr, exp_csc, exp_bsr;
+    int64_t result_bs = 0;  // block size a product of two BSR handles is exported with (mkl_sparse_?_export_bsr)
     std::shared_ptr<void> staged;  // result handles of the staged product (mi_sparse_sp2m): symbolic-phase state
     std::mutex mtx;  // guards lazy derivation of csr / csrT / plans
 };

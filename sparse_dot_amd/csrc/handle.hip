@@ -890,6 +890,122 @@ static int export_generic(mi_sparse_matrix_t A, bool csc, int* base, I* rows, I*
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+// export as BSR (mkl_sparse_?_export_bsr, reference _common.py:503-609): the CSR the handle holds is re-blocked
+// on the device -- a block is stored when any of its bs x bs entries is.  One thread per block row walks the
+// distinct block columns in ascending order (rows sorted: the next one is a lower_bound per row); test-sized by
+// nature (the reference only reaches it for products of BSR operands).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t lb_col(const int32_t* col, int64_t lo, int64_t hi, int64_t key)
+{
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)col[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <typename T, bool FILL>
+__global__ void k_csr_to_bsr(int64_t brows, int64_t bs, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                             const T* __restrict__ val, int64_t* __restrict__ cnt, const int64_t* __restrict__ bptr,
+                             int32_t* __restrict__ bcol, T* __restrict__ bval)
+{
+    const int64_t bi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= brows) return;
+    int64_t n = 0, out = FILL ? bptr[bi] : 0;
+    int64_t cur = -1;  // last block column emitted
+    for (;;) {
+        int64_t next = INT64_MAX;
+        for (int64_t r = bi * bs; r < (bi + 1) * bs; ++r) {
+            const int64_t q = lb_col(col, ptr[r], ptr[r + 1], (cur + 1) * bs);
+            if (q < ptr[r + 1]) {
+                const int64_t b = (int64_t)col[q] / bs;
+                if (b < next) next = b;
+            }
+        }
+        if (next == INT64_MAX) break;
+        if (FILL) {
+            bcol[out] = (int32_t)next;
+            T* blk = bval + out * bs * bs;
+            for (int64_t k = 0; k < bs * bs; ++k) blk[k] = vt<T>::zero();
+            for (int64_t r = 0; r < bs; ++r) {
+                const int64_t row = bi * bs + r;
+                for (int64_t q = lb_col(col, ptr[row], ptr[row + 1], next * bs); q < ptr[row + 1] && (int64_t)col[q] < (next + 1) * bs; ++q)
+                    blk[r * bs + ((int64_t)col[q] - next * bs)] = vt<T>::add(blk[r * bs + ((int64_t)col[q] - next * bs)], val[q]);
+            }
+            ++out;
+        }
+        ++n;
+        cur = next;
+    }
+    if (!FILL) cnt[bi] = n;
+}
+
+template <typename I, typename T>
+static int export_bsr_generic(mi_sparse_matrix_t A, int* base, int* block_layout, I* brows_out, I* bcols_out, I* bs_out,
+                              I** ps, I** pe, I** idx, T** values)
+{
+    return guarded([&] {
+        mi_sparse_matrix* h = check_handle(A);
+        if (h->vtype != type_char<T>::value)
+            fail(MI_SPARSE_STATUS_INVALID_VALUE, "handle holds '%c' values, export asked for '%c'", h->vtype,
+                 type_char<T>::value);
+        const int64_t bs = h->bsr.valid ? h->bsr.bs : h->result_bs;
+        if (bs <= 0 || h->rows % bs || h->cols % bs)
+            fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "handle has no block size to export with (not created from / produced by BSR operands)");
+        Context& c = ctx();
+        c.scratch_reset();
+        Csr& m = need_csr(h);
+        if (!rows_sorted(m)) sort_csr(h->vtype, m);  // ordering the entries of a row does not change the matrix
+        const int64_t brows = h->rows / bs, bcols = h->cols / bs;
+        int64_t* cnt = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(brows + 1)));
+        int64_t* bptr = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(brows + 1)));
+        int64_t nblocks = 0;
+        if (brows) {
+            MI_LAUNCH((k_csr_to_bsr<T, false>), grid1d(brows, 128), dim3(128), c.stream, brows, bs, (const int64_t*)m.ptr,
+                      (const int32_t*)m.col, (const T*)m.val, cnt, (const int64_t*)nullptr, (int32_t*)nullptr, (T*)nullptr);
+            nblocks = exclusive_scan_i64(cnt, bptr, brows);
+        }
+        if (sizeof(I) == 4 && (nblocks > INT32_MAX || brows > INT32_MAX || bcols > INT32_MAX))
+            fail(MI_SPARSE_STATUS_ALLOC_FAILED, "matrix does not fit 32-bit indices; use the _64 entry point");
+        HostExport& e = h->exp_bsr;
+        e.ptr.resize(sizeof(I) * (size_t)(brows + 1));
+        e.col.resize(sizeof(I) * (size_t)(nblocks ? nblocks : 1));
+        e.val.resize(sizeof(T) * (size_t)(nblocks ? nblocks * bs * bs : 1));
+        if (brows) {
+            int32_t* bcol = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(nblocks + 1)));
+            T* bval = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)(nblocks * bs * bs + 1)));
+            MI_LAUNCH((k_csr_to_bsr<T, true>), grid1d(brows, 128), dim3(128), c.stream, brows, bs, (const int64_t*)m.ptr,
+                      (const int32_t*)m.col, (const T*)m.val, (int64_t*)nullptr, (const int64_t*)bptr, bcol, bval);
+            I* dptr = static_cast<I*>(c.scratch_alloc(sizeof(I) * (size_t)(brows + 1)));
+            MI_LAUNCH((k_export_ptr<I>), grid1d(brows + 1, 256), dim3(256), c.stream, (const int64_t*)bptr, brows + 1, dptr);
+            MI_HIP_CHECK(hipMemcpyAsync(e.ptr.data(), dptr, sizeof(I) * (size_t)(brows + 1), hipMemcpyDeviceToHost, c.stream));
+            if (nblocks) {
+                if (sizeof(I) == 4) {
+                    copy_d2h(e.col.data(), bcol, sizeof(int32_t) * (size_t)nblocks);
+                } else {
+                    I* dcol = static_cast<I*>(c.scratch_alloc(sizeof(I) * (size_t)nblocks));
+                    MI_LAUNCH((k_export_col<I>), grid1d_stride(nblocks, 256), dim3(256), c.stream, (const int32_t*)bcol, nblocks, dcol);
+                    copy_d2h(e.col.data(), dcol, sizeof(I) * (size_t)nblocks);
+                }
+                copy_d2h(e.val.data(), bval, sizeof(T) * (size_t)(nblocks * bs * bs));
+            }
+        } else {
+            memset(e.ptr.data(), 0, e.ptr.size());
+        }
+        c.sync();
+        if (base) *base = 0;
+        if (block_layout) *block_layout = MI_SPARSE_LAYOUT_ROW_MAJOR;
+        if (brows_out) *brows_out = (I)brows;
+        if (bcols_out) *bcols_out = (I)bcols;
+        if (bs_out) *bs_out = (I)bs;
+        if (ps) *ps = reinterpret_cast<I*>(e.ptr.data());
+        if (pe) *pe = reinterpret_cast<I*>(e.ptr.data()) + 1;
+        if (idx) *idx = reinterpret_cast<I*>(e.col.data());
+        if (values) *values = reinterpret_cast<T*>(e.val.data());
+    });
+}
+
 }  // namespace mi
 
 // ================================================================================================
@@ -970,6 +1086,24 @@ MI_DEFINE_CREATE(s, float, float)
 MI_DEFINE_CREATE(d, double, double)
 MI_DEFINE_CREATE(c, cfloat, mi_complex8)
 MI_DEFINE_CREATE(z, cdouble, mi_complex16)
+
+#define MI_DEFINE_EXPORT_BSR(letter, T, CT)                                                                          \
+    extern "C" mi_sparse_status_t mi_sparse_##letter##_export_bsr(mi_sparse_matrix_t A, int* base, int* block_layout,     \
+                                                                  int32_t* rows, int32_t* cols, int32_t* bs,              \
+                                                                  int32_t** rs, int32_t** re, int32_t** ci, CT** v)       \
+    {                                                                                                                    \
+        return mi::export_bsr_generic<int32_t, T>(A, base, block_layout, rows, cols, bs, rs, re, ci, (T**)v);            \
+    }                                                                                                                    \
+    extern "C" mi_sparse_status_t mi_sparse_##letter##_export_bsr_64(mi_sparse_matrix_t A, int* base, int* block_layout,  \
+                                                                     int64_t* rows, int64_t* cols, int64_t* bs,           \
+                                                                     int64_t** rs, int64_t** re, int64_t** ci, CT** v)    \
+    {                                                                                                                    \
+        return mi::export_bsr_generic<int64_t, T>(A, base, block_layout, rows, cols, bs, rs, re, ci, (T**)v);            \
+    }
+MI_DEFINE_EXPORT_BSR(s, float, float)
+MI_DEFINE_EXPORT_BSR(d, double, double)
+MI_DEFINE_EXPORT_BSR(c, mi::cfloat, mi_complex8)
+MI_DEFINE_EXPORT_BSR(z, mi::cdouble, mi_complex16)
 
 extern "C" {
 

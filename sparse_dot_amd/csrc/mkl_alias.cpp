@@ -9,7 +9,7 @@
 // MKL.  Every integer argument is declared 64 bits wide here and truncated under LP64: on the x86-64 SysV ABI an
 // `int` argument travels in a full register / stack slot whose upper half is unspecified, so one symbol serves both
 // layers.  Index ARRAYS are read as int32 or int64 accordingly (mi_*_create_* / *_64).
-// Out of the hot path (QR solver, PARDISO, CG / FGMRES, BSR export): present so that the import
+// Out of the hot path (QR solver, PARDISO, CG / FGMRES): present so that the import
 // resolves, they return SPARSE_STATUS_NOT_SUPPORTED / an error code and do nothing.
 #include <cstdint>
 #include <cstdio>
@@ -99,9 +99,13 @@ void MKL_Get_Version_String(char* buf, int len)
                        : mi_sparse_##t##_export_csc(A, base, (int32_t*)rows, (int32_t*)cols, (int32_t**)cs,              \
                                                     (int32_t**)ce, (int32_t**)ri, v);                                    \
     }                                                                                                                    \
-    int mkl_sparse_##t##_export_bsr(H, int*, int*, void*, void*, void*, void**, void**, void**, CT**)                    \
+    int mkl_sparse_##t##_export_bsr(H A, int* base, int* layout, void* rows, void* cols, void* bs, void** rs, void** re, \
+                                    void** ci, CT** v)                                                                   \
     {                                                                                                                    \
-        return MI_SPARSE_STATUS_NOT_SUPPORTED; /* results are kept as CSR; the Python layer re-blocks them */            \
+        return g_ilp64 ? mi_sparse_##t##_export_bsr_64(A, base, layout, (int64_t*)rows, (int64_t*)cols, (int64_t*)bs,     \
+                                                       (int64_t**)rs, (int64_t**)re, (int64_t**)ci, v)                   \
+                       : mi_sparse_##t##_export_bsr(A, base, layout, (int32_t*)rows, (int32_t*)cols, (int32_t*)bs,        \
+                                                    (int32_t**)rs, (int32_t**)re, (int32_t**)ci, v);                     \
     }
 ALIAS_CREATE(s, float)
 ALIAS_CREATE(d, double)

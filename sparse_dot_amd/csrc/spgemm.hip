@@ -1679,6 +1679,8 @@ mi_sparse_status_t mi_sparse_spmm(int op, mi_sparse_matrix_t A, mi_sparse_matrix
         mi::Csr& b = mi::need_csr(hb);
         const int ib = ha->index_bytes > hb->index_bytes ? ha->index_bytes : hb->index_bytes;
         mi_sparse_matrix* r = mi::new_result_handle(ha->vtype, ib, ha->rows, hb->cols);
+        // MKL keeps the operands' format: the product of two BSR handles with one block size is exportable as BSR
+        if (ha->bsr.valid && hb->bsr.valid && ha->bsr.bs == hb->bsr.bs) r->result_bs = ha->bsr.bs;
         try {
             mi::spgemm(ha->vtype, a, b, false, r->csr);
             mi::ctx().sync();

@@ -20,4 +20,4 @@ c = s.dot_product_mkl(a, a.T.tocsr()); print("spgemm max err", np.abs(c.toarray(
 g = s.gram_matrix_mkl(a, dense=True); print("gram  max err", np.abs(np.triu(g) - np.triu((a.T @ a).toarray())).max())
 PY
 # the reference's own tests (pytest collects them from the read-only tree; cache disabled)
-timeout ${ALIAS_TEST_TIMEOUT:-3000} python3 -m pytest -p no:cacheprovider -q -x ${ALIAS_TESTS:-/root/reference/sparse_dot_mkl/tests/test_sparse_dense.py /root/reference/sparse_dot_mkl/tests/test_sparse_sparse.py /root/reference/sparse_dot_mkl/tests/test_gram_matrix.py /root/reference/sparse_dot_mkl/tests/test_dense_dense.py /root/reference/sparse_dot_mkl/tests/test_sparse_vector.py} 2>&1 | tail -15
+timeout ${ALIAS_TEST_TIMEOUT:-3000} python3 -m pytest -p no:cacheprovider -q ${ALIAS_TESTS:-/root/reference/sparse_dot_mkl/tests/test_sparse_dense.py /root/reference/sparse_dot_mkl/tests/test_sparse_sparse.py /root/reference/sparse_dot_mkl/tests/test_gram_matrix.py /root/reference/sparse_dot_mkl/tests/test_dense_dense.py /root/reference/sparse_dot_mkl/tests/test_sparse_vector.py} 2>&1 | tail -15
