@@ -165,6 +165,41 @@ class SparseHandle:
         return ctor((data, indices, indptr), shape=(rows, cols))
 
 
+    def export_bsr(self, output_type="bsr_matrix"):
+        """The handle's matrix as a scipy BSR object, re-blocked ON THE DEVICE with the block size the handle was created
+        with / produced with (mi_sparse_?_export_bsr, the replacement of mkl_sparse_?_export_bsr; reference
+        _common.py:503-609)."""
+        ctor = _NAMED_TYPES[output_type.lower()]
+        rows, cols, nnz, letter, index_bytes = self.info()
+        dtype = _output_dtypes[{"s": (False, False), "d": (True, False), "c": (False, True), "z": (True, True)}[letter]]
+        wide = index_bytes == 8 or max(rows, cols) > _INT32_MAX
+        itype, ctype = (_np.int64, _ct.c_int64) if wide else (_np.int32, _ct.c_int32)
+        name = "mi_sparse_%s_export_bsr%s" % (letter, "_64" if wide else "")
+        base, layout = _ct.c_int(), _ct.c_int()
+        br, bc, bs = ctype(), ctype(), ctype()
+        p_start, p_end, p_idx, p_val = _ct.c_void_p(), _ct.c_void_p(), _ct.c_void_p(), _ct.c_void_p()
+        ret = MI.call(name, self.ptr, _ct.byref(base), _ct.byref(layout), _ct.byref(br), _ct.byref(bc), _ct.byref(bs),
+                      _ct.byref(p_start), _ct.byref(p_end), _ct.byref(p_idx), _ct.byref(p_val))
+        _check_return_value(ret, name)
+        b = bs.value
+
+        def view(ptr, count, np_dtype):
+            buf = (_ct.c_char * (count * _np.dtype(np_dtype).itemsize)).from_address(ptr.value)
+            return _np.frombuffer(buf, dtype=np_dtype, count=count).copy()  # library memory dies with the handle
+
+        if br.value == 0 or bc.value == 0:
+            return ctor((rows, cols), dtype=dtype, blocksize=(b, b))
+        indptr = view(p_start, br.value + 1, itype)
+        nblocks = int(indptr[-1])
+        if nblocks == 0:
+            return ctor((rows, cols), dtype=dtype, blocksize=(b, b))
+        indices = view(p_idx, nblocks, itype)
+        data = view(p_val, nblocks * b * b, dtype).reshape(nblocks, b, b)
+        if layout.value != LAYOUT_CODE_C:
+            data = _np.ascontiguousarray(data.transpose(0, 2, 1))
+        return ctor((data, indices, indptr), shape=(rows, cols), blocksize=(b, b))
+
+
 # ---- reference-style functional surface (same call shapes as the reference's helpers) ----------------
 def _create_mi_sparse(matrix):
     """scipy CSR / CSC / BSR -> (handle, double_precision, complex_type)."""

@@ -63,9 +63,12 @@ def _sparse_dot_sparse(matrix_a, matrix_b, cast=False, reorder_output=False, den
                 hc.order()
                 t = debug_timer("Reordered output indices", t)
             if is_bsr(matrix_a):
-                # the backend computes on the expanded CSR; re-block on the way out
-                csr = hc.export("csr_array" if output_type.endswith("array") else "csr_matrix")
-                result = make_output(csr, blocksize=matrix_a.blocksize)
+                if is_bsr(matrix_b) and matrix_a.blocksize == matrix_b.blocksize:
+                    result = hc.export_bsr(output_type)  # re-blocked on the device (mi_sparse_?_export_bsr)
+                else:
+                    # the backend computes on the expanded CSR; blocks of A's size are cut on the host
+                    csr = hc.export("csr_array" if output_type.endswith("array") else "csr_matrix")
+                    result = make_output(csr, blocksize=matrix_a.blocksize)
             else:
                 result = hc.export(output_type)
             debug_timer("Created python handle", t)

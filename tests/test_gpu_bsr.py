@@ -76,3 +76,31 @@ def test_bsr_block_layout_column_major_and_device_matrix(gpu, oracle):
             assert np.allclose(got, want * (k + 1), rtol=1e-12, atol=0)
     finally:
         dm.free()
+
+
+@pytest.mark.parametrize("bs", [1, 3, 4, 10])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex128])
+def test_bsr_product_exported_as_bsr(gpu, dtype, bs):
+    """BSR x BSR -> BSR: the product handle remembers the block size and mi_sparse_?_export_bsr re-blocks it on the device
+    (reference _common.py:503-609; MKL keeps the operands' format)."""
+    rng = np.random.default_rng(bs + 40)
+    d1 = (rng.random((30 * bs, 20 * bs)) < 0.05) * rng.uniform(0.5, 1.5, (30 * bs, 20 * bs))
+    d2 = (rng.random((20 * bs, 25 * bs)) < 0.05) * rng.uniform(0.5, 1.5, (20 * bs, 25 * bs))
+    if np.dtype(dtype).kind == "c":
+        d1 = d1 + 1j * (d1 != 0)
+        d2 = d2 - 1j * (d2 != 0)
+    a = sps.bsr_matrix(d1.astype(dtype), blocksize=(bs, bs))
+    b = sps.bsr_matrix(d2.astype(dtype), blocksize=(bs, bs))
+    got = gpu.dot_product_mkl(a, b)
+    want = sps.bsr_matrix(d1 @ d2, blocksize=(bs, bs))
+    want.sort_indices()
+    assert isinstance(got, sps.bsr_matrix) and got.blocksize == (bs, bs) and got.dtype == dtype and got.shape == want.shape
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)  # same block structure
+    assert np.allclose(got.toarray(), d1 @ d2, rtol=_tol(dtype), atol=0)
+    # the BSR array class, and a handle with no block size -> NOT_SUPPORTED through the ABI
+    ga = gpu.dot_product_mkl(sps.bsr_array(a), sps.bsr_array(b))
+    assert type(ga).__name__ == "bsr_array" and np.allclose(ga.toarray(), d1 @ d2, rtol=_tol(dtype), atol=0)
+    from sparse_dot_amd._mi_interface import SparseHandle
+    with SparseHandle.from_scipy(a.tocsr()) as h:
+        with pytest.raises(ValueError, match="NOT_SUPPORTED"):
+            h.export_bsr()
