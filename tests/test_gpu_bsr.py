@@ -92,10 +92,15 @@ def test_bsr_product_exported_as_bsr(gpu, dtype, bs):
     a = sps.bsr_matrix(d1.astype(dtype), blocksize=(bs, bs))
     b = sps.bsr_matrix(d2.astype(dtype), blocksize=(bs, bs))
     got = gpu.dot_product_mkl(a, b)
-    want = sps.bsr_matrix(d1 @ d2, blocksize=(bs, bs))
+    # block structure = the structural product of the two BLOCK patterns (a stored block is bs x bs stored values, zeros
+    # included, exactly as MKL treats BSR operands; scipy's dense round trip would drop numerically empty blocks)
+    pa = sps.csr_matrix((np.ones(a.indices.size), a.indices, a.indptr), shape=(30, 20))
+    pb = sps.csr_matrix((np.ones(b.indices.size), b.indices, b.indptr), shape=(20, 25))
+    want = (pa @ pb).tocsr()
     want.sort_indices()
-    assert isinstance(got, sps.bsr_matrix) and got.blocksize == (bs, bs) and got.dtype == dtype and got.shape == want.shape
-    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)  # same block structure
+    assert isinstance(got, sps.bsr_matrix) and got.blocksize == (bs, bs) and got.dtype == dtype
+    assert got.shape == (30 * bs, 25 * bs)
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
     assert np.allclose(got.toarray(), d1 @ d2, rtol=_tol(dtype), atol=0)
     # the BSR array class, and a handle with no block size -> NOT_SUPPORTED through the ABI
     ga = gpu.dot_product_mkl(sps.bsr_array(a), sps.bsr_array(b))
