@@ -136,6 +136,32 @@ __device__ __forceinline__ int flat_find(const int* inc, int f)
     return l;
 }
 
+// Walking the flat product list: a WAVE takes 64 * U consecutive products (lane + 64 u), so the products of one lane
+// are 64 apart and mostly stay inside one slice (the B rows that matter are long): the slice of the first is found by
+// bisection, the following ones by stepping forward -- about one LDS read per product instead of log2(N) + 2.
+template <int N>
+struct FlatCursor {
+    int l, lo, hi;  // slice l holds the flat positions [lo, hi)
+    __device__ __forceinline__ void seek(const int* inc, int f)
+    {
+        l = flat_find<N>(inc, f);
+        lo = l ? inc[l - 1] : 0;
+        hi = inc[l];
+    }
+    // f >= the previous position and < the total; true when the slice changed
+    __device__ __forceinline__ bool advance(const int* inc, int f)
+    {
+        bool moved = false;
+        while (f >= hi) {
+            ++l;
+            lo = hi;
+            hi = inc[l];
+            moved = true;
+        }
+        return moved;
+    }
+};
+
 // ---- LDS hash kernel: one workgroup per row -------------------------------------------------------
 // The B rows selected by the row of A are taken THREADS at a time: every thread fetches the extent of
 // one of them, a workgroup scan turns the lengths into offsets, and the products are walked as one flat
@@ -194,18 +220,30 @@ __global__ void __launch_bounds__(THREADS)
         }
         block_scan_inclusive<THREADS>(len, inc, wave_tot, tid);
         const int total = inc[THREADS - 1];
-        for (int f0 = tid; f0 < total; f0 += THREADS * LDS_UNROLL) {
+        for (int g0 = 0; g0 < total; g0 += THREADS * LDS_UNROLL) {
             int32_t j[LDS_UNROLL];
             T v[LDS_UNROLL];
+            const int f0 = g0 + (tid >> 6) * 64 * LDS_UNROLL + (tid & 63);
+            FlatCursor<THREADS> cur;
+            int64_t qb = 0;
+            T av = vt<T>::zero();
+            if (f0 < total) {
+                cur.seek(inc, f0);
+                qb = qlo[cur.l];
+                if (NUMERIC) av = a_s[cur.l];
+            }
 #pragma unroll
             for (int u = 0; u < LDS_UNROLL; ++u) {
-                const int f = f0 + u * THREADS;
+                const int f = f0 + u * 64;
                 j[u] = -1;
                 if (f < total) {
-                    const int l = flat_find<THREADS>(inc, f);
-                    const int64_t q = qlo[l] + (f - (l ? inc[l - 1] : 0));
+                    if (u && cur.advance(inc, f)) {
+                        qb = qlo[cur.l];
+                        if (NUMERIC) av = a_s[cur.l];
+                    }
+                    const int64_t q = qb + (f - cur.lo);
                     j[u] = bcol[q];
-                    if (NUMERIC) v[u] = vt<T>::mul(a_s[l], bval[q]);
+                    if (NUMERIC) v[u] = vt<T>::mul(av, bval[q]);
                 }
             }
 #pragma unroll
@@ -503,12 +541,16 @@ __global__ void __launch_bounds__(256)
 #define MI_PART_UNROLL 2
 #endif
 #ifndef MI_BITMAP_UNROLL
-#define MI_BITMAP_UNROLL 4
+#define MI_BITMAP_UNROLL 8
 #endif
 #ifndef MI_PART_THREADS
 #define MI_PART_THREADS 512
 #endif
 constexpr int PART_THREADS = MI_PART_THREADS;
+#ifndef MI_PART_GROUP
+#define MI_PART_GROUP 1
+#endif
+constexpr int PART_GROUP = MI_PART_GROUP;  // consecutive ranges of a big row per workgroup (k_spgemm_part)
 constexpr int PART_UNROLL = MI_PART_UNROLL;
 constexpr int BITMAP_UNROLL = MI_BITMAP_UNROLL;
 
@@ -575,15 +617,22 @@ __global__ void __launch_bounds__(1024)
             block_scan_inclusive<1024>(len, scan, wave_tot, tid);
             const int* inc = scan;
             const int total = inc[1023];
-            for (int f0 = tid; f0 < total; f0 += 1024 * BITMAP_UNROLL) {
+            for (int g0 = 0; g0 < total; g0 += 1024 * BITMAP_UNROLL) {
                 int32_t j[BITMAP_UNROLL];
+                const int f0 = g0 + (tid >> 6) * 64 * BITMAP_UNROLL + (tid & 63);
+                FlatCursor<1024> cur;
+                int64_t qb = 0;
+                if (f0 < total) {
+                    cur.seek(inc, f0);
+                    qb = qlo[cur.l];
+                }
 #pragma unroll
                 for (int u = 0; u < BITMAP_UNROLL; ++u) {
-                    const int f = f0 + u * 1024;
+                    const int f = f0 + u * 64;
                     j[u] = -1;
                     if (f < total) {
-                        const int l = flat_find<1024>(inc, f);
-                        j[u] = bcol[qlo[l] + (f - (l ? inc[l - 1] : 0))];
+                        if (u && cur.advance(inc, f)) qb = qlo[cur.l];
+                        j[u] = bcol[qb + (f - cur.lo)];
                     }
                 }
 #pragma unroll
@@ -654,6 +703,10 @@ __global__ void k_part_items(const int32_t* __restrict__ row_list, const int64_t
 // for the literal configs[2]; inside k_spgemm_part the same searches are dependent loads in a
 // workgroup-synchronous phase, which is slower still.)
 constexpr int SLICE_EB = 32;  // nonzeros of A per wave
+#ifndef MI_SLICE_ILP
+#define MI_SLICE_ILP 4
+#endif
+constexpr int SLICE_ILP = MI_SLICE_ILP;  // bisections in flight per lane
 
 __global__ void k_part_slice_sizes(const int32_t* __restrict__ row_list, const int64_t* __restrict__ item_off,
                                    const int64_t* __restrict__ aptr, int64_t nb, int64_t* __restrict__ n_work,
@@ -713,16 +766,45 @@ __global__ void __launch_bounds__(256)
         x = rb[p0 + pl];
         if (upper && x < row) x = row;
     }
-    for (int eo = 0; eo < ne; eo += el_n) {
-        const int e = eo + el;
-        if (e < ne && p_ok) {
-            const int32_t kk = acol[a0 + e0 + e];
-            const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
-            int64_t pos;
-            if (is_end) pos = b1;
-            else if (x <= 0) pos = b0;
-            else pos = lower_bound_col(bcol, b0, b1, x);
-            tile[pl][e] = (int32_t)pos;
+    // SLICE_ILP nonzeros per lane at a time: their bisections advance in lockstep with unconditional loads, so
+    // SLICE_ILP dependent chains are in flight per lane (one search after the other was ~10 dependent cache
+    // round trips per nonzero, 32 nonzeros per wave in sequence: the kernel waited 85 % of its cycles)
+    for (int eo = 0; eo < ne; eo += el_n * SLICE_ILP) {
+        int64_t lo[SLICE_ILP], hi[SLICE_ILP];
+#pragma unroll
+        for (int u = 0; u < SLICE_ILP; ++u) {
+            const int e = eo + u * el_n + el;
+            lo[u] = hi[u] = 0;
+            if (e < ne && p_ok) {
+                const int32_t kk = acol[a0 + e0 + e];
+                const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
+                if (is_end) lo[u] = hi[u] = b1;
+                else if (x <= 0) lo[u] = hi[u] = b0;
+                else lo[u] = b0, hi[u] = b1;
+            }
+        }
+        for (;;) {  // first position in [lo, hi) with column >= x, all searches together
+            bool any = false;
+            int32_t c[SLICE_ILP];
+            int64_t mid[SLICE_ILP];
+#pragma unroll
+            for (int u = 0; u < SLICE_ILP; ++u) {
+                mid[u] = (lo[u] + hi[u]) >> 1;
+                c[u] = bcol[lo[u] < hi[u] ? mid[u] : 0];  // finished searches load a harmless element
+            }
+#pragma unroll
+            for (int u = 0; u < SLICE_ILP; ++u) {
+                if (lo[u] < hi[u]) {
+                    if (c[u] < x) lo[u] = mid[u] + 1; else hi[u] = mid[u];
+                    any = true;
+                }
+            }
+            if (!any) break;
+        }
+#pragma unroll
+        for (int u = 0; u < SLICE_ILP; ++u) {
+            const int e = eo + u * el_n + el;
+            if (e < ne && p_ok) tile[pl][e] = (int32_t)lo[u];
         }
     }
     // LDS is only shared inside the wave: lanes run in lockstep, a compiler / LDS fence is all that is needed
@@ -748,13 +830,13 @@ struct alignas(64) PartDesc {
     int64_t out0;           // cptr[row]
     int64_t boff;           // the row's range starts in bounds
     int32_t row, npass;
-    int64_t pad_;
+    int64_t group0;         // first workgroup of the row (a workgroup takes PART_GROUP consecutive ranges)
 };
 
 __global__ void k_part_desc(const int32_t* __restrict__ row_list, int64_t nb, const int64_t* __restrict__ item_off,
                             const int64_t* __restrict__ aptr, const int64_t* __restrict__ slice_base,
                             const int64_t* __restrict__ cptr, const int64_t* __restrict__ boff_by_row,
-                            PartDesc* __restrict__ desc)
+                            const int64_t* __restrict__ group_off, PartDesc* __restrict__ desc)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nb) return;
@@ -768,7 +850,7 @@ __global__ void k_part_desc(const int32_t* __restrict__ row_list, int64_t nb, co
     d.boff = boff_by_row[row];
     d.row = row;
     d.npass = (int32_t)(item_off[t + 1] - item_off[t]);
-    d.pad_ = 0;
+    d.group0 = group_off[t];
     desc[t] = d;
 }
 
@@ -783,6 +865,13 @@ __global__ void k_part_item_map(int64_t n_items, int64_t nb, const int64_t* __re
         }
         item_t[g] = (int32_t)lo;
     }
+}
+
+// workgroups per big row: PART_GROUP consecutive ranges each
+__global__ void k_part_groups(const int64_t* __restrict__ items, int64_t nb, int64_t* __restrict__ groups)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nb) groups[t] = (items[t] + PART_GROUP - 1) / PART_GROUP;
 }
 
 template <typename T, int LOG2S, bool PRE>
@@ -805,16 +894,15 @@ __global__ void __launch_bounds__(PART_THREADS)
     const int tid = threadIdx.x;
     const int64_t item = item_base + blockIdx.x;
     const PartDesc d = desc[item_t[item]];
-    const int64_t pass = item - d.item0;
+    // PART_GROUP consecutive ranges of the row, one after the other: the descriptor is loaded once and the first
+    // slices of the next range are fetched while the current one is walked.  Measured on the literal configs[2]
+    // (profiles/r02_spgemm_group_ab.log): 1 / 2 / 4 / 8 / 16 ranges per workgroup = 237 / 246 / 247 / 246 / 249 ms
+    // -- with four workgroups resident per CU the dependent chain item -> descriptor -> slices -> B entries is
+    // already overlapped across workgroups -- so the default stays 1; kept as a tuning hook.
+    const int64_t p_first = (item - d.group0) * PART_GROUP;
+    const int64_t p_last = p_first + PART_GROUP < d.npass ? p_first + PART_GROUP : d.npass;
     const int32_t row = d.row;
-    int32_t c_lo = 0;
-    int64_t c_hi = ncols;
-    if constexpr (!PRE) {
-        const int32_t* rb = bounds + d.boff;
-        c_lo = rb[pass];
-        if (pass + 1 < d.npass) c_hi = rb[pass + 1];
-        if (upper && c_lo < row) c_lo = row;
-    }
+    const int32_t* rb = bounds + d.boff;
     for (int k = tid; k < S; k += NT) {
         keys[k] = HASH_EMPTY;
         vals[k] = vt<T>::zero();
@@ -822,19 +910,21 @@ __global__ void __launch_bounds__(PART_THREADS)
     if (tid == 0) n_out = 0;
     __syncthreads();
     const int64_t a0 = d.a0, a1 = d.a0 + d.na;
-    // slice of B row acol[p] that falls in [c_lo, c_hi), and the A value: loaded one chunk ahead so that the
-    // latency of these loads is hidden behind the product walk of the current chunk
+    // slice of B row acol[p] that falls in the range's columns [c_lo, c_hi), and the A value: loaded one chunk ahead so
+    // that the latency of these loads is hidden behind the product walk of the current chunk
     int64_t s_n = 0, e_n = 0;
     T a_n = vt<T>::zero();
-    const int32_t* sl0 = nullptr;
-    if constexpr (PRE) sl0 = bnd + d.slice_base + pass * d.na;  // slices precomputed by k_part_slices
-    auto fetch = [&](int64_t p) {
+    auto fetch = [&](int64_t pass, int64_t p) {
         s_n = e_n = 0;
         if (p < a1) {
             if constexpr (PRE) {
+                const int32_t* sl0 = bnd + d.slice_base + pass * d.na;  // slices precomputed by k_part_slices
                 s_n = sl0[p - a0];
                 e_n = sl0[p - a0 + (a1 - a0)];
             } else {
+                int32_t c_lo = rb[pass];
+                const int64_t c_hi = pass + 1 < d.npass ? rb[pass + 1] : ncols;
+                if (upper && c_lo < row) c_lo = row;
                 const int32_t kk = acol[p];
                 const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
                 s_n = b0;
@@ -847,55 +937,75 @@ __global__ void __launch_bounds__(PART_THREADS)
             a_n = aval[p];
         }
     };
-    fetch(a0 + tid);
-    for (int64_t base = a0; base < a1; base += NT) {
-        // 1. this chunk's slices into LDS, the next chunk's on their way
-        qlo[tid] = s_n;
-        a_s[tid] = a_n;
-        const int len = (int)(e_n - s_n);
-        fetch(base + NT + tid);
-        // 2. inclusive scan of the slice lengths
-        block_scan_inclusive<NT>(len, pre, wave_tot, tid);
-        const int* inc = pre;
-        const int total = inc[NT - 1];
-        // 3. the slices as one flat list of products
-        for (int f0 = tid; f0 < total; f0 += NT * PART_UNROLL) {
-            int32_t j[PART_UNROLL];
-            T v[PART_UNROLL];
+    fetch(p_first, a0 + tid);
+    for (int64_t pass = p_first; pass < p_last; ++pass) {
+        for (int64_t base = a0; base < a1; base += NT) {
+            // 1. this chunk's slices into LDS, the next chunk's (or the next range's first) on their way
+            qlo[tid] = s_n;
+            a_s[tid] = a_n;
+            const int len = (int)(e_n - s_n);
+            if (base + NT < a1) fetch(pass, base + NT + tid);
+            else if (pass + 1 < p_last) fetch(pass + 1, a0 + tid);
+            // 2. inclusive scan of the slice lengths
+            block_scan_inclusive<NT>(len, pre, wave_tot, tid);
+            const int* inc = pre;
+            const int total = inc[NT - 1];
+            // 3. the slices as one flat list of products
+            // (binary search per product, not the stepping cursor of the other kernels: the slices of ONE range are
+            // short -- ~12 products -- and stepping over five of them per product costs more than the search)
+            for (int f0 = tid; f0 < total; f0 += NT * PART_UNROLL) {
+                int32_t j[PART_UNROLL];
+                T v[PART_UNROLL];
 #pragma unroll
-            for (int u = 0; u < PART_UNROLL; ++u) {
-                const int f = f0 + u * NT;
-                j[u] = -1;
-                if (f < total) {
-                    const int l = flat_find<NT>(inc, f);
-                    const int64_t q = qlo[l] + (f - (l ? inc[l - 1] : 0));
-                    j[u] = bcol[q];
-                    v[u] = vt<T>::mul(a_s[l], bval[q]);
+                for (int u = 0; u < PART_UNROLL; ++u) {
+                    const int f = f0 + u * NT;
+                    j[u] = -1;
+                    if (f < total) {
+                        const int l = flat_find<NT>(inc, f);
+                        const int64_t q = qlo[l] + (f - (l ? inc[l - 1] : 0));
+                        j[u] = bcol[q];
+                        v[u] = vt<T>::mul(a_s[l], bval[q]);
+                    }
+                }
+                // first probe of every product issued back to back (the compare-and-swap returns a value: its latency
+                // is paid once per batch, not once per product); the few collisions continue one at a time
+                uint32_t hs[PART_UNROLL];
+                int32_t was[PART_UNROLL];
+#pragma unroll
+                for (int u = 0; u < PART_UNROLL; ++u) {
+                    hs[u] = hash_col(j[u] < 0 ? 0 : j[u], LOG2S);
+                    was[u] = j[u];
+                    if (j[u] >= 0) was[u] = atomicCAS(&keys[hs[u]], HASH_EMPTY, j[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < PART_UNROLL; ++u) {
+                    if (j[u] < 0) continue;
+                    uint32_t hsh = hs[u];
+                    int32_t old = was[u];
+                    while (!(old == HASH_EMPTY || old == j[u])) {
+                        hsh = (hsh + 1) & (S - 1);
+                        old = atomicCAS(&keys[hsh], HASH_EMPTY, j[u]);
+                    }
+                    atomic_accum(&vals[hsh], v[u]);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < PART_UNROLL; ++u) {
-                if (j[u] < 0) continue;
-                uint32_t hsh = hash_col(j[u], LOG2S);
-                for (;;) {
-                    const int32_t old = atomicCAS(&keys[hsh], HASH_EMPTY, j[u]);
-                    if (old == HASH_EMPTY || old == j[u]) {
-                        atomic_accum(&vals[hsh], v[u]);
-                        break;
-                    }
-                    hsh = (hsh + 1) & (S - 1);
-                }
+            __syncthreads();
+        }
+        // the range's entries out, the table left empty for the next range
+        const int64_t out0 = d.out0 + pass * cap;
+        for (int k = tid; k < S; k += NT) {
+            const int32_t key = keys[k];
+            if (key != HASH_EMPTY) {
+                const int pos = atomicAdd(&n_out, 1);
+                ccol[out0 + pos] = key;
+                cval[out0 + pos] = vals[k];
+                keys[k] = HASH_EMPTY;
+                vals[k] = vt<T>::zero();
             }
         }
-        __syncthreads();
-    }
-    const int64_t out0 = d.out0 + pass * cap;
-    for (int k = tid; k < S; k += NT) {
-        const int32_t key = keys[k];
-        if (key != HASH_EMPTY) {
-            const int pos = atomicAdd(&n_out, 1);
-            ccol[out0 + pos] = key;
-            cval[out0 + pos] = vals[k];
+        if (pass + 1 < p_last) {
+            __syncthreads();
+            if (tid == 0) n_out = 0;  // ordered before the next compaction by the barriers of the next range's walk
         }
     }
 }
@@ -1156,26 +1266,33 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                                   (const int64_t*)slice_base, bnd);
                     });
                 }
+                // work items of the numeric kernel: groups of PART_GROUP consecutive ranges of a row
+                int64_t* groups = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                int64_t* group_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                MI_LAUNCH(k_part_groups, dim3((unsigned)ceil_div(nbig, 256)), dim3(256), c.stream, (const int64_t*)items, nbig,
+                          groups);
+                const int64_t n_groups = exclusive_scan_i64(groups, group_off, nbig);
                 PartDesc* desc = static_cast<PartDesc*>(c.scratch_alloc(sizeof(PartDesc) * (size_t)(nbig + 1)));
-                int32_t* item_t = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(n_items + 1)));
+                int32_t* item_t = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(n_groups + 1)));
                 MI_LAUNCH(k_part_desc, dim3((unsigned)ceil_div(nbig, 256)), dim3(256), c.stream, (const int32_t*)big_list, nbig,
-                          (const int64_t*)item_off, (const int64_t*)A.ptr, (const int64_t*)slice_base, cptr, brow, desc);
-                if (n_items) {
-                    const int64_t gb = ceil_div(n_items, 256);
-                    MI_LAUNCH(k_part_item_map, dim3((unsigned)(gb < (1 << 20) ? gb : (1 << 20))), dim3(256), c.stream, n_items,
-                              nbig, (const int64_t*)item_off, item_t);
+                          (const int64_t*)item_off, (const int64_t*)A.ptr, (const int64_t*)slice_base, cptr, brow,
+                          (const int64_t*)group_off, desc);
+                if (n_groups) {
+                    const int64_t gb = ceil_div(n_groups, 256);
+                    MI_LAUNCH(k_part_item_map, dim3((unsigned)(gb < (1 << 20) ? gb : (1 << 20))), dim3(256), c.stream, n_groups,
+                              nbig, (const int64_t*)group_off, item_t);
                 }
                 auto launch = [&](auto log2s_tag, auto pre_tag) {
                     constexpr int L = decltype(log2s_tag)::value;
                     constexpr bool P = decltype(pre_tag)::value;
-                    launch_batched(n_items, PART_THREADS, [&](int64_t off, int64_t nblk) {
+                    launch_batched(n_groups, PART_THREADS, [&](int64_t off, int64_t nblk) {
                         MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)nblk), dim3(PART_THREADS), c.stream, off,
                                   (const int32_t*)item_t, (const PartDesc*)desc, bounds, B.cols, CAP, (const int32_t*)A.col,
                                   (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val, upper,
                                   (const int32_t*)bnd, ccol, cval);
                     });
                 };
-                if (n_items) {
+                if (n_groups) {
                     constexpr int LO = sizeof(T) >= 16 ? 10 : 11, HI = LO + 1;
                     using lo_t = std::integral_constant<int, LO>;
                     using hi_t = std::integral_constant<int, HI>;
