@@ -247,6 +247,7 @@ void pool_reset_cap();  // re-read pool_max_mb on the next release
 struct Context {
     bool initialised = false;
     int device = -1;  // -1: adopt the calling thread's current HIP device at first use (mi_sparse_set_device overrides)
+    int cus = 0;      // compute units of `device` (persistent-kernel grids)
     hipStream_t stream = nullptr;
     // grow-only scratch arena; kernels on one stream execute in order, so a later call may reuse
     // the arena as soon as it is enqueued behind the earlier one
@@ -434,6 +435,7 @@ struct Options {
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory
     int64_t trace_phases = 0;      // print host wall-clock per SpGEMM phase to stderr (diagnostics; synchronises)
+    int64_t gram_persistent = 4;   // dense gram: workgroups per LDS slot of the chip walking the tile list (0: one workgroup per tile)
     int64_t gram_tile_kb = 128;    // dense gram, outputs wider than one 64 KiB tile: LDS tile of 128 (default) or 64 KiB
     int64_t bsr_native = 1;        // BSR handles x row-major dense: the block kernel (0: always the CSR expansion)
     int64_t staged_copies = 1;     // large pageable host <-> device copies through the parallel pinned stager (0: plain hipMemcpy)

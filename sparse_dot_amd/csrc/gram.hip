@@ -17,10 +17,24 @@ namespace mi {
 // same column), and the finished tile is written to HBM exactly once, coalesced, with beta applied
 // on the way -- no global atomics, no separate scaling pass.  Tiles start at the diagonal (only
 // col >= row is produced).
+// `src` is the same in every lane: v_readlane_b32 -- the result is a scalar register and nothing goes through the LDS
+// queue (as __shfl / ds_bpermute it was five LDS-pipeline instructions per selected row, next to that row's one LDS
+// atomic, and kept the per-row scalars in vector registers)
 template <typename T>
 __device__ __forceinline__ T shfl_bcast(T v, int src)
 {
+#ifdef MI_HIP_EMU
     return __shfl(v, src);
+#else
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "shfl_bcast: 4- or 8-byte values");
+    int w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); ++k) w[k] = __builtin_amdgcn_readlane(w[k], src);
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+#endif
 }
 
 // LDS tile of one workgroup: TKB KiB of accumulators.  64 KiB (two 512-thread workgroups per CU) or 128 KiB (one
@@ -34,19 +48,24 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     k_syrkd_lds(int64_t n, int64_t row0, int64_t row_end, int64_t tiles_per_row, const int64_t* __restrict__ tptr, const int32_t* __restrict__ tcol,
                 const T* __restrict__ tval, const int64_t* __restrict__ xptr, const int32_t* __restrict__ xcol,
                 const T* __restrict__ xval, T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta,
-                int beta_zero)
+                int beta_zero, int64_t n_virtual)
 {
     constexpr int TILE = syrkd_tile<T, TKB>();
     __shared__ T acc[TILE];
+    // PERSISTENT workgroups: the grid is a few workgroups per CU and each walks the (row, tile) list with stride
+    // gridDim.x (a multiple of 8, so the XCD of a list position stays position % 8).  A tile workgroup owns the whole
+    // LDS of its CU; launched one per tile, every tile paid a dispatch + wave launch with the CU idle in between,
+    // and the empty tiles below the diagonal paid it too.
+    for (int64_t vb = blockIdx.x; vb < n_virtual; vb += gridDim.x) {
     // XCD-affine order: workgroup b runs on XCD b % 8 (observed; speed only).  All column tiles of one output row go
     // to the SAME XCD, back to back, so the rows of X that the row's nonzeros select (the same for every tile) are
     // fetched from HBM once and then served by that XCD's L2 -- with one tile per XCD in round-robin order every
     // tile missed (rocprof: FETCH = 100 x the matrix at the literal configs[3]).
-    const int64_t q = (int64_t)(blockIdx.x >> 3);
-    const int64_t i = row0 + (q / tiles_per_row) * 8 + (int64_t)(blockIdx.x & 7u);  // output row (C points at row `row0`)
+    const int64_t q = vb >> 3;
+    const int64_t i = row0 + (q / tiles_per_row) * 8 + (vb & 7);  // output row (C points at row `row0`)
     const int64_t t = q % tiles_per_row;
     const int64_t j_lo = i + t * TILE;
-    if (i >= row_end || j_lo >= n) return;  // uniform for the whole workgroup
+    if (i >= row_end || j_lo >= n) continue;  // uniform for the whole workgroup
     const int64_t j_hi = (j_lo + TILE < n) ? j_lo + TILE : n;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     for (int k = tid; k < (int)(j_hi - j_lo); k += nthreads) acc[k] = vt<T>::zero();
@@ -67,7 +86,13 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         const int cnt = (t1 - base < WAVE) ? (int)(t1 - base) : WAVE;
         // R rows per step, two steps in flight: the loads of step s + 1 are issued before the LDS atomics of step s,
         // so the walk is a pipeline of independent loads instead of one dependent round trip per step
-        constexpr int R = 4;
+#ifndef MI_GRAM_R
+#define MI_GRAM_R 4
+#endif
+#ifndef MI_GRAM_EXP
+#define MI_GRAM_EXP 0
+#endif
+        constexpr int R = MI_GRAM_R;
         struct Step {
             int64_t qs[R], qe[R];
             T ae[R], xv[R];
@@ -85,15 +110,24 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
             for (int u = 0; u < R; ++u) {  // first 64 entries of each row: loads issued together
                 const int64_t q = st.qs[u] + lane;
                 const bool ok = q < st.qe[u];
+#if MI_GRAM_EXP == 3
+                st.jj[u] = ok ? (int32_t)(q * 40503u & 0x3ffff) : -1;  // experiment: no row loads
+                st.xv[u] = st.ae[u];
+#else
                 st.jj[u] = ok ? xcol[q] : -1;
                 st.xv[u] = ok ? xval[q] : vt<T>::zero();
+#endif
             }
         };
         auto consume = [&](const Step& st) {
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const int64_t j = st.jj[u];
+#if MI_GRAM_EXP == 1
+                if (j == 0x7ffffff1 && st.xv[u] == st.ae[u]) acc[0] = st.xv[u];  // experiment: no LDS atomics
+#else
                 if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(st.ae[u], st.xv[u]));
+#endif
             }
 #pragma unroll
             for (int u = 0; u < R; ++u) {  // rows longer than one wave
@@ -114,10 +148,15 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     }
     __syncthreads();
     T* crow = C + (i - row0) * c_rs;
+#if MI_GRAM_EXP == 2
+    if (acc[tid] == T(12345.678)) // experiment: no write-out
+#endif
     for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
         T* c = crow + j * c_cs;
         const T v = acc[j - j_lo];
         *c = beta_zero ? v : vt<T>::fma(beta, *c, v);
+    }
+    __syncthreads();  // the tile is reused by the next list position
     }
 }
 
@@ -161,14 +200,26 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         const int64_t tiles_per_row = ceil_div(n, tile);
         const int64_t nblocks = ceil_div(nr, 8) * 8 * tiles_per_row;  // 8 rows (one per XCD) x all their tiles per group
         if (nblocks > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "gram output too large for one launch");
+        // persistent grid: gram_persistent workgroups per LDS slot (one 128 KiB or two 64 KiB tiles per CU), a multiple of 8
+        int64_t grid = nblocks;
+        if (options().gram_persistent > 0) {
+            c.ensure();
+            const int64_t slots = (int64_t)c.cus * (wide ? 1 : 2) * options().gram_persistent;
+            // the list position of a workgroup advances by grid / 8 (row, tile) pairs per step: coprime with the tiles
+            // per row, or a workgroup would see the same tile index for ever (tile 0 always full, the last always empty)
+            int64_t g = slots / 8 > 0 ? slots / 8 : 1;
+            auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t r = a % b; a = b; b = r; } return a; };
+            while (g > 1 && gcd(g, tiles_per_row) != 1) --g;
+            if (g * 8 < grid) grid = g * 8;
+        }
         if (wide)
-            MI_LAUNCH((k_syrkd_lds<T, 128>), dim3((unsigned)nblocks), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
+            MI_LAUNCH((k_syrkd_lds<T, 128>), dim3((unsigned)grid), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
                       (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
-                      (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero);
+                      (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
         else
-            MI_LAUNCH((k_syrkd_lds<T, 64>), dim3((unsigned)nblocks), dim3(512), c.stream, n, row0, row1, tiles_per_row,
+            MI_LAUNCH((k_syrkd_lds<T, 64>), dim3((unsigned)grid), dim3(512), c.stream, n, row0, row1, tiles_per_row,
                       (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
-                      (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero);
+                      (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
         MI_HIP_CHECK(hipGetLastError());
         sc.copy_back();
     });

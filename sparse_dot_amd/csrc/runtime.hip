@@ -266,6 +266,9 @@ void Context::ensure()
     }
     if (device >= n) fail(MI_SPARSE_STATUS_INVALID_VALUE, "device %d out of range (%d devices)", device, n);
     MI_HIP_CHECK(hipSetDevice(device));
+    int n_cu = 0;
+    MI_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
+    cus = n_cu > 0 ? n_cu : 256;
     initialised = true;
 }
 
@@ -769,6 +772,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
                 mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_slices must be 0 (automatic), 1, 2, 4 or 8");
             o.spmm_slices = value;
+        } else if (!strcmp(name, "gram_persistent")) {
+            o.gram_persistent = value;
         } else if (!strcmp(name, "gram_tile_kb")) {
             if (value != 64 && value != 128) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "gram_tile_kb must be 64 or 128");
             o.gram_tile_kb = value;
