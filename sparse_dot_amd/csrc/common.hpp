@@ -299,6 +299,10 @@ struct Csr {
     DevBuf ptr_own, col_own, val_own;  // storage when the library owns it (else aliases caller HBM)
     bool valid = false;
     bool sorted = false;  // column indices known to be ascending inside every row
+    // dense gram (gram.hip): entries of every row left of each tile boundary, int32[rows * (cols / w + 2)], built on first
+    // use for tile width gram_off_w (structure only: unaffected by set_values)
+    DevBuf gram_off;
+    int64_t gram_off_w = 0;
 };
 
 // block form kept next to the CSR expansion on handles created from BSR arrays: the SpMM block kernel (bsr.hip) reads it
@@ -435,6 +439,7 @@ struct Options {
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory
     int64_t trace_phases = 0;      // print host wall-clock per SpGEMM phase to stderr (diagnostics; synchronises)
+    int64_t gram_sliced = 1;       // dense gram: per-(row, tile) slice table + 8 lanes per selected row (rows of X sorted); 0: whole rows per wave
     int64_t gram_persistent = 4;   // dense gram: workgroups per LDS slot of the chip walking the tile list (0: one workgroup per tile)
     int64_t gram_tile_kb = 128;    // dense gram, outputs wider than one 64 KiB tile: LDS tile of 128 (default) or 64 KiB
     int64_t bsr_native = 1;        // BSR handles x row-major dense: the block kernel (0: always the CSR expansion)

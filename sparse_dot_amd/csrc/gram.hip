@@ -77,20 +77,21 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     // three, and four rows' loads in flight together.
     const int64_t t0 = tptr[i], t1 = tptr[i + 1];
     for (int64_t base = t0 + (int64_t)wave * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {
+        // every load below is UNCONDITIONAL (lanes / rows past the end read a harmless valid element and are masked
+        // afterwards): a predicated load is a branch around the load, and behind branches the compiler's wait-count
+        // bookkeeping falls back to vmcnt(0) -- which silently serialised the two-step pipeline further down
         const int64_t p = base + lane;
         const bool valid = p < t1;
-        const int32_t r = valid ? tcol[p] : 0;
-        const T a = valid ? vt<T>::mul(alpha, tval[p]) : vt<T>::zero();
-        const int64_t q0 = valid ? xptr[r] : 0;
-        const int64_t q1 = valid ? xptr[r + 1] : 0;
+        const int64_t p_safe = valid ? p : base;  // base < t1
+        const int32_t r = tcol[p_safe];
+        const T a = valid ? vt<T>::mul(alpha, tval[p_safe]) : vt<T>::zero();
+        const int64_t q0 = xptr[r];
+        const int64_t q1 = valid ? xptr[r + 1] : q0;
         const int cnt = (t1 - base < WAVE) ? (int)(t1 - base) : WAVE;
         // R rows per step, two steps in flight: the loads of step s + 1 are issued before the LDS atomics of step s,
         // so the walk is a pipeline of independent loads instead of one dependent round trip per step
 #ifndef MI_GRAM_R
 #define MI_GRAM_R 4
-#endif
-#ifndef MI_GRAM_EXP
-#define MI_GRAM_EXP 0
 #endif
         constexpr int R = MI_GRAM_R;
         struct Step {
@@ -110,24 +111,17 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
             for (int u = 0; u < R; ++u) {  // first 64 entries of each row: loads issued together
                 const int64_t q = st.qs[u] + lane;
                 const bool ok = q < st.qe[u];
-#if MI_GRAM_EXP == 3
-                st.jj[u] = ok ? (int32_t)(q * 40503u & 0x3ffff) : -1;  // experiment: no row loads
-                st.xv[u] = st.ae[u];
-#else
-                st.jj[u] = ok ? xcol[q] : -1;
-                st.xv[u] = ok ? xval[q] : vt<T>::zero();
-#endif
+                const int64_t q_safe = ok ? q : t0;  // X^T and X hold the same number of entries: t0 indexes both
+                const int32_t jl = xcol[q_safe];
+                st.xv[u] = xval[q_safe];
+                st.jj[u] = ok ? jl : -1;
             }
         };
         auto consume = [&](const Step& st) {
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const int64_t j = st.jj[u];
-#if MI_GRAM_EXP == 1
-                if (j == 0x7ffffff1 && st.xv[u] == st.ae[u]) acc[0] = st.xv[u];  // experiment: no LDS atomics
-#else
                 if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(st.ae[u], st.xv[u]));
-#endif
             }
 #pragma unroll
             for (int u = 0; u < R; ++u) {  // rows longer than one wave
@@ -148,9 +142,6 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     }
     __syncthreads();
     T* crow = C + (i - row0) * c_rs;
-#if MI_GRAM_EXP == 2
-    if (acc[tid] == T(12345.678)) // experiment: no write-out
-#endif
     for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
         T* c = crow + j * c_cs;
         const T v = acc[j - j_lo];
@@ -159,6 +150,114 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     __syncthreads();  // the tile is reused by the next list position
     }
 }
+
+// ---- sliced variant (rows of X sorted): the default ------------------------------------------------------------
+// The tiles lie on a GLOBAL grid (tile g = columns [g * TILE, (g + 1) * TILE); the tile holding the diagonal is cut at
+// column i) and a table gives, for every row r of X and every tile boundary, how many of the row's entries lie left of
+// it: the part of row r that falls into tile g is the contiguous slice [off[r][g], off[r][g + 1]).  A wave takes 64
+// selected rows at a time (lane = row: the entry of X^T, the row start, the two offsets -- three gathers in flight
+// together), then EIGHT LANES walk each row's slice, eight rows per step, all eight steps' loads issued before the
+// first LDS atomic.  Against the whole-row walk above (every tile pass read all 64+ entries of every selected row
+// and kept ~TILE / n of them, ~75 instructions per row): an eighth of the loads at 8 tiles per row and ~2
+// instructions per row, which is what that kernel's time was made of (a wave issues one instruction per ~4 cycles).
+__global__ void k_gram_offsets(int64_t rows, int64_t G, int64_t w, const int64_t* __restrict__ xptr,
+                               const int32_t* __restrict__ xcol, int32_t* __restrict__ off)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * (G + 1)) return;
+    const int64_t r = t / (G + 1), g = t - r * (G + 1);
+    int64_t lo = xptr[r], hi = xptr[r + 1];
+    const int64_t b0 = lo;
+    const int64_t key = g * w;  // first position with column >= key (g == G: past every column)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)xcol[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    off[t] = (int32_t)(lo - b0);
+}
+
+template <typename T, int TKB>
+__global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
+    k_syrkd_sliced(int64_t n, int64_t row0, int64_t row_end, int64_t G, const int64_t* __restrict__ tptr,
+                   const int32_t* __restrict__ tcol, const T* __restrict__ tval, const int64_t* __restrict__ xptr,
+                   const int32_t* __restrict__ xcol, const T* __restrict__ xval, const int32_t* __restrict__ off,
+                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual)
+{
+    constexpr int TILE = syrkd_tile<T, TKB>();
+    constexpr int SUB = 8;            // lanes per selected row
+    constexpr int RPS = WAVE / SUB;   // rows per step
+    __shared__ T acc[TILE];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int wave = tid / WAVE, lane = tid % WAVE, nwaves = nthreads / WAVE;
+    const int sub = lane % SUB, grp = lane / SUB;
+    for (int64_t vb = blockIdx.x; vb < n_virtual; vb += gridDim.x) {  // persistent: see k_syrkd_lds
+        const int64_t q = vb >> 3;
+        const int64_t i = row0 + (q / G) * 8 + (vb & 7);  // output row (C points at row `row0`)
+        const int64_t g = q % G;
+        const int64_t tile_lo = g * TILE;
+        if (i >= row_end || tile_lo + TILE <= i) continue;  // past the block / left of the diagonal (uniform)
+        const int64_t j_lo = i > tile_lo ? i : tile_lo;
+        const int64_t j_hi = tile_lo + TILE < n ? tile_lo + TILE : n;
+        for (int k = tid; k < (int)(j_hi - tile_lo); k += nthreads) acc[k] = vt<T>::zero();
+        __syncthreads();
+        const int64_t t0 = tptr[i], t1 = tptr[i + 1];
+        for (int64_t base = t0 + (int64_t)wave * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {
+            // lane = selected row; loads unconditional (lanes past the end re-read entry `base` and get an empty slice)
+            const int64_t p = base + lane;
+            const bool valid = p < t1;
+            const int64_t p_safe = valid ? p : base;
+            const int32_t r = tcol[p_safe];
+            const T a = vt<T>::mul(alpha, tval[p_safe]);
+            const int64_t xb = xptr[r];
+            int32_t o0, o1;
+            if (off) {
+                const int32_t* orow = off + (int64_t)r * (G + 1) + g;
+                o0 = orow[0];
+                o1 = orow[1];
+            } else {  // one tile per row: the slice is the row
+                o0 = 0;
+                o1 = (int32_t)(xptr[r + 1] - xb);
+            }
+            const int64_t s = xb + o0;
+            const int32_t len = valid ? o1 - o0 : 0;
+            // eight rows per step, eight lanes per row; the first SUB entries of all eight steps in flight together
+            int32_t jv[RPS], ln[RPS];
+            int64_t sk[RPS];
+            T av[RPS], xv[RPS];
+#pragma unroll
+            for (int k = 0; k < RPS; ++k) {
+                const int src = k * RPS + grp;
+                sk[k] = __shfl(s, src);
+                ln[k] = __shfl(len, src);
+                av[k] = __shfl(a, src);
+                const bool ok = sub < ln[k];
+                const int64_t qq = ok ? sk[k] + sub : t0;  // X^T and X hold the same number of entries: t0 indexes both
+                jv[k] = xcol[qq];
+                xv[k] = xval[qq];
+                if (!ok) jv[k] = -1;
+            }
+#pragma unroll
+            for (int k = 0; k < RPS; ++k)
+                if (jv[k] >= j_lo) atomic_accum(&acc[jv[k] - tile_lo], vt<T>::mul(av[k], xv[k]));
+#pragma unroll
+            for (int k = 0; k < RPS; ++k) {  // slices longer than SUB entries
+                for (int e = sub + SUB; e < ln[k]; e += SUB) {
+                    const int64_t j = xcol[sk[k] + e];
+                    if (j >= j_lo) atomic_accum(&acc[j - tile_lo], vt<T>::mul(av[k], xval[sk[k] + e]));
+                }
+            }
+        }
+        __syncthreads();
+        T* crow = C + (i - row0) * c_rs;
+        for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
+            T* c = crow + j * c_cs;
+            const T v = acc[j - tile_lo];
+            *c = beta_zero ? v : vt<T>::fma(beta, *c, v);
+        }
+        __syncthreads();  // the tile is reused by the next list position
+    }
+}
+
 
 template <typename T>
 static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, int layout, int64_t ldc, int64_t row0 = 0,
@@ -212,14 +311,41 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
             while (g > 1 && gcd(g, tiles_per_row) != 1) --g;
             if (g * 8 < grid) grid = g * 8;
         }
-        if (wide)
+        // sliced walk when the rows of X are sorted (always, for a transpose built here)
+        bool sliced = options().gram_sliced != 0;
+        if (sliced && !x.sorted) {
+            if (rows_sorted(x)) x.sorted = true; else sliced = false;
+        }
+        const int32_t* off = nullptr;
+        const size_t need = sizeof(int32_t) * (size_t)x.rows * (size_t)(tiles_per_row + 1);
+        if (need > ((size_t)16 << 30)) sliced = false;  // slice table out of proportion (very tall X, very wide output)
+        if (sliced && tiles_per_row > 1) {
+            if (x.gram_off_w != tile || !x.gram_off.p) {
+                x.gram_off.alloc(need);
+                MI_LAUNCH(k_gram_offsets, dim3((unsigned)ceil_div(x.rows * (tiles_per_row + 1), 256)), dim3(256), c.stream,
+                          x.rows, tiles_per_row, tile, (const int64_t*)x.ptr, (const int32_t*)x.col, x.gram_off.as<int32_t>());
+                x.gram_off_w = tile;
+            }
+            off = x.gram_off.as<int32_t>();
+        }
+#define MI_SYRKD_ARGS                                                                                               \
+    (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, (const int32_t*)x.col,   \
+        (const T*)x.val
+        if (sliced) {
+            if (wide)
+                MI_LAUNCH((k_syrkd_sliced<T, 128>), dim3((unsigned)grid), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
+                          MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
+            else
+                MI_LAUNCH((k_syrkd_sliced<T, 64>), dim3((unsigned)grid), dim3(512), c.stream, n, row0, row1, tiles_per_row,
+                          MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
+        } else if (wide) {
             MI_LAUNCH((k_syrkd_lds<T, 128>), dim3((unsigned)grid), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
-                      (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
-                      (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
-        else
+                      MI_SYRKD_ARGS, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
+        } else {
             MI_LAUNCH((k_syrkd_lds<T, 64>), dim3((unsigned)grid), dim3(512), c.stream, n, row0, row1, tiles_per_row,
-                      (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr,
-                      (const int32_t*)x.col, (const T*)x.val, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
+                      MI_SYRKD_ARGS, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
+        }
+#undef MI_SYRKD_ARGS
         MI_HIP_CHECK(hipGetLastError());
         sc.copy_back();
     });

@@ -232,19 +232,32 @@ __global__ void __launch_bounds__(THREADS)
                 qb = qlo[cur.l];
                 if (NUMERIC) av = a_s[cur.l];
             }
+            // loads of B unconditional and issued together, uses after the last one (see k_spgemm_part)
+            int64_t q[LDS_UNROLL];
+            T avs[LDS_UNROLL];
 #pragma unroll
             for (int u = 0; u < LDS_UNROLL; ++u) {
                 const int f = f0 + u * 64;
-                j[u] = -1;
+                q[u] = 0;
+                avs[u] = av;
                 if (f < total) {
                     if (u && cur.advance(inc, f)) {
                         qb = qlo[cur.l];
                         if (NUMERIC) av = a_s[cur.l];
                     }
-                    const int64_t q = qb + (f - cur.lo);
-                    j[u] = bcol[q];
-                    if (NUMERIC) v[u] = vt<T>::mul(av, bval[q]);
+                    q[u] = qb + (f - cur.lo);
+                    avs[u] = av;
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < LDS_UNROLL; ++u) {
+                j[u] = bcol[q[u]];
+                if (NUMERIC) v[u] = bval[q[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < LDS_UNROLL; ++u) {
+                if (f0 + u * 64 >= total) j[u] = -1;
+                if (NUMERIC) v[u] = vt<T>::mul(avs[u], v[u]);
             }
 #pragma unroll
             for (int u = 0; u < LDS_UNROLL; ++u) {
@@ -626,15 +639,21 @@ __global__ void __launch_bounds__(1024)
                     cur.seek(inc, f0);
                     qb = qlo[cur.l];
                 }
+                int64_t q[BITMAP_UNROLL];
 #pragma unroll
                 for (int u = 0; u < BITMAP_UNROLL; ++u) {
                     const int f = f0 + u * 64;
-                    j[u] = -1;
+                    q[u] = 0;
                     if (f < total) {
                         if (u && cur.advance(inc, f)) qb = qlo[cur.l];
-                        j[u] = bcol[qb + (f - cur.lo)];
+                        q[u] = qb + (f - cur.lo);
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < BITMAP_UNROLL; ++u) j[u] = bcol[q[u]];  // unconditional, issued together
+#pragma unroll
+                for (int u = 0; u < BITMAP_UNROLL; ++u)
+                    if (f0 + u * 64 >= total) j[u] = -1;
 #pragma unroll
                 for (int u = 0; u < BITMAP_UNROLL; ++u)
                     if (j[u] >= 0 && !(upper && j[u] < row)) atomicOr(&bits[BITMAP_IDX(j[u] >> 5)], 1u << (j[u] & 31));
@@ -954,18 +973,29 @@ __global__ void __launch_bounds__(PART_THREADS)
             // (binary search per product, not the stepping cursor of the other kernels: the slices of ONE range are
             // short -- ~12 products -- and stepping over five of them per product costs more than the search)
             for (int f0 = tid; f0 < total; f0 += NT * PART_UNROLL) {
+                // The loads of B are UNCONDITIONAL (positions past the end re-read the lane's first product and are
+                // masked afterwards) and every use comes after the last load: with `if (f < total) { load; multiply }`
+                // per product the compiler waited for product u before issuing the loads of product u + 1.
                 int32_t j[PART_UNROLL];
                 T v[PART_UNROLL];
+                int64_t q[PART_UNROLL];
+                T av[PART_UNROLL];
 #pragma unroll
                 for (int u = 0; u < PART_UNROLL; ++u) {
-                    const int f = f0 + u * NT;
-                    j[u] = -1;
-                    if (f < total) {
-                        const int l = flat_find<NT>(inc, f);
-                        const int64_t q = qlo[l] + (f - (l ? inc[l - 1] : 0));
-                        j[u] = bcol[q];
-                        v[u] = vt<T>::mul(a_s[l], bval[q]);
-                    }
+                    const int f = f0 + u * NT < total ? f0 + u * NT : f0;
+                    const int l = flat_find<NT>(inc, f);
+                    q[u] = qlo[l] + (f - (l ? inc[l - 1] : 0));
+                    av[u] = a_s[l];
+                }
+#pragma unroll
+                for (int u = 0; u < PART_UNROLL; ++u) {
+                    j[u] = bcol[q[u]];
+                    v[u] = bval[q[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < PART_UNROLL; ++u) {
+                    if (f0 + u * NT >= total) j[u] = -1;
+                    v[u] = vt<T>::mul(av[u], v[u]);
                 }
                 // first probe of every product issued back to back (the compare-and-swap returns a value: its latency
                 // is paid once per batch, not once per product); the few collisions continue one at a time

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../sparse_dot_amd/csrc"
 mkdir -p build/var
-SPECS="si1:-DMI_SLICE_ILP=1 si2:-DMI_SLICE_ILP=2 si8:-DMI_SLICE_ILP=8 bu16:-DMI_BITMAP_UNROLL=16 bu4:-DMI_BITMAP_UNROLL=4"
+SPECS="pu4:-DMI_PART_UNROLL=4 pu3:-DMI_PART_UNROLL=3 lu4:-DMI_LDS_UNROLL=4 bu16:-DMI_BITMAP_UNROLL=16"
 for spec in $SPECS; do
   tag=${spec%%:*}; def=$(echo ${spec#*:} | tr '@' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $def -c spgemm.hip -o build/var/spgemm_$tag.o &
