@@ -37,6 +37,52 @@ __device__ __forceinline__ T shfl_bcast(T v, int src)
 #endif
 }
 
+#ifndef MI_GRAM_SUB
+#define MI_GRAM_SUB 8
+#endif
+#ifndef MI_GRAM_NT_STORE
+#define MI_GRAM_NT_STORE 1
+#endif
+// Finished tile -> C.  Row-major with beta = 0 (the reference's call): 16-byte NON-TEMPORAL stores -- the tile is
+// never read again by this kernel, and a wave's stores sit in the same in-order counter (vmcnt) as its next loads, so
+// the faster they retire the sooner the next tile's first loads are seen to complete.
+template <typename T>
+__device__ __forceinline__ void syrkd_write_tile(const T* acc, T* crow, int64_t c_cs, int64_t j_lo, int64_t j_hi, int64_t tile_lo,
+                                                 T beta, int beta_zero, int tid, int nthreads)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+#ifndef MI_HIP_EMU
+    if (beta_zero && c_cs == 1 && MI_GRAM_NT_STORE) {
+        T* p0 = crow + j_lo;
+        int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(p0) & 15)) & 15) / sizeof(T));
+        if (head > j_hi - j_lo) head = j_hi - j_lo;
+        const int64_t body = (j_hi - j_lo - head) / V;  // vectors
+        if (tid < head) __builtin_nontemporal_store(acc[j_lo - tile_lo + tid], p0 + tid);
+        typedef T vec_t __attribute__((ext_vector_type(V)));
+        vec_t* pv = reinterpret_cast<vec_t*>(p0 + head);
+        const T* a0 = acc + (j_lo - tile_lo + head);
+        for (int64_t k = tid; k < body; k += nthreads) {
+            vec_t v;
+#pragma unroll
+            for (int u = 0; u < V; ++u) v[u] = a0[k * V + u];
+#if MI_GRAM_NT_STORE == 2
+            pv[k] = v;  // A/B: 16-byte stores without the non-temporal hint
+#else
+            __builtin_nontemporal_store(v, pv + k);
+#endif
+        }
+        const int64_t done = head + body * V;
+        if (tid < j_hi - j_lo - done) __builtin_nontemporal_store(acc[j_lo - tile_lo + done + tid], p0 + done + tid);
+        return;
+    }
+#endif
+    for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
+        T* c = crow + j * c_cs;
+        const T v = acc[j - tile_lo];
+        *c = beta_zero ? v : vt<T>::fma(beta, *c, v);
+    }
+}
+
 // LDS tile of one workgroup: TKB KiB of accumulators.  64 KiB (two 512-thread workgroups per CU) or 128 KiB (one
 // 1024-thread workgroup per CU): a wider tile halves the number of passes over the row's nonzeros when the output row
 // is wider than one tile (every pass re-reads all of them and keeps ~tile / n of the entries).
@@ -141,12 +187,7 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         }
     }
     __syncthreads();
-    T* crow = C + (i - row0) * c_rs;
-    for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
-        T* c = crow + j * c_cs;
-        const T v = acc[j - j_lo];
-        *c = beta_zero ? v : vt<T>::fma(beta, *c, v);
-    }
+    syrkd_write_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, j_lo, beta, beta_zero, tid, nthreads);
     __syncthreads();  // the tile is reused by the next list position
     }
 }
@@ -184,80 +225,128 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
                    T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual)
 {
     constexpr int TILE = syrkd_tile<T, TKB>();
-    constexpr int SUB = 8;            // lanes per selected row
+    constexpr int SUB = MI_GRAM_SUB;  // lanes per selected row
     constexpr int RPS = WAVE / SUB;   // rows per step
+    constexpr int NSTEP = WAVE / RPS; // steps per 64 rows, all in flight together
     __shared__ T acc[TILE];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid / WAVE, lane = tid % WAVE, nwaves = nthreads / WAVE;
     const int sub = lane % SUB, grp = lane / SUB;
-    for (int64_t vb = blockIdx.x; vb < n_virtual; vb += gridDim.x) {  // persistent: see k_syrkd_lds
+    // list position -> (output row, tile); false: nothing to do there (past the row block / left of the diagonal)
+    auto decode = [&](int64_t vb, int64_t& i, int64_t& g) {
         const int64_t q = vb >> 3;
-        const int64_t i = row0 + (q / G) * 8 + (vb & 7);  // output row (C points at row `row0`)
-        const int64_t g = q % G;
+        i = row0 + (q / G) * 8 + (vb & 7);
+        g = q % G;
+        return i < row_end && g * TILE + TILE > i;
+    };
+    auto next_valid = [&](int64_t vb, int64_t& i, int64_t& g) {
+        while (vb < n_virtual && !decode(vb, i, g)) vb += gridDim.x;
+        return vb;
+    };
+    // The dependent chain  row pointer of X^T -> (r, X[r,i]) -> start of row r and its slice offsets  costs three memory
+    // round trips of ~3.5 us each under load (measured per phase with wall_clock64: 10.4 of a tile's 27 us), and a tile
+    // workgroup is alone on its CU: nothing else hides them.  So they are fetched ONE TILE AHEAD, one level per phase of
+    // the current tile (A: before zeroing, B: before the walk, C: before the write-out), for the wave's first 64 rows.
+    struct Head {
+        int64_t t0, t1;   // A
+        int32_t r;        // B (lane = selected row)
+        T a;
+        int64_t s;        // C: start of the slice
+        int32_t len;      //    its length (0 for lanes past the end)
+    };
+    auto stage_a = [&](int64_t i, Head& h) {
+        h.t0 = tptr[i];
+        h.t1 = tptr[i + 1];
+    };
+    auto stage_b = [&](Head& h) {
+        const int64_t base = h.t0 + (int64_t)wave * WAVE;
+        const int64_t p = base + lane < h.t1 ? base + lane : (h.t0 < h.t1 ? h.t1 - 1 : 0);  // always a valid entry
+        h.r = tcol[p];
+        h.a = vt<T>::mul(alpha, tval[p]);
+    };
+    auto stage_c = [&](int64_t g, Head& h) {
+        const int64_t base = h.t0 + (int64_t)wave * WAVE;
+        const bool valid = base + lane < h.t1;
+        const int64_t xb = xptr[h.r];
+        int32_t o0, o1;
+        if (off) {
+            const int32_t* orow = off + (int64_t)h.r * (G + 1) + g;
+            o0 = orow[0];
+            o1 = orow[1];
+        } else {  // one tile per row: the slice is the row
+            o0 = 0;
+            o1 = (int32_t)(xptr[h.r + 1] - xb);
+        }
+        h.s = xb + o0;
+        h.len = valid ? o1 - o0 : 0;
+    };
+    // RPS rows per step, SUB lanes per row; the first SUB entries of every row of all NSTEP steps are in flight together
+    auto walk64 = [&](int64_t s, int32_t len, T a, int64_t j_lo, int64_t tile_lo, int64_t safe) {
+        int32_t jv[NSTEP], ln[NSTEP];
+        int64_t sk[NSTEP];
+        T av[NSTEP], xv[NSTEP];
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {
+            const int src = k * RPS + grp;
+            sk[k] = __shfl(s, src);
+            ln[k] = __shfl(len, src);
+            av[k] = __shfl(a, src);
+            const bool ok = sub < ln[k];
+            const int64_t qq = ok ? sk[k] + sub : safe;
+            jv[k] = xcol[qq];
+            xv[k] = xval[qq];
+            if (!ok) jv[k] = -1;
+        }
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k)
+            if (jv[k] >= j_lo) atomic_accum(&acc[jv[k] - tile_lo], vt<T>::mul(av[k], xv[k]));
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {  // slices longer than SUB entries
+            for (int e = sub + SUB; e < ln[k]; e += SUB) {
+                const int64_t j = xcol[sk[k] + e];
+                if (j >= j_lo) atomic_accum(&acc[j - tile_lo], vt<T>::mul(av[k], xval[sk[k] + e]));
+            }
+        }
+    };
+    int64_t i = 0, g = 0, ni = 0, ng = 0;
+    int64_t vb = next_valid(blockIdx.x, i, g);
+    Head cur, nxt;
+    if (vb < n_virtual) {
+        stage_a(i, cur);
+        stage_b(cur);
+        stage_c(g, cur);
+    }
+    while (vb < n_virtual) {
+        const int64_t nvb = next_valid(vb + gridDim.x, ni, ng);
+        const bool more = nvb < n_virtual;
+        if (more) stage_a(ni, nxt);
         const int64_t tile_lo = g * TILE;
-        if (i >= row_end || tile_lo + TILE <= i) continue;  // past the block / left of the diagonal (uniform)
         const int64_t j_lo = i > tile_lo ? i : tile_lo;
         const int64_t j_hi = tile_lo + TILE < n ? tile_lo + TILE : n;
         for (int k = tid; k < (int)(j_hi - tile_lo); k += nthreads) acc[k] = vt<T>::zero();
         __syncthreads();
-        const int64_t t0 = tptr[i], t1 = tptr[i + 1];
-        for (int64_t base = t0 + (int64_t)wave * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {
-            // lane = selected row; loads unconditional (lanes past the end re-read entry `base` and get an empty slice)
-            const int64_t p = base + lane;
-            const bool valid = p < t1;
-            const int64_t p_safe = valid ? p : base;
-            const int32_t r = tcol[p_safe];
-            const T a = vt<T>::mul(alpha, tval[p_safe]);
-            const int64_t xb = xptr[r];
-            int32_t o0, o1;
-            if (off) {
-                const int32_t* orow = off + (int64_t)r * (G + 1) + g;
-                o0 = orow[0];
-                o1 = orow[1];
-            } else {  // one tile per row: the slice is the row
-                o0 = 0;
-                o1 = (int32_t)(xptr[r + 1] - xb);
-            }
-            const int64_t s = xb + o0;
-            const int32_t len = valid ? o1 - o0 : 0;
-            // eight rows per step, eight lanes per row; the first SUB entries of all eight steps in flight together
-            int32_t jv[RPS], ln[RPS];
-            int64_t sk[RPS];
-            T av[RPS], xv[RPS];
-#pragma unroll
-            for (int k = 0; k < RPS; ++k) {
-                const int src = k * RPS + grp;
-                sk[k] = __shfl(s, src);
-                ln[k] = __shfl(len, src);
-                av[k] = __shfl(a, src);
-                const bool ok = sub < ln[k];
-                const int64_t qq = ok ? sk[k] + sub : t0;  // X^T and X hold the same number of entries: t0 indexes both
-                jv[k] = xcol[qq];
-                xv[k] = xval[qq];
-                if (!ok) jv[k] = -1;
-            }
-#pragma unroll
-            for (int k = 0; k < RPS; ++k)
-                if (jv[k] >= j_lo) atomic_accum(&acc[jv[k] - tile_lo], vt<T>::mul(av[k], xv[k]));
-#pragma unroll
-            for (int k = 0; k < RPS; ++k) {  // slices longer than SUB entries
-                for (int e = sub + SUB; e < ln[k]; e += SUB) {
-                    const int64_t j = xcol[sk[k] + e];
-                    if (j >= j_lo) atomic_accum(&acc[j - tile_lo], vt<T>::mul(av[k], xval[sk[k] + e]));
-                }
-            }
+        if (more) stage_b(nxt);
+        const int64_t t0 = cur.t0, t1 = cur.t1;
+        if (t0 + (int64_t)wave * WAVE < t1) walk64(cur.s, cur.len, cur.a, j_lo, tile_lo, t0);
+        for (int64_t base = t0 + (int64_t)(wave + nwaves) * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {
+            // further rows of a long list: fetched here, the chain exposed
+            Head h;
+            h.t0 = base - (int64_t)wave * WAVE;  // so that stage_b / stage_c address `base`
+            h.t1 = t1;
+            stage_b(h);
+            stage_c(g, h);
+            walk64(h.s, h.len, h.a, j_lo, tile_lo, t0);
         }
+        if (more) stage_c(ng, nxt);
         __syncthreads();
-        T* crow = C + (i - row0) * c_rs;
-        for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
-            T* c = crow + j * c_cs;
-            const T v = acc[j - tile_lo];
-            *c = beta_zero ? v : vt<T>::fma(beta, *c, v);
-        }
+        syrkd_write_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, tile_lo, beta, beta_zero, tid, nthreads);
         __syncthreads();  // the tile is reused by the next list position
+        vb = nvb;
+        i = ni;
+        g = ng;
+        cur = nxt;
     }
 }
-
 
 template <typename T>
 static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, int layout, int64_t ldc, int64_t row0 = 0,
@@ -299,11 +388,22 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         const int64_t tiles_per_row = ceil_div(n, tile);
         const int64_t nblocks = ceil_div(nr, 8) * 8 * tiles_per_row;  // 8 rows (one per XCD) x all their tiles per group
         if (nblocks > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "gram output too large for one launch");
+        // sliced walk when the rows of X are sorted (always, for a transpose built here) and a row's share of one tile is
+        // short: with long slices the whole-row walk (64 lanes per row) is the faster one (2^20 x 65 536, 64 per row:
+        // 15.8 vs 19.3 ms; literal configs[3], 8 per slice: 141 vs 116 ms)
+        bool sliced = options().gram_sliced != 0 && x.nnz > 0;
+        if (sliced && options().gram_sliced == 1 && x.nnz / (x.rows > 0 ? x.rows : 1) / tiles_per_row > 12) sliced = false;
+        if (sliced && !x.sorted) {
+            if (rows_sorted(x)) x.sorted = true; else sliced = false;
+        }
+        const size_t need = sizeof(int32_t) * (size_t)x.rows * (size_t)(tiles_per_row + 1);
+        if (need > ((size_t)16 << 30)) sliced = false;  // slice table out of proportion (very tall X, very wide output)
         // persistent grid: gram_persistent workgroups per LDS slot (one 128 KiB or two 64 KiB tiles per CU), a multiple of 8
         int64_t grid = nblocks;
-        if (options().gram_persistent > 0) {
+        const int64_t persistent = options().gram_persistent >= 0 ? options().gram_persistent : (sliced ? 1 : 4);
+        if (persistent > 0) {
             c.ensure();
-            const int64_t slots = (int64_t)c.cus * (wide ? 1 : 2) * options().gram_persistent;
+            const int64_t slots = (int64_t)c.cus * (wide ? 1 : 2) * persistent;
             // the list position of a workgroup advances by grid / 8 (row, tile) pairs per step: coprime with the tiles
             // per row, or a workgroup would see the same tile index for ever (tile 0 always full, the last always empty)
             int64_t g = slots / 8 > 0 ? slots / 8 : 1;
@@ -311,14 +411,7 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
             while (g > 1 && gcd(g, tiles_per_row) != 1) --g;
             if (g * 8 < grid) grid = g * 8;
         }
-        // sliced walk when the rows of X are sorted (always, for a transpose built here)
-        bool sliced = options().gram_sliced != 0;
-        if (sliced && !x.sorted) {
-            if (rows_sorted(x)) x.sorted = true; else sliced = false;
-        }
         const int32_t* off = nullptr;
-        const size_t need = sizeof(int32_t) * (size_t)x.rows * (size_t)(tiles_per_row + 1);
-        if (need > ((size_t)16 << 30)) sliced = false;  // slice table out of proportion (very tall X, very wide output)
         if (sliced && tiles_per_row > 1) {
             if (x.gram_off_w != tile || !x.gram_off.p) {
                 x.gram_off.alloc(need);

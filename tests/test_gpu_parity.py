@@ -1151,3 +1151,81 @@ def test_config4_scaled_gram_properties(gpu):
         if h:
             MI.call("mi_sparse_destroy", h)
         gpu.mi_set_stream(0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gram_dense_multi_tile_every_walk(gpu, dtype):
+    """Dense gram whose output rows span several LDS tiles (n = 70 000: 3-9 tiles per row depending on dtype / tile
+    size), device resident, through every walk the library has: sliced (slice table + 8 lanes per selected row) and
+    whole-row, 128 and 64 KiB tiles, persistent and one-workgroup-per-tile grids, row bands (mi_sparse_?_syrkd_rows),
+    and an input whose rows are NOT sorted (falls back to the whole-row walk).  Sampled output rows equal scipy's
+    float64 A^T A on and above the diagonal to the north-star tolerance; left of the diagonal the array is untouched."""
+    torch = pytest.importorskip("torch")
+    from sparse_dot_amd._mi_interface import MI, sparse_matrix_t, _check_return_value
+    dev = torch.device("cuda", 0)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    pre = "s" if dtype == np.float32 else "d"
+    tolv = F32_TOL if dtype == np.float32 else F64_TOL
+    m, n = 30000, 70000
+    ip, idx, val = _uniform_csr_torch(torch, dev, m, n, 24, 11, tdt)
+    a_host = sps.csr_matrix((val.cpu().numpy().astype(np.float64), idx.cpu().numpy(), ip.cpu().numpy()), shape=(m, n))
+    want = (a_host.T @ a_host).tocsr()
+    rng = np.random.default_rng(3)
+    sample = np.unique(np.concatenate([[0, 1, 16383, 16384, 32767, 32768, 65535, 65536, n - 1], rng.integers(0, n, 150)]))
+
+    def check_rows(C, row0, rows):
+        got = C[torch.as_tensor(rows - row0, device=dev)].cpu().numpy().astype(np.float64)
+        for k, i in enumerate(rows.tolist()):
+            ref = np.asarray(want[i].todense()).ravel()
+            assert np.all(got[k, :i] == -7.0), i                                   # strict lower part never written
+            assert np.all(np.abs(got[k, i:] - ref[i:]) <= tolv * np.abs(ref[i:]) + 1e-300), i
+
+    gpu.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+    handles = []
+    try:
+        def mk(ip_, idx_, val_):
+            h = sparse_matrix_t()
+            _check_return_value(MI.call("mi_sparse_%s_create_csr" % pre, ct.byref(h), 0, m, n, ip_.data_ptr(), ip_.data_ptr() + 4,
+                                        idx_.data_ptr(), val_.data_ptr()), "create")
+            handles.append(h)
+            return h
+        h = mk(ip, idx, val)
+        one, zero = (ct.c_float(1.0), ct.c_float(0.0)) if dtype == np.float32 else (ct.c_double(1.0), ct.c_double(0.0))
+        for sliced, tile_kb, persistent in ((2, 128, -1), (2, 64, 4), (2, 128, 0), (0, 128, -1), (0, 64, 1), (1, 128, -1)):
+            gpu.mi_set_option("gram_sliced", sliced)
+            gpu.mi_set_option("gram_tile_kb", tile_kb)
+            gpu.mi_set_option("gram_persistent", persistent)
+            C = torch.full((n, n), -7.0, device=dev, dtype=tdt)
+            _check_return_value(MI.call("mi_sparse_%s_syrkd" % pre, 11, h, one, zero, C.data_ptr(), 101, n), "syrkd")
+            torch.cuda.synchronize()
+            check_rows(C, 0, sample)
+            C = None
+        gpu.mi_set_option("gram_sliced", 2)
+        gpu.mi_set_option("gram_tile_kb", 128)
+        gpu.mi_set_option("gram_persistent", -1)
+        # a band of output rows that starts inside a tile
+        r0, r1 = 20001, 20001 + 4099
+        band = torch.full((r1 - r0, n), -7.0, device=dev, dtype=tdt)
+        _check_return_value(MI.call("mi_sparse_%s_syrkd_rows" % pre, 11, h, one, zero, band.data_ptr(), 101, n, r0, r1), "rows")
+        torch.cuda.synchronize()
+        check_rows(band, r0, np.unique(np.concatenate([[r0, r1 - 1], rng.integers(r0, r1, 40)])))
+        band = None
+        # rows of A in shuffled order inside each row: not sorted -> whole-row walk
+        perm = torch.argsort(torch.rand(idx.numel(), device=dev) + torch.repeat_interleave(
+            torch.arange(m, device=dev, dtype=torch.float32), (ip[1:] - ip[:-1]).long()) * 2.0)
+        idx2, val2 = idx[perm].contiguous(), val[perm].contiguous()
+        assert bool((idx2 != idx).any())
+        h2 = mk(ip, idx2, val2)
+        C = torch.full((n, n), -7.0, device=dev, dtype=tdt)
+        _check_return_value(MI.call("mi_sparse_%s_syrkd" % pre, 11, h2, one, zero, C.data_ptr(), 101, n), "syrkd")
+        torch.cuda.synchronize()
+        check_rows(C, 0, sample[::4])
+        C = None
+    finally:
+        gpu.mi_set_option("gram_sliced", 1)
+        gpu.mi_set_option("gram_tile_kb", 128)
+        gpu.mi_set_option("gram_persistent", -1)
+        for h in handles:
+            MI.call("mi_sparse_destroy", h)
+        gpu.mi_set_stream(0)
+        torch.cuda.empty_cache()

@@ -1,11 +1,13 @@
 # Round-2 GPU session: parity tests, bench, rocprof stats, PMC passes (SpMM + SpGEMM + gram kernels), 2-rank dry run.
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r02b; O=$GRAFT_REPO_ROOT/gpurun_out/r02b
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r02f; O=$GRAFT_REPO_ROOT/gpurun_out/r02f
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"
 ( time timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=15 ) > $O/pytest.log 2>&1; echo "pytest rc=$?"
 tail -25 $O/pytest.log
 ( time timeout 1500 python bench.py --steps 20 --warmup 3 ) > $O/bench.log 2>&1; echo "bench rc=$?"; grep '^{' $O/bench.log | tail -1 | cut -c1-3000
 echo "== 2-rank dry run (gloo, both ranks on GPU 0)"
 BENCH_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 3 > $O/bench_2rank_dry.log 2>&1; echo "rc=$?"; grep '^{' $O/bench_2rank_dry.log | tail -1 | cut -c1-1500
+echo "== host-array call overhead (staged copies on / off)"
+timeout 600 python tools/gpu_api_overhead.py > $O/api_overhead.log 2>&1; echo "rc=$?"; grep "ms per call" $O/api_overhead.log | cut -c1-120
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o r02 -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu --no-secondary > $O/prof_bench.log 2>&1; echo "prof bench rc=$?"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sec -o r02 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 3 --no-cpu --secondary spgemm,spgemm_rmat,gram > $O/prof_sec.log 2>&1; echo "prof secondary rc=$?"
