@@ -51,6 +51,9 @@ __device__ __forceinline__ void syrkd_write_tile(const T* acc, T* crow, int64_t 
                                                  T beta, int beta_zero, int tid, int nthreads)
 {
     constexpr int V = 16 / (int)sizeof(T);
+#ifdef MI_GRAM_NOWRITE
+    if (acc[tid] != T(-12345.5)) return;  // experiment: no write-out
+#endif
 #ifndef MI_HIP_EMU
     if (beta_zero && c_cs == 1 && MI_GRAM_NT_STORE) {
         T* p0 = crow + j_lo;
@@ -222,7 +225,8 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     k_syrkd_sliced(int64_t n, int64_t row0, int64_t row_end, int64_t G, const int64_t* __restrict__ tptr,
                    const int32_t* __restrict__ tcol, const T* __restrict__ tval, const int64_t* __restrict__ xptr,
                    const int32_t* __restrict__ xcol, const T* __restrict__ xval, const int32_t* __restrict__ off,
-                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual)
+                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual,
+                   unsigned long long* __restrict__ queue, int cs)
 {
     constexpr int TILE = syrkd_tile<T, TKB>();
     constexpr int SUB = MI_GRAM_SUB;  // lanes per selected row
@@ -282,50 +286,100 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     };
     // RPS rows per step, SUB lanes per row; the first SUB entries of every row of all NSTEP steps are in flight together
     auto walk64 = [&](int64_t s, int32_t len, T a, int64_t j_lo, int64_t tile_lo, int64_t safe) {
-        int32_t jv[NSTEP], ln[NSTEP];
+        // entries sub and sub + SUB of every row of all NSTEP steps are loaded before the first LDS atomic: a slice
+        // longer than SUB entries used to cost its step one more DEPENDENT round trip, one step after the other
+        // (with ~8 entries per slice nearly every step of 8 rows has such a row: 8 serial round trips per 64 rows)
+        int32_t jv[2][NSTEP], ln[NSTEP];
         int64_t sk[NSTEP];
-        T av[NSTEP], xv[NSTEP];
+        T av[NSTEP], xv[2][NSTEP];
 #pragma unroll
         for (int k = 0; k < NSTEP; ++k) {
             const int src = k * RPS + grp;
             sk[k] = __shfl(s, src);
             ln[k] = __shfl(len, src);
             av[k] = __shfl(a, src);
-            const bool ok = sub < ln[k];
-            const int64_t qq = ok ? sk[k] + sub : safe;
-            jv[k] = xcol[qq];
-            xv[k] = xval[qq];
-            if (!ok) jv[k] = -1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = sub + h * SUB < ln[k];
+                const int64_t qq = ok ? sk[k] + sub + h * SUB : safe;
+                jv[h][k] = xcol[qq];
+                xv[h][k] = xval[qq];
+                if (!ok) jv[h][k] = -1;
+            }
         }
 #pragma unroll
-        for (int k = 0; k < NSTEP; ++k)
-            if (jv[k] >= j_lo) atomic_accum(&acc[jv[k] - tile_lo], vt<T>::mul(av[k], xv[k]));
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int k = 0; k < NSTEP; ++k) {  // slices longer than SUB entries
-            for (int e = sub + SUB; e < ln[k]; e += SUB) {
+            for (int k = 0; k < NSTEP; ++k)
+                if (jv[h][k] >= j_lo) atomic_accum(&acc[jv[h][k] - tile_lo], vt<T>::mul(av[k], xv[h][k]));
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {  // slices longer than 2 SUB entries
+            for (int e = sub + 2 * SUB; e < ln[k]; e += SUB) {
                 const int64_t j = xcol[sk[k] + e];
                 if (j >= j_lo) atomic_accum(&acc[j - tile_lo], vt<T>::mul(av[k], xval[sk[k] + e]));
             }
         }
     };
+    // Order of the tiles.  queue == nullptr: static, list position vb = blockIdx.x + k * gridDim.x.  Otherwise CLUSTERS of
+    // `cs` workgroups of one XCD (cluster id = XCD + 8 * c) own the output rows i = id (mod #clusters) and pull their
+    // tiles in row-major order from a per-cluster counter: at any moment the cs workgroups of a cluster work on
+    // neighbouring items, i.e. on the tiles of one or two output rows, which all gather from the SAME ~1000 rows of X.
+    // With the static order the workgroups drift apart (tiles left of the diagonal cost nothing, the first tile of a
+    // row is partial) until the 32 workgroups of an XCD sit on 32 different output rows: 32 x 512 KB of X rows against
+    // a 4 MB L2, every tile fetched its slices from HBM again (measured: walk 75 of 117 ms, 600 GB at 5.2 TB/s).
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int64_t cid = queue ? xcd + 8 * (int64_t)((blockIdx.x >> 3) / cs) : 0;
+    const int64_t nclus = queue ? 8 * (int64_t)((gridDim.x >> 3) / cs) : 1;
+    auto decode_k = [&](int64_t k, int64_t& i, int64_t& g) {
+        for (int64_t b = row0 / TILE; b < G && b * TILE < row_end; ++b) {
+            const int64_t lo = row0 > b * TILE ? row0 : b * TILE;
+            const int64_t hi = row_end < (b + 1) * TILE ? row_end : (b + 1) * TILE;
+            const int64_t first = lo + (((cid - lo) % nclus) + nclus) % nclus;  // first row of the band owned by this cluster
+            if (first >= hi) continue;
+            const int64_t cnt = (hi - first + nclus - 1) / nclus, nt = G - b;
+            if (k < cnt * nt) {
+                i = first + (k / nt) * nclus;
+                g = b + k % nt;
+                return true;
+            }
+            k -= cnt * nt;
+        }
+        return false;
+    };
+    __shared__ unsigned long long s_next;
     int64_t i = 0, g = 0, ni = 0, ng = 0;
-    int64_t vb = next_valid(blockIdx.x, i, g);
+    int64_t vb = 0;
+    bool have;
+    if (queue) {
+        if (tid == 0) s_next = atomicAdd(&queue[cid], 1ull);
+        __syncthreads();
+        have = decode_k((int64_t)s_next, i, g);
+        __syncthreads();
+    } else {
+        vb = next_valid(blockIdx.x, i, g);
+        have = vb < n_virtual;
+    }
     Head cur, nxt;
-    if (vb < n_virtual) {
+    if (have) {
         stage_a(i, cur);
         stage_b(cur);
         stage_c(g, cur);
     }
-    while (vb < n_virtual) {
-        const int64_t nvb = next_valid(vb + gridDim.x, ni, ng);
-        const bool more = nvb < n_virtual;
-        if (more) stage_a(ni, nxt);
+    while (have) {
+        if (queue && tid == 0) s_next = atomicAdd(&queue[cid], 1ull);  // next item: read by everybody after the barrier
         const int64_t tile_lo = g * TILE;
         const int64_t j_lo = i > tile_lo ? i : tile_lo;
         const int64_t j_hi = tile_lo + TILE < n ? tile_lo + TILE : n;
         for (int k = tid; k < (int)(j_hi - tile_lo); k += nthreads) acc[k] = vt<T>::zero();
         __syncthreads();
-        if (more) stage_b(nxt);
+        bool more;
+        if (queue) {
+            more = decode_k((int64_t)s_next, ni, ng);
+        } else {
+            vb = next_valid(vb + gridDim.x, ni, ng);
+            more = vb < n_virtual;
+        }
+        if (more) stage_a(ni, nxt);
         const int64_t t0 = cur.t0, t1 = cur.t1;
         if (t0 + (int64_t)wave * WAVE < t1) walk64(cur.s, cur.len, cur.a, j_lo, tile_lo, t0);
         for (int64_t base = t0 + (int64_t)(wave + nwaves) * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {
@@ -337,13 +391,156 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
             stage_c(g, h);
             walk64(h.s, h.len, h.a, j_lo, tile_lo, t0);
         }
-        if (more) stage_c(ng, nxt);
+        if (more) stage_b(nxt);
         __syncthreads();
+        if (more) stage_c(ng, nxt);
         syrkd_write_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, tile_lo, beta, beta_zero, tid, nthreads);
-        __syncthreads();  // the tile is reused by the next list position
-        vb = nvb;
+        __syncthreads();  // the tile (and s_next) are reused
         i = ni;
         g = ng;
+        cur = nxt;
+        have = more;
+    }
+}
+
+// ---- sliced, ROW-persistent: one workgroup walks ALL tiles of an output row (G <= GRAM_GMAX tiles per row) --------
+// The head of the chain (entry of X^T, start of row r) is the same for every tile of the row and the G + 1 slice
+// offsets of a row of X are one 4 (G + 1)-byte record: a lane fetches them ONCE per output row into registers (one row
+// ahead, spread over the phases of the current row's first tile), and a tile is then zero -> one round trip for the
+// slice entries -> barrier -> write-out, with no gather of its own.  The tiles of a row are adjacent slices of the same
+// rows of X, so three of four are cache hits on the line the previous tile brought in.
+constexpr int GRAM_GMAX = 16;  // instantiated for <= 8 and <= 16 tiles per row (offsets live in registers)
+
+template <typename T, int TKB, int GMAX>
+__global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
+    k_syrkd_rowtiles(int64_t n, int64_t row0, int64_t row_end, int G, const int64_t* __restrict__ tptr,
+                     const int32_t* __restrict__ tcol, const T* __restrict__ tval, const int64_t* __restrict__ xptr,
+                     const int32_t* __restrict__ xcol, const T* __restrict__ xval, const int32_t* __restrict__ off,
+                     T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero)
+{
+    constexpr int TILE = syrkd_tile<T, TKB>();
+    constexpr int SUB = MI_GRAM_SUB;
+    constexpr int RPS = WAVE / SUB;
+    constexpr int NSTEP = WAVE / RPS;
+    __shared__ T acc[TILE];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int wave = tid / WAVE, lane = tid % WAVE, nwaves = nthreads / WAVE;
+    const int sub = lane % SUB, grp = lane / SUB;
+    struct Head {
+        int64_t t0, t1;            // A
+        int32_t r;                 // B (lane = selected row)
+        T a;
+        int64_t xb;                // C: start of row r of X ...
+        int32_t o[GMAX + 1];        //    ... and its entries left of every tile boundary
+        bool valid;
+    };
+    auto stage_a = [&](int64_t i, Head& h) {
+        h.t0 = tptr[i];
+        h.t1 = tptr[i + 1];
+    };
+    auto stage_b = [&](Head& h) {
+        const int64_t base = h.t0 + (int64_t)wave * WAVE;
+        const int64_t p = base + lane < h.t1 ? base + lane : (h.t0 < h.t1 ? h.t1 - 1 : 0);  // always a valid entry
+        h.valid = base + lane < h.t1;
+        h.r = tcol[p];
+        h.a = vt<T>::mul(alpha, tval[p]);
+    };
+    auto stage_c = [&](Head& h) {
+        h.xb = xptr[h.r];
+        const int32_t* orow = off + (int64_t)h.r * (G + 1);
+#pragma unroll
+        for (int k = 0; k <= GMAX; ++k) h.o[k] = orow[k <= G ? k : G];
+    };
+    auto slice_of = [&](const Head& h, int g, int64_t& s, int32_t& len) {
+        int32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < GMAX; ++k)
+            if (k == g) {
+                lo = h.o[k];
+                hi = h.o[k + 1];
+            }
+        s = h.xb + lo;
+        len = h.valid ? hi - lo : 0;
+    };
+    auto walk64 = [&](int64_t s, int32_t len, T a, int64_t j_lo, int64_t tile_lo, int64_t safe) {
+        // entries sub and sub + SUB of every row of all NSTEP steps are loaded before the first LDS atomic: a slice
+        // longer than SUB entries used to cost its step one more DEPENDENT round trip, one step after the other
+        // (with ~8 entries per slice nearly every step of 8 rows has such a row: 8 serial round trips per 64 rows)
+        int32_t jv[2][NSTEP], ln[NSTEP];
+        int64_t sk[NSTEP];
+        T av[NSTEP], xv[2][NSTEP];
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {
+            const int src = k * RPS + grp;
+            sk[k] = __shfl(s, src);
+            ln[k] = __shfl(len, src);
+            av[k] = __shfl(a, src);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = sub + h * SUB < ln[k];
+                const int64_t qq = ok ? sk[k] + sub + h * SUB : safe;
+                jv[h][k] = xcol[qq];
+                xv[h][k] = xval[qq];
+                if (!ok) jv[h][k] = -1;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k)
+                if (jv[h][k] >= j_lo) atomic_accum(&acc[jv[h][k] - tile_lo], vt<T>::mul(av[k], xv[h][k]));
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {  // slices longer than 2 SUB entries
+            for (int e = sub + 2 * SUB; e < ln[k]; e += SUB) {
+                const int64_t j = xcol[sk[k] + e];
+                if (j >= j_lo) atomic_accum(&acc[j - tile_lo], vt<T>::mul(av[k], xval[sk[k] + e]));
+            }
+        }
+    };
+    int64_t i = row0 + blockIdx.x;
+    Head cur, nxt;
+    if (i < row_end) {
+        stage_a(i, cur);
+        stage_b(cur);
+        stage_c(cur);
+    }
+    for (; i < row_end; i += gridDim.x) {
+        const int64_t ni = i + gridDim.x;
+        const bool more = ni < row_end;
+        const int g_first = (int)(i / TILE);
+        if (more) stage_a(ni, nxt);
+        const int64_t t0 = cur.t0, t1 = cur.t1;
+        for (int g = g_first; g < G; ++g) {
+            const int64_t tile_lo = (int64_t)g * TILE;
+            const int64_t j_lo = i > tile_lo ? i : tile_lo;
+            const int64_t j_hi = tile_lo + TILE < n ? tile_lo + TILE : n;
+            for (int k = tid; k < (int)(j_hi - tile_lo); k += nthreads) acc[k] = vt<T>::zero();
+            __syncthreads();
+            if (more && g == g_first) stage_b(nxt);
+            if (t0 + (int64_t)wave * WAVE < t1) {
+                int64_t s;
+                int32_t len;
+                slice_of(cur, g, s, len);
+#ifdef MI_GRAM_NOWALK
+                if (s == -1 && len == -1)  // experiment: no walk
+#endif
+                walk64(s, len, cur.a, j_lo, tile_lo, t0);
+            }
+            for (int64_t base = t0 + (int64_t)(wave + nwaves) * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {
+                // further rows of a long list: fetched here, per tile, the chain exposed
+                const int64_t p = base + lane < t1 ? base + lane : t1 - 1;
+                const int32_t r = tcol[p];
+                const T a = vt<T>::mul(alpha, tval[p]);
+                const int64_t xb = xptr[r];
+                const int32_t* orow = off + (int64_t)r * (G + 1) + g;
+                const int32_t o0 = orow[0], o1 = orow[1];
+                walk64(xb + o0, base + lane < t1 ? o1 - o0 : 0, a, j_lo, tile_lo, t0);
+            }
+            if (more && g == g_first) stage_c(nxt);
+            __syncthreads();
+            syrkd_write_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, tile_lo, beta, beta_zero, tid, nthreads);
+            __syncthreads();  // the tile is reused
+        }
         cur = nxt;
     }
 }
@@ -424,13 +621,41 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
 #define MI_SYRKD_ARGS                                                                                               \
     (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, (const int32_t*)x.col,   \
         (const T*)x.val
-        if (sliced) {
+        if (sliced && off && tiles_per_row <= GRAM_GMAX && options().gram_rowtiles) {
+            // one workgroup per output row, persistent over rows: grid = LDS slots of the chip (a multiple of 8: row i on XCD i % 8)
+            c.ensure();
+            int64_t rgrid = (int64_t)c.cus * (wide ? 1 : 2) * (persistent > 0 ? persistent : 1);
+            rgrid = (rgrid + 7) / 8 * 8;
+            if (rgrid > nr) rgrid = nr;
+#define MI_ROWTILES(TKB_, GM_, THREADS_)                                                                              \
+    MI_LAUNCH((k_syrkd_rowtiles<T, TKB_, GM_>), dim3((unsigned)rgrid), dim3(THREADS_), c.stream, n, row0, row1,         \
+              (int)tiles_per_row, MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero)
+            if (wide) {
+                if (tiles_per_row <= 8) MI_ROWTILES(128, 8, 1024); else MI_ROWTILES(128, 16, 1024);
+            } else {
+                if (tiles_per_row <= 8) MI_ROWTILES(64, 8, 512); else MI_ROWTILES(64, 16, 512);
+            }
+#undef MI_ROWTILES
+        } else if (sliced) {
+            // clusters of `cs` workgroups per XCD pulling the tiles of their output rows from a queue (see the kernel)
+            unsigned long long* queue = nullptr;
+            const int cs = (int)options().gram_cluster;
+            if (cs > 0 && persistent > 0 && off) {
+                const int64_t slots = (int64_t)c.cus * (wide ? 1 : 2) * persistent;
+                const int64_t gq = slots / (8 * cs) * (8 * cs);
+                if (gq >= 8 * cs && gq <= nblocks) {
+                    grid = gq;
+                    const int64_t nclus = gq / cs;
+                    queue = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * (size_t)nclus));
+                    MI_HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long) * (size_t)nclus, c.stream));
+                }
+            }
             if (wide)
                 MI_LAUNCH((k_syrkd_sliced<T, 128>), dim3((unsigned)grid), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
-                          MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
+                          MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks, queue, cs);
             else
                 MI_LAUNCH((k_syrkd_sliced<T, 64>), dim3((unsigned)grid), dim3(512), c.stream, n, row0, row1, tiles_per_row,
-                          MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
+                          MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks, queue, cs);
         } else if (wide) {
             MI_LAUNCH((k_syrkd_lds<T, 128>), dim3((unsigned)grid), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
                       MI_SYRKD_ARGS, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);

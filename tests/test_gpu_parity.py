@@ -1191,7 +1191,13 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
             return h
         h = mk(ip, idx, val)
         one, zero = (ct.c_float(1.0), ct.c_float(0.0)) if dtype == np.float32 else (ct.c_double(1.0), ct.c_double(0.0))
-        for sliced, tile_kb, persistent in ((2, 128, -1), (2, 64, 4), (2, 128, 0), (0, 128, -1), (0, 64, 1), (1, 128, -1)):
+        # (sliced, tile KiB, persistent, rowtiles): rowtiles = one workgroup walks all tiles of an output row
+        # cluster = workgroups per cluster pulling tiles from a queue (0: static tile order)
+        for sliced, tile_kb, persistent, rowtiles, cluster in ((2, 128, -1, 1, 8), (2, 64, 4, 1, 8), (2, 128, -1, 0, 8), (2, 64, 4, 0, 4),
+                                                               (2, 128, 1, 0, 0), (2, 128, 0, 0, 8), (0, 128, -1, 0, 8), (0, 64, 1, 0, 8),
+                                                               (1, 128, -1, 0, 16)):
+            gpu.mi_set_option("gram_cluster", cluster)
+            gpu.mi_set_option("gram_rowtiles", rowtiles)
             gpu.mi_set_option("gram_sliced", sliced)
             gpu.mi_set_option("gram_tile_kb", tile_kb)
             gpu.mi_set_option("gram_persistent", persistent)
@@ -1203,6 +1209,8 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         gpu.mi_set_option("gram_sliced", 2)
         gpu.mi_set_option("gram_tile_kb", 128)
         gpu.mi_set_option("gram_persistent", -1)
+        gpu.mi_set_option("gram_rowtiles", 0)
+        gpu.mi_set_option("gram_cluster", 8)
         # a band of output rows that starts inside a tile
         r0, r1 = 20001, 20001 + 4099
         band = torch.full((r1 - r0, n), -7.0, device=dev, dtype=tdt)
@@ -1225,6 +1233,8 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         gpu.mi_set_option("gram_sliced", 1)
         gpu.mi_set_option("gram_tile_kb", 128)
         gpu.mi_set_option("gram_persistent", -1)
+        gpu.mi_set_option("gram_rowtiles", 0)
+        gpu.mi_set_option("gram_cluster", 8)
         for h in handles:
             MI.call("mi_sparse_destroy", h)
         gpu.mi_set_stream(0)
