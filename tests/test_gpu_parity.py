@@ -1210,7 +1210,7 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         gpu.mi_set_option("gram_tile_kb", 128)
         gpu.mi_set_option("gram_persistent", -1)
         gpu.mi_set_option("gram_rowtiles", 0)
-        gpu.mi_set_option("gram_cluster", 8)
+        gpu.mi_set_option("gram_cluster", 8)   # the band through the cluster queue
         # a band of output rows that starts inside a tile
         r0, r1 = 20001, 20001 + 4099
         band = torch.full((r1 - r0, n), -7.0, device=dev, dtype=tdt)
@@ -1234,7 +1234,7 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         gpu.mi_set_option("gram_tile_kb", 128)
         gpu.mi_set_option("gram_persistent", -1)
         gpu.mi_set_option("gram_rowtiles", 0)
-        gpu.mi_set_option("gram_cluster", 8)
+        gpu.mi_set_option("gram_cluster", 0)
         for h in handles:
             MI.call("mi_sparse_destroy", h)
         gpu.mi_set_stream(0)
