@@ -150,6 +150,51 @@ __device__ __forceinline__ T nt_load(const T* p)
     else return *p;
 }
 
+// streaming stores (written once, not read again by the kernel): one element, or 16 bytes from `src` to a 16-byte
+// aligned `dst`
+template <typename T>
+__device__ __forceinline__ void nt_store(T* dst, T v)
+{
+#ifdef MI_HIP_EMU
+    *dst = v;
+#else
+    __builtin_nontemporal_store(v, dst);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void nt_store16(T* dst, const T* src)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+#ifdef MI_HIP_EMU
+    for (int u = 0; u < V; ++u) dst[u] = src[u];
+#else
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    vec_t v;
+#pragma unroll
+    for (int u = 0; u < V; ++u) v[u] = src[u];
+    __builtin_nontemporal_store(v, reinterpret_cast<vec_t*>(dst));
+#endif
+}
+
+// value of lane `src` when `src` is the SAME in every lane: v_readlane_b32 -- a scalar result, nothing goes through the
+// LDS queue (as __shfl = ds_bpermute it is an LDS-pipeline instruction per 32 bits and the value stays in a VGPR)
+template <typename T>
+__device__ __forceinline__ T lane_bcast(T v, int src)
+{
+#ifdef MI_HIP_EMU
+    return __shfl(v, src);
+#else
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "lane_bcast: 4- or 8-byte values");
+    int w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); ++k) w[k] = __builtin_amdgcn_readlane(w[k], src);
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+#endif
+}
+
 // atomic accumulate (LDS or global).  Real types map to the hardware float / double atomic add
 // (-munsafe-fp-atomics); complex does the two components independently.
 template <typename T>

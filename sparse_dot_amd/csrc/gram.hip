@@ -17,26 +17,6 @@ namespace mi {
 // same column), and the finished tile is written to HBM exactly once, coalesced, with beta applied
 // on the way -- no global atomics, no separate scaling pass.  Tiles start at the diagonal (only
 // col >= row is produced).
-// `src` is the same in every lane: v_readlane_b32 -- the result is a scalar register and nothing goes through the LDS
-// queue (as __shfl / ds_bpermute it was five LDS-pipeline instructions per selected row, next to that row's one LDS
-// atomic, and kept the per-row scalars in vector registers)
-template <typename T>
-__device__ __forceinline__ T shfl_bcast(T v, int src)
-{
-#ifdef MI_HIP_EMU
-    return __shfl(v, src);
-#else
-    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "shfl_bcast: 4- or 8-byte values");
-    int w[sizeof(T) / 4];
-    __builtin_memcpy(w, &v, sizeof(T));
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(T) / 4); ++k) w[k] = __builtin_amdgcn_readlane(w[k], src);
-    T r;
-    __builtin_memcpy(&r, w, sizeof(T));
-    return r;
-#endif
-}
-
 #ifndef MI_GRAM_SUB
 #define MI_GRAM_SUB 8
 #endif
@@ -51,34 +31,18 @@ __device__ __forceinline__ void syrkd_write_tile(const T* acc, T* crow, int64_t 
                                                  T beta, int beta_zero, int tid, int nthreads)
 {
     constexpr int V = 16 / (int)sizeof(T);
-#ifdef MI_GRAM_NOWRITE
-    if (acc[tid] != T(-12345.5)) return;  // experiment: no write-out
-#endif
-#ifndef MI_HIP_EMU
     if (beta_zero && c_cs == 1 && MI_GRAM_NT_STORE) {
         T* p0 = crow + j_lo;
         int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(p0) & 15)) & 15) / sizeof(T));
         if (head > j_hi - j_lo) head = j_hi - j_lo;
-        const int64_t body = (j_hi - j_lo - head) / V;  // vectors
-        if (tid < head) __builtin_nontemporal_store(acc[j_lo - tile_lo + tid], p0 + tid);
-        typedef T vec_t __attribute__((ext_vector_type(V)));
-        vec_t* pv = reinterpret_cast<vec_t*>(p0 + head);
+        const int64_t body = (j_hi - j_lo - head) / V;  // 16-byte vectors
+        if (tid < head) nt_store(p0 + tid, acc[j_lo - tile_lo + tid]);
         const T* a0 = acc + (j_lo - tile_lo + head);
-        for (int64_t k = tid; k < body; k += nthreads) {
-            vec_t v;
-#pragma unroll
-            for (int u = 0; u < V; ++u) v[u] = a0[k * V + u];
-#if MI_GRAM_NT_STORE == 2
-            pv[k] = v;  // A/B: 16-byte stores without the non-temporal hint
-#else
-            __builtin_nontemporal_store(v, pv + k);
-#endif
-        }
+        for (int64_t k = tid; k < body; k += nthreads) nt_store16(p0 + head + k * V, a0 + k * V);
         const int64_t done = head + body * V;
-        if (tid < j_hi - j_lo - done) __builtin_nontemporal_store(acc[j_lo - tile_lo + done + tid], p0 + done + tid);
+        if (tid < j_hi - j_lo - done) nt_store(p0 + done + tid, acc[j_lo - tile_lo + done + tid]);
         return;
     }
-#endif
     for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
         T* c = crow + j * c_cs;
         const T v = acc[j - tile_lo];
@@ -152,9 +116,9 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const int e = (e0 + u < cnt) ? e0 + u : (e0 < cnt ? e0 : 0);  // clamp: duplicates are masked out below
-                st.qs[u] = shfl_bcast(q0, e);
-                st.qe[u] = (e0 + u < cnt) ? shfl_bcast(q1, e) : st.qs[u];
-                st.ae[u] = shfl_bcast(a, e);
+                st.qs[u] = lane_bcast(q0, e);
+                st.qe[u] = (e0 + u < cnt) ? lane_bcast(q1, e) : st.qs[u];
+                st.ae[u] = lane_bcast(a, e);
             }
 #pragma unroll
             for (int u = 0; u < R; ++u) {  // first 64 entries of each row: loads issued together
@@ -521,9 +485,6 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
                 int64_t s;
                 int32_t len;
                 slice_of(cur, g, s, len);
-#ifdef MI_GRAM_NOWALK
-                if (s == -1 && len == -1)  // experiment: no walk
-#endif
                 walk64(s, len, cur.a, j_lo, tile_lo, t0);
             }
             for (int64_t base = t0 + (int64_t)(wave + nwaves) * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {

@@ -175,7 +175,7 @@ struct FlatCursor {
 #define MI_BIN4_THREADS 128
 #endif
 #ifndef MI_LDS_UNROLL
-#define MI_LDS_UNROLL 2
+#define MI_LDS_UNROLL 4
 #endif
 constexpr int LDS_UNROLL = MI_LDS_UNROLL;
 template <typename T, int LOG2S, int THREADS, bool NUMERIC>

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../sparse_dot_amd/csrc"
 mkdir -p build/var
-SPECS="${SPECS:-ge1:-DMI_GRAM_EXP=1 ge2:-DMI_GRAM_EXP=2 ge3:-DMI_GRAM_EXP=3 gr8:-DMI_GRAM_R=8 gr2:-DMI_GRAM_R=2}"
+SPECS="${SPECS:-gr8:-DMI_GRAM_R=8 gr2:-DMI_GRAM_R=2 sub16:-DMI_GRAM_SUB=16 sub4:-DMI_GRAM_SUB=4 scalarst:-DMI_GRAM_NT_STORE=0}"
 for spec in $SPECS; do
   tag=${spec%%:*}; def=$(echo ${spec#*:} | tr '@' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $def -c gram.hip -o build/var/gram_$tag.o &
