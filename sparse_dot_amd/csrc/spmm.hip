@@ -586,6 +586,11 @@ __device__ __forceinline__ cx<R> shfl_down_val(cx<R> v, int d)
     return cx<R>{__shfl_xor(v.re, d), __shfl_xor(v.im, d)};
 }
 
+#ifndef MI_SPMV_U
+#define MI_SPMV_U 4
+#endif
+constexpr int SPMV_U = MI_SPMV_U;  // nonzeros per lane in flight (k_spmv)
+
 template <typename T>
 __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
     k_spmv(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
@@ -650,28 +655,20 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
         const int len = (int)(P1 - P0);
         // coalesced A stream + gather of x, four nonzeros per lane in flight (all loads of a group are issued
         // before the first use: the chain col -> x is paid once per group, not once per nonzero)
-        for (int k0 = lane; k0 < len; k0 += 4 * WAVE) {
-            T a[4], xv[4];
-            int32_t cc[4];
+        for (int k0 = lane; k0 < len; k0 += SPMV_U * WAVE) {
+            // loads unconditional (positions past the end re-read the lane's first item), every use after the last load
+            T a[SPMV_U], xv[SPMV_U];
+            int32_t cc[SPMV_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * WAVE;
-                cc[u] = 0;
-                a[u] = vt<T>::zero();
-                if (k < len) {
-                    cc[u] = col[P0 + k];
-                    a[u] = val[P0 + k];
-                }
+            for (int u = 0; u < SPMV_U; ++u) {
+                const int k = k0 + u * WAVE < len ? k0 + u * WAVE : k0;
+                cc[u] = col[P0 + k];
+                a[u] = val[P0 + k];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                xv[u] = vt<T>::zero();
-                if (k0 + u * WAVE < len) {
-                    xv[u] = x[(int64_t)cc[u] * x_s];  // plain loads: non-temporal ones are 1.7-2x slower here (measured)
-                }
-            }
+            for (int u = 0; u < SPMV_U; ++u) xv[u] = x[(int64_t)cc[u] * x_s];  // plain loads: non-temporal ones are 1.7-2x slower here (measured)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SPMV_U; ++u) {
                 const int k = k0 + u * WAVE;
                 if (k < len) s_prod[k] = vt<T>::mul(conj_a ? vt<T>::conj(a[u]) : a[u], xv[u]);
             }
