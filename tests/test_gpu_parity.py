@@ -1218,6 +1218,27 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         torch.cuda.synchronize()
         check_rows(band, r0, np.unique(np.concatenate([[r0, r1 - 1], rng.integers(r0, r1, 40)])))
         band = None
+        # column-major output with beta = 1 on a prefilled array, through A A^T of the transpose (op = 10 on a handle
+        # of A^T): the scalar write-out path with the read-modify-write, multi-tile
+        at = a_host.T.tocsr()
+        at.sort_indices()
+        tip = torch.as_tensor(at.indptr.astype(np.int32), device=dev)
+        tidx = torch.as_tensor(at.indices.astype(np.int32), device=dev)
+        tval = torch.as_tensor(at.data.astype(dtype), device=dev)
+        ht = sparse_matrix_t()
+        _check_return_value(MI.call("mi_sparse_%s_create_csr" % pre, ct.byref(ht), 0, n, m, tip.data_ptr(), tip.data_ptr() + 4,
+                                    tidx.data_ptr(), tval.data_ptr()), "create")
+        handles.append(ht)
+        Ct = torch.full((n, n), -7.0, device=dev, dtype=tdt)   # column-major: element (i, j) lives at Ct[j, i]
+        _check_return_value(MI.call("mi_sparse_%s_syrkd" % pre, 10, ht, one, one, Ct.data_ptr(), 102, n), "syrkd col-major")
+        torch.cuda.synchronize()
+        rows_cm = sample[::3]
+        got = Ct[:, torch.as_tensor(rows_cm, device=dev)].T.cpu().numpy().astype(np.float64)
+        for k, i in enumerate(rows_cm.tolist()):
+            ref = np.asarray(want[i].todense()).ravel()
+            assert np.all(got[k, :i] == -7.0), i
+            assert np.all(np.abs(got[k, i:] - (ref[i:] - 7.0)) <= tolv * (np.abs(ref[i:]) + 7.0) + 1e-300), i
+        Ct = None
         # rows of A in shuffled order inside each row: not sorted -> whole-row walk
         perm = torch.argsort(torch.rand(idx.numel(), device=dev) + torch.repeat_interleave(
             torch.arange(m, device=dev, dtype=torch.float32), (ip[1:] - ip[:-1]).long()) * 2.0)
