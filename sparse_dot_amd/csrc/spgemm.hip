@@ -563,6 +563,10 @@ constexpr int PART_THREADS = MI_PART_THREADS;
 #ifndef MI_PART_GROUP
 #define MI_PART_GROUP 1
 #endif
+#ifndef MI_PART_XCD_RUN
+#define MI_PART_XCD_RUN 32
+#endif
+constexpr int PART_XCD_RUN = MI_PART_XCD_RUN;  // consecutive work items per XCD (0: round-robin)
 constexpr int PART_GROUP = MI_PART_GROUP;  // consecutive ranges of a big row per workgroup (k_spgemm_part)
 constexpr int PART_UNROLL = MI_PART_UNROLL;
 constexpr int BITMAP_UNROLL = MI_BITMAP_UNROLL;
@@ -895,7 +899,7 @@ __global__ void k_part_groups(const int64_t* __restrict__ items, int64_t nb, int
 
 template <typename T, int LOG2S, bool PRE>
 __global__ void __launch_bounds__(PART_THREADS)
-    k_spgemm_part(int64_t item_base, const int32_t* __restrict__ item_t, const PartDesc* __restrict__ desc,
+    k_spgemm_part(int64_t item_base, int64_t n_items, const int32_t* __restrict__ item_t, const PartDesc* __restrict__ desc,
                   const int32_t* __restrict__ bounds, int64_t ncols, int64_t cap,
                   const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
@@ -911,7 +915,17 @@ __global__ void __launch_bounds__(PART_THREADS)
     __shared__ int wave_tot[NT / 64];
     __shared__ int n_out;
     const int tid = threadIdx.x;
-    const int64_t item = item_base + blockIdx.x;
+    // XCD-affine order: workgroup b runs on XCD b % 8 (observed; speed only).  Runs of PART_XCD_RUN consecutive items --
+    // the neighbouring ranges of one or two rows, which read neighbouring slices of the SAME rows of B and share the
+    // cache lines at the slice boundaries (a slice is ~12 entries, a line 16-32) -- go to one XCD, back to back; the
+    // runs go round-robin over the XCDs.  (One item per XCD in turn put neighbouring ranges on eight different L2s.)
+    int64_t item;
+    {
+        const int64_t b = item_base + blockIdx.x;
+        const int64_t local = b >> 3, blk = local / PART_XCD_RUN;
+        item = PART_XCD_RUN > 0 ? (blk * 8 + (b & 7)) * PART_XCD_RUN + (local - blk * PART_XCD_RUN) : b;
+        if (item >= n_items) return;  // the list is padded to a multiple of 8 runs
+    }
     const PartDesc d = desc[item_t[item]];
     // PART_GROUP consecutive ranges of the row, one after the other: the descriptor is loaded once and the first
     // slices of the next range are fetched while the current one is walked.  Measured on the literal configs[2]
@@ -1315,8 +1329,9 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                 auto launch = [&](auto log2s_tag, auto pre_tag) {
                     constexpr int L = decltype(log2s_tag)::value;
                     constexpr bool P = decltype(pre_tag)::value;
-                    launch_batched(n_groups, PART_THREADS, [&](int64_t off, int64_t nblk) {
-                        MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)nblk), dim3(PART_THREADS), c.stream, off,
+                    const int64_t run8 = PART_XCD_RUN > 0 ? (int64_t)PART_XCD_RUN * 8 : 1;
+                    launch_batched(ceil_div(n_groups, run8) * run8, PART_THREADS, [&](int64_t off, int64_t nblk) {
+                        MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)nblk), dim3(PART_THREADS), c.stream, off, n_groups,
                                   (const int32_t*)item_t, (const PartDesc*)desc, bounds, B.cols, CAP, (const int32_t*)A.col,
                                   (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val, upper,
                                   (const int32_t*)bnd, ccol, cval);

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../sparse_dot_amd/csrc"
 mkdir -p build/var
-SPECS="pu4:-DMI_PART_UNROLL=4 pu3:-DMI_PART_UNROLL=3 lu4:-DMI_LDS_UNROLL=4 bu16:-DMI_BITMAP_UNROLL=16"
+SPECS="xr0:-DMI_PART_XCD_RUN=0 xr8:-DMI_PART_XCD_RUN=8 xr128:-DMI_PART_XCD_RUN=128 xr32g4:-DMI_PART_GROUP=4"
 for spec in $SPECS; do
   tag=${spec%%:*}; def=$(echo ${spec#*:} | tr '@' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $def -c spgemm.hip -o build/var/spgemm_$tag.o &
