@@ -6,6 +6,9 @@ import sparse_dot_amd as sda
 from sparse_dot_amd._mi_interface import MI, matrix_descr, sparse_matrix_t, _check_return_value
 dev = torch.device("cuda", 0)
 sda.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+for kv in os.environ.get("MI_BENCH_OPTS", "").split(","):  # e.g. MI_BENCH_OPTS=spmv_rows=0
+    if "=" in kv:
+        sda.mi_set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for kind in ("rmat", "uniform"):
     ip, idx, val, n = bench.rmat_csr(torch, 20, 32, 7, dev) if kind == "rmat" else bench.uniform_csr(torch, 1 << 20, 32, 7, dev)
     x = torch.rand(n, device=dev); y = torch.empty(n, device=dev)
