@@ -111,20 +111,28 @@ __host__ __device__ constexpr size_t spmm_wave_lds(int ch)
     return (size_t)(ch + SPMM_SPLIT) * sizeof(SpEntry<T>) + (size_t)(ch + 2) * sizeof(int32_t);
 }
 
-#ifndef MI_SPMM_MIN_WAVES
-#define MI_SPMM_MIN_WAVES 8
-#endif
-// TAG: the staged column indices carry a "cold" flag in bit 31 (plan.col_tagged).  Hot rows of B are
-// fetched with the default cache policy, cold rows with the non-temporal one (`buffer_load ... nt`:
-// the cache policy is an immediate of the instruction, so the two flavours are two instructions
-// selected per lane group), which keeps the streaming majority of the gather from evicting the few
-// MB of B rows that power-law matrices hit over and over.  Needs B below 4 GiB (32-bit buffer offsets).
-template <typename T, int V, int LPN, int U, bool TAG>
-__global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ? MI_SPMM_MIN_WAVES : 1)
+// TAG != 0: the staged column indices carry a "cold" flag in bit 31 (plan.col_tagged).  Hot rows of B are
+// fetched with the default cache policy, cold rows with the non-temporal one (the cache policy is an
+// immediate of the instruction, so the two flavours are two instructions selected per lane group), which
+// keeps the streaming majority of the gather from evicting the few MB of B rows that power-law matrices
+// hit over and over.
+//   TAG == 1: raw buffer loads, 32-bit byte offsets (one VGPR of address per load) -- B below 4 GiB.  The
+//             resource spans the whole 32-bit offset range (num_records = 0xffffffff): the range check
+//             returns ZERO for any offset at or beyond num_records, so a smaller constant silently
+//             drops rows of B (tests/test_gpu_baseline_configs.py::test_spmm_tagged_gather_large_dense_operand).
+//   TAG == 2: STRUCTURED buffer loads (`buffer_load_dwordx4 ... idxen offen`): the hardware forms
+//             base + column * stride + offset in 64 bits, so B may exceed 4 GiB (BASELINE configs[4]: 17 GB) and the
+//             address costs no VALU multiply; needs a row stride below 16 KiB (14-bit stride field).
+//             (Two global loads that differ only in the non-temporal hint are merged by the compiler, which
+//             drops the hint -- the buffer forms carry the policy as an immediate and stay apart.)
+constexpr int SPMM_TAG_NONE = 0, SPMM_TAG_BUFFER = 1, SPMM_TAG_STRUCT = 2;
+template <typename T, int V, int LPN, int U, int TAG>
+__global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ? 8 : 1)
     k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
            const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
            const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
-           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices)
+           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices, int stream_nt,
+           int64_t b_rows)
 {
     MI_DYN_SMEM(smem);
     constexpr int NG = WAVE / LPN;  // lane groups per wave, each on its own nonzero
@@ -200,12 +208,23 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
             s_end[k] = (int32_t)(en - P0);
         }
         const int len = (int)(P1 - P0);
-        for (int k = lane; k < len; k += WAVE) {
-            const T a = val[P0 + k];
-            SpEntry<T> en;
-            en.c = col[P0 + k];
-            en.v = conj_a ? vt<T>::conj(a) : a;
-            s_nz[k] = en;
+        // stream_nt: A is touched once per slice -- the non-temporal policy keeps it from displacing rows of B in L2
+        if (stream_nt) {
+            for (int k = lane; k < len; k += WAVE) {
+                const T a = nt_load(&val[P0 + k]);
+                SpEntry<T> en;
+                en.c = nt_load(&col[P0 + k]);
+                en.v = conj_a ? vt<T>::conj(a) : a;
+                s_nz[k] = en;
+            }
+        } else {
+            for (int k = lane; k < len; k += WAVE) {
+                const T a = val[P0 + k];
+                SpEntry<T> en;
+                en.c = col[P0 + k];
+                en.v = conj_a ? vt<T>::conj(a) : a;
+                s_nz[k] = en;
+            }
         }
     }
     __syncthreads();
@@ -215,7 +234,10 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     const int li = lane % LPN;
     const int nproc = n_owned + has_trail;
     __amdgpu_buffer_rsrc_t b_rsrc;
-    if constexpr (TAG) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+    if constexpr (TAG == SPMM_TAG_BUFFER) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0xffffffff, 0x00020000);
+    // structured: record = one row of B (stride bytes), num_records = rows of B (range check: index < records, offset + 16 <= stride)
+    if constexpr (TAG == SPMM_TAG_STRUCT)
+        b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, (short)(b_rs * (int64_t)sizeof(T)), (int)b_rows, 0x00020000);
 
     for (int64_t j0 = jlo; j0 < jhi; j0 += (int64_t)LPN * V) {
         const int64_t jc = j0 + (int64_t)li * V;  // first column of this lane
@@ -243,12 +265,19 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
                     // narrow rows of B (many lane groups): idle groups issue no load at all; wide rows: the
                     // clamped entry is re-read (an L1 hit) and the loop stays free of divergence
                     if (NG >= 8 && !ok[u]) continue;
-                    if constexpr (TAG) {
+                    if constexpr (TAG == SPMM_TAG_BUFFER) {
                         const int32_t cidx = nz[u].c & 0x7fffffff;
                         const unsigned voff = (unsigned)(((int64_t)cidx * b_rs + (col_ok ? jc : jlo)) * (int64_t)sizeof(T));
                         u32x4 r;
                         if (nz[u].c < 0) r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 2);  // nt
                         else r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 0);
+                        b[u] = __builtin_bit_cast(vec<T, V>, r);
+                    } else if constexpr (TAG == SPMM_TAG_STRUCT) {
+                        const int32_t cidx = nz[u].c & 0x7fffffff;
+                        const int boff = (int)((col_ok ? jc : jlo) * (int64_t)sizeof(T));
+                        u32x4 r;
+                        if (nz[u].c < 0) r = mi_struct_buffer_load_b128(b_rsrc, cidx, boff, 0, 2);  // nt
+                        else r = mi_struct_buffer_load_b128(b_rsrc, cidx, boff, 0, 0);
                         b[u] = __builtin_bit_cast(vec<T, V>, r);
                     } else {
                         const T* src = bcol + (int64_t)nz[u].c * b_rs;
@@ -293,7 +322,8 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
                             out.v[v] = vt<T>::fma(alpha, acc[v], vt<T>::mul(beta, old.v[v]));
                     }
                     if (V > 1) {
-                        *reinterpret_cast<vec<T, V>*>(crow) = out;
+                        if (stream_nt) nt_store16(crow, out.v);  // written once, never re-read by this kernel
+                        else *reinterpret_cast<vec<T, V>*>(crow) = out;
                     } else {
                         crow[0] = out.v[0];
                     }
@@ -315,281 +345,10 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
 }
 
 // ------------------------------------------------------------------------------------------------
-// Flat variant for NARROW (slices of) rows of B: LPN <= 16 lanes cover the slice, so a wave has NG = 64 / LPN >= 4
-// lane groups.  k_spmm lets all groups work on one output row at a time and combines them with shuffles at every
-// row end: with 8 or 16 groups and ~30 nonzeros per row that is one round trip to memory per row, idle slots
-// for short rows and a drained load queue at every row end.  Here the chunk's nonzeros are one flat list cut into
-// NG CONTIGUOUS pieces, one per lane group.  A group walks its piece with U loads in flight that never drain
-// (software pipelined across row ends); rows that lie inside one piece are finished and stored by that group
-// alone; a row that crosses piece boundaries leaves a tail partial in every earlier group and a head partial in
-// the group where it ends, which that group sums in piece order after the walk (deterministic).  Same partition,
-// ownership rules, carries and fix-up as k_spmm; empty rows are written by a separate short pass.
-// The A stream and the C stores use the non-temporal policy: both are touched once and should not evict B rows.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int V, int LPN, bool TAG>
-__global__ void __launch_bounds__(SPMM_WAVES* WAVE, (sizeof(T) <= 8) ? 5 : 1)  // ~94 VGPRs without spills: 5 waves / SIMD
-    k_spmm_flat(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
-                const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
-                const T* __restrict__ B, int64_t b_rs, T* __restrict__ C, int64_t c_rs, int64_t N, T alpha, T beta,
-                int beta_zero, T* __restrict__ carry_val, int slices)
-{
-    MI_DYN_SMEM(smem);
-    constexpr int NG = WAVE / LPN;
-    constexpr int U = 4;
-    static_assert(V * sizeof(T) == 16, "flat kernel is the 16-byte vector path");
-    const int wave_in_block = threadIdx.x / WAVE;
-    const int lane = threadIdx.x % WAVE;
-    int64_t cb = blockIdx.x;
-    int64_t jlo = 0, jhi = N;
-    if (slices > 1) {  // XCD-affine column slices, see k_spmm
-        const int xcd = (int)(blockIdx.x & 7u);
-        const int per = 8 / slices;
-        cb = (int64_t)(blockIdx.x >> 3) * per + (xcd % per);
-        const int64_t ns = N / slices;
-        jlo = (xcd / per) * ns;
-        jhi = jlo + ns;
-    }
-    const int64_t w = cb * SPMM_WAVES + wave_in_block;
-    const bool active = w < nchunks;
-    const size_t per_wave = (spmm_wave_lds<T>(ch) + 15) & ~size_t(15);
-    char* base = smem + per_wave * wave_in_block;
-    SpEntry<T>* s_nz = reinterpret_cast<SpEntry<T>*>(base);
-    int32_t* s_end = reinterpret_cast<int32_t*>(base + sizeof(SpEntry<T>) * (size_t)(ch + SPMM_SPLIT));
-
-    int64_t r0 = 0, P0 = 0;
-    int n_owned = 0, has_trail = 0, len = 0;
-    if (active) {  // identical partition logic to k_spmm (see there for the ownership rules)
-        const int64_t total = nnz + rows;
-        const int64_t s = w * ch;
-        const int64_t e = (s + ch < total) ? s + ch : total;
-        const int64_t ra = chunk_row[w];
-        const int64_t rb = chunk_row[w + 1];
-        {
-            const int64_t pa = ptr[ra], pa1 = ptr[ra + 1];
-            const bool before = (pa + ra) < s;
-            const bool is_long = (pa1 - pa + 1) > SPMM_SPLIT;
-            if (before && !is_long) {
-                r0 = ra + 1;
-                P0 = pa1;
-            } else {
-                r0 = ra;
-                P0 = before ? s - ra : pa;
-            }
-        }
-        int64_t r_stop, P1;
-        if (rb < rows && (ptr[rb] + rb) < e) {
-            const int64_t pb = ptr[rb], pb1 = ptr[rb + 1];
-            r_stop = rb + 1;
-            if ((pb1 - pb + 1) > SPMM_SPLIT) {
-                P1 = (e - rb < pb1) ? e - rb : pb1;
-                has_trail = 1;
-            } else {
-                P1 = pb1;
-            }
-        } else {
-            r_stop = rb;
-            P1 = (rb < rows) ? ptr[rb] : nnz;
-        }
-        if (r_stop < r0) r_stop = r0;
-        const int nproc = (int)(r_stop - r0);
-        n_owned = nproc - has_trail;
-        for (int k = lane; k < nproc; k += WAVE) {
-            int64_t en = ptr[r0 + k + 1];
-            if (k == nproc - 1) en = P1;
-            s_end[k] = (int32_t)(en - P0);
-        }
-        len = (int)(P1 - P0);
-        if (len < 0) len = 0;
-        for (int k = lane; k < len; k += WAVE) {
-            const T a = nt_load(val + P0 + k);
-            SpEntry<T> en;
-            en.c = nt_load(col + P0 + k);
-            en.v = conj_a ? vt<T>::conj(a) : a;
-            s_nz[k] = en;
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-
-    const int g = lane / LPN;
-    const int li = lane % LPN;
-    const int nproc = n_owned + has_trail;
-    __amdgpu_buffer_rsrc_t b_rsrc;
-    if constexpr (TAG) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
-
-    // write one finished row (or the raw partial of the cut row into the carry buffer)
-    auto emit = [&](int k, const T (&acc)[V], int64_t jc) {
-        vec<T, V> out;
-        if (k < n_owned) {
-            T* crow = C + (r0 + k) * c_rs + jc;
-            if (beta_zero) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) out.v[v] = vt<T>::mul(alpha, acc[v]);
-            } else {
-                const vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(crow);
-#pragma unroll
-                for (int v = 0; v < V; ++v) out.v[v] = vt<T>::fma(alpha, acc[v], vt<T>::mul(beta, old.v[v]));
-            }
-            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, out), reinterpret_cast<u32x4*>(crow));
-        } else {
-#pragma unroll
-            for (int v = 0; v < V; ++v) out.v[v] = acc[v];
-            *reinterpret_cast<vec<T, V>*>(carry_val + w * N + jc) = out;
-        }
-    };
-
-    for (int64_t j0 = jlo; j0 < jhi; j0 += (int64_t)LPN * V) {
-        const int64_t jc = j0 + (int64_t)li * V;
-        const bool col_ok = jc < jhi;
-        const int64_t jcc = col_ok ? jc : jlo;
-        // ---- empty rows: nothing is accumulated for them, they are written here --------------------------------
-        for (int k = g; k < nproc; k += NG) {
-            const int b0 = k ? s_end[k - 1] : 0;
-            if (s_end[k] == b0 && col_ok) {
-                T z[V];
-#pragma unroll
-                for (int v = 0; v < V; ++v) z[v] = vt<T>::zero();
-                emit(k, z, jc);
-            }
-        }
-        if (len == 0) continue;
-        // ---- this group's piece [gs, ge) of the flat list --------------------------------------------------------
-        const int L = (len + NG - 1) / NG;
-        const int gs = g * L;
-        const int ge = (gs + L < len) ? gs + L : len;
-        const bool has_piece = gs < len;
-        int k = 0, row_end = 0x7fffffff;
-        bool started_before = false;
-        if (has_piece) {
-            int lo = 0, hi = nproc - 1;  // smallest k with s_end[k] > gs (exists: s_end[nproc - 1] == len > gs)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_end[mid] > gs) hi = mid; else lo = mid + 1;
-            }
-            k = lo;
-            row_end = s_end[k];
-            started_before = (k ? s_end[k - 1] : 0) < gs;
-        }
-        T acc[V], head[V];
-#pragma unroll
-        for (int v = 0; v < V; ++v) acc[v] = head[v] = vt<T>::zero();
-        int head_row = -1;
-        SpEntry<T> nz[U];
-        vec<T, V> b[U];
-        auto fetch = [&](int u, int pp) {  // entry pp of this group's piece -> registers, its row of B on the way
-            if (pp < ge) {
-                nz[u] = s_nz[pp];
-                if constexpr (TAG) {
-                    const int32_t cidx = nz[u].c & 0x7fffffff;
-                    const unsigned voff = (unsigned)(((int64_t)cidx * b_rs + jcc) * (int64_t)sizeof(T));
-                    u32x4 r;
-                    if (nz[u].c < 0) r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 2);  // nt
-                    else r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 0);
-                    b[u] = __builtin_bit_cast(vec<T, V>, r);
-                } else {
-                    b[u] = *reinterpret_cast<const vec<T, V>*>(B + (int64_t)nz[u].c * b_rs + jcc);
-                }
-            }
-        };
-#pragma unroll
-        for (int u = 0; u < U; ++u) fetch(u, gs + u);
-        for (int p = gs; p < gs + L; p += U) {  // same trip count in every group
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int pp = p + u;
-                if (pp < ge) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v) acc[v] = vt<T>::fma(nz[u].v, b[u].v[v], acc[v]);
-                    if (pp + 1 == row_end) {  // row k ends inside this piece
-                        if (started_before) {
-#pragma unroll
-                            for (int v = 0; v < V; ++v) head[v] = acc[v];
-                            head_row = k;
-                        } else if (col_ok) {
-                            emit(k, acc, jc);
-                        }
-#pragma unroll
-                        for (int v = 0; v < V; ++v) acc[v] = vt<T>::zero();
-                        started_before = false;
-                        do { ++k; } while (k < nproc && s_end[k] == pp + 1);  // skip the empty rows that follow
-                        row_end = (k < nproc) ? s_end[k] : 0x7fffffff;
-                    }
-                }
-                fetch(u, pp + U);
-            }
-        }
-        const int tail_row = (has_piece && k < nproc && row_end != 0x7fffffff && (k ? s_end[k - 1] : 0) < ge && row_end > ge) ? k : -1;
-        // ---- rows that cross piece boundaries: partials through LDS (the staged nonzeros are no longer needed) ----
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        T* s_tail = reinterpret_cast<T*>(base);                        // [NG][LPN * V]
-        int32_t* s_trow = reinterpret_cast<int32_t*>(s_tail + NG * LPN * V);  // [NG]
-        {
-            vec<T, V> t;
-#pragma unroll
-            for (int v = 0; v < V; ++v) t.v[v] = acc[v];
-            *reinterpret_cast<vec<T, V>*>(s_tail + (g * LPN + li) * V) = t;
-            if (li == 0) s_trow[g] = tail_row;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (head_row >= 0) {
-            T sum[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) sum[v] = vt<T>::zero();
-            for (int gg = 0; gg < g; ++gg) {  // earlier pieces of the same row, in piece order
-                if (s_trow[gg] == head_row) {
-                    const vec<T, V> t = *reinterpret_cast<const vec<T, V>*>(s_tail + (gg * LPN + li) * V);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], t.v[v]);
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], head[v]);
-            if (col_ok) emit(head_row, sum, jc);
-        }
-        if (j0 + (int64_t)LPN * V < jhi) {  // another column tile follows: the staged nonzeros must come back
-            // (only when the slice is wider than LPN * V values, which the dispatcher avoids)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int kk = lane; kk < len; kk += WAVE) {
-                const T a = val[P0 + kk];
-                SpEntry<T> en;
-                en.c = col[P0 + kk];
-                en.v = conj_a ? vt<T>::conj(a) : a;
-                s_nz[kk] = en;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // SpMV (N = 1): y := alpha * A x + beta * y  -- the lanes span NONZEROS instead of dense columns.
-// Same work partition, ownership rules and carry / fix-up machinery as k_spmm.  A wave multiplies
-// its chunk's nonzeros by the gathered x entries with fully coalesced (col, val) loads, parks the
-// products in LDS and reduces them per row: rows of up to 32 products by one lane each (most rows
-// of a sparse matrix), longer segments cooperatively with a shuffle reduction.  Traffic is A once
-// (8-12 B per nonzero) plus the x gather, which stays in L2 for vectors of a few MB.
+// Same work partition, ownership rules and carry / fix-up machinery as k_spmm.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T shfl_down_val(T v, int d)
-{
-    return __shfl_xor(v, d);  // butterfly: every lane ends with the full sum
-}
-template <typename R>
-__device__ __forceinline__ cx<R> shfl_down_val(cx<R> v, int d)
-{
-    return cx<R>{__shfl_xor(v.re, d), __shfl_xor(v.im, d)};
-}
-
-#ifndef MI_SPMV_U
-#define MI_SPMV_U 4
-#endif
-constexpr int SPMV_U = MI_SPMV_U;  // nonzeros per lane in flight (k_spmv)
+constexpr int SPMV_U = 4;  // nonzeros per lane in flight (k_spmv)
 
 template <typename T>
 __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
@@ -700,7 +459,7 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
         T sum = vt<T>::zero();
         for (int p = begin + lane; p < end; p += WAVE) sum = vt<T>::add(sum, s_prod[p]);
 #pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) sum = vt<T>::add(sum, shfl_down_val(sum, d));
+        for (int d = 1; d < WAVE; d <<= 1) sum = vt<T>::add(sum, shfl_xor_val(sum, d));
         if (lane == 0) {
             if (k < n_owned) {
                 T* yy = y + (r0 + k) * y_s;
@@ -1036,7 +795,7 @@ static void plan_after_product(mi_sparse_matrix* h, bool transposed, const Csr& 
 template <typename T, int V, int LPN, int U>
 static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
                           int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
-                          bool use_tags, int slices)
+                          int tag_mode, int slices)
 {
     Context& c = ctx();
     const size_t per_wave = (spmm_wave_lds<T>(p.chunk) + 15) & ~size_t(15);
@@ -1044,58 +803,48 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
     unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
     if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
-    if constexpr (V * sizeof(T) == 16 && LPN <= 16 && U == 4) {
-        // narrow (slices of) rows: the flat kernel (row-major operands only: the vector path guarantees b_cs == c_cs == 1)
-        if (options().spmm_flat && b_cs == 1 && c_cs == 1) {
-            if (use_tags)
-                MI_LAUNCH_SMEM((k_spmm_flat<T, V, LPN, true>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows,
-                               m.nnz, (const int64_t*)m.ptr, (const int32_t*)p.col_tagged.as<int32_t>(), (const T*)m.val,
-                               (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, C, c_rs, N,
-                               alpha, beta, beta_zero, carry_val, slices);
-            else
-                MI_LAUNCH_SMEM((k_spmm_flat<T, V, LPN, false>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows,
-                               m.nnz, (const int64_t*)m.ptr, (const int32_t*)m.col, (const T*)m.val,
-                               (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, C, c_rs, N,
-                               alpha, beta, beta_zero, carry_val, slices);
-            return;
-        }
-    }
+    const int stream_nt = options().spmm_stream_nt != 0 ? 1 : 0;
+#define MI_SPMM_LAUNCH(TAGMODE, COLS)                                                                                  \
+    MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz, \
+                   (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,                                      \
+                   (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,      \
+                   c_cs, N, alpha, beta, beta_zero, carry_val, slices, stream_nt, m.cols)
     if constexpr (V * sizeof(T) == 16) {
-        if (use_tags) {
-            MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, true>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows,
-                           m.nnz, (const int64_t*)m.ptr, (const int32_t*)p.col_tagged.as<int32_t>(), (const T*)m.val,
-                           (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C,
-                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_val, slices);
+        if (tag_mode == SPMM_TAG_BUFFER) {
+            MI_SPMM_LAUNCH(SPMM_TAG_BUFFER, p.col_tagged.as<int32_t>());
+            return;
+        }
+        if (tag_mode == SPMM_TAG_STRUCT) {
+            MI_SPMM_LAUNCH(SPMM_TAG_STRUCT, p.col_tagged.as<int32_t>());
             return;
         }
     }
-    MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, false>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz,
-                   (const int64_t*)m.ptr, (const int32_t*)m.col, (const T*)m.val,
-                   (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,
-                   c_cs, N, alpha, beta, beta_zero, carry_val, slices);
+    MI_SPMM_LAUNCH(SPMM_TAG_NONE, m.col);
+#undef MI_SPMM_LAUNCH
 }
 
 template <typename T, int V, int LPN>
 static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
                         int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
-                        bool use_tags, int slices)
+                        int tag_mode, int slices)
 {
     // U = independent 16-byte loads in flight per lane.  The deeper variant exists for the 512-byte
     // row shapes of the headline configs only (keeps the instantiation count down).
     if constexpr (V > 1 && LPN >= 32) {
         if (options().spmm_unroll == 8) {
             launch_spmm_u<T, V, LPN, 8>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val,
-                                        use_tags, slices);
+                                        tag_mode, slices);
             return;
         }
     }
-    launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, use_tags,
+    launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, tag_mode,
                                 slices);
 }
 
+// every byte offset (row * ld + column) * elem of the operand, plus the 16 bytes one load covers, fits 32 bits
 static inline bool dense_bytes_below_4g(int64_t rows, int64_t ld, size_t elem)
 {
-    return (double)rows * (double)ld * (double)elem < 4294967296.0 * 0.99;
+    return (double)rows * (double)ld * (double)elem + 16.0 < 4294967295.0;
 }
 
 // Core executor on DEVICE pointers.  m is the CSR of op(A) (rows of m = rows of C).
@@ -1169,13 +918,19 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         plan_after_product(h, transposed, m, hot_rows);
         return;
     }
-    // tagged (hot / cold) gather: needs 32-bit byte offsets into B
-    const bool use_tags = p.tagged && vec_ok && dense_bytes_below_4g(m.cols, ldb, sizeof(T));
-    counters().spmm_last_tagged = use_tags ? 1.0 : 0.0;
+    // tagged (hot / cold) gather: raw buffer loads while 32-bit byte offsets reach all of B, structured ones beyond
+    // (row stride below 16 KiB); wider rows of a > 4 GiB operand gather untagged
+    const bool raw_ok = dense_bytes_below_4g(m.cols, ldb, sizeof(T));
+    const bool struct_ok = ldb * (int64_t)sizeof(T) <= 16383 && m.cols <= 0x7fffffff;
+    const int tag_mode = !(p.tagged && vec_ok)                              ? SPMM_TAG_NONE
+                         : (raw_ok && !(options().spmm_tag_struct && struct_ok)) ? SPMM_TAG_BUFFER
+                         : struct_ok                                         ? SPMM_TAG_STRUCT
+                                                                             : SPMM_TAG_NONE;
+    counters().spmm_last_tagged = (double)tag_mode;
     counters().spmm_hot_coverage = p.hot_coverage;
     if (!vec_ok) slices = 1;
     counters().spmm_last_slices = (double)slices;
-#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, use_tags, slices
+#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, tag_mode, slices
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool prof = options().profile_events != 0;
     if (prof) {

@@ -267,3 +267,98 @@ def test_config5_shape_single_gpu(gpu):
         gpu.mi_set_stream(0)
         gpu.mi_set_option("pool_trim", 1)
         torch.cuda.empty_cache()
+
+
+def _hub_csr(torch, dev, rows, cols, per_row, hubs, seed):
+    """Skewed CSR on the device: half of every row's entries fall on `hubs` hub columns spread over the WHOLE column
+    range (so that hot and cold rows of the dense operand both lie beyond any 2 GiB / 4 GiB boundary), the rest are
+    uniform.  De-duplicated, sorted; int32 indptr / indices, fp32 values U[0.5, 1.5)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    hub_cols = (torch.arange(hubs, device=dev, dtype=torch.int64) * (cols // hubs) + (cols // hubs) // 2)
+    r = torch.arange(rows, device=dev, dtype=torch.int64).repeat_interleave(per_row)
+    pick = torch.randint(0, hubs, (rows * per_row,), generator=g, device=dev)
+    uni = torch.randint(0, cols, (rows * per_row,), generator=g, device=dev)
+    is_hub = torch.rand(rows * per_row, generator=g, device=dev) < 0.5
+    c = torch.where(is_hub, hub_cols[pick], uni)
+    key = torch.unique(r * cols + c)
+    rr = key // cols
+    indices = (key % cols).to(torch.int32)
+    indptr = torch.zeros(rows + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(torch.bincount(rr, minlength=rows), 0)
+    vals = torch.rand(indices.numel(), generator=g, device=dev, dtype=torch.float32) + 0.5
+    return indptr.to(torch.int32), indices, vals
+
+
+@pytest.mark.parametrize("k_cols,n_dense,want_mode", [
+    (1 << 22, 128, 1),        # B = exactly 2 GiB: raw buffer loads, 32-bit offsets up to 2^31
+    (3 << 20, 256, 1),        # B = 3 GiB: offsets in [2^31, 2^32) -- zeros came back here with num_records = 0x7fffffff
+    (5 << 20, 256, 2),        # B = 5 GiB: beyond 32-bit offsets -> structured buffer loads
+])
+def test_spmm_tagged_gather_large_dense_operand(gpu, k_cols, n_dense, want_mode):
+    """The hot / cold TAGGED gather (third call onward on a skewed matrix) addresses B through a buffer resource whose
+    range check returns ZERO for out-of-range offsets.  Dense operands of 2-4 GiB (32-bit offsets beyond 2^31) and
+    beyond 4 GiB (structured loads) must give, bit for bit, the untagged result, and a row sample that references
+    columns in the upper half of B must equal an fp64 evaluation."""
+    torch = pytest.importorskip("torch")
+    MI, matrix_descr, sparse_matrix_t, check = _abi()
+    dev = torch.device("cuda", 0)
+    gpu.mi_set_option("pool_trim", 1)
+    torch.cuda.empty_cache()
+    rows = 1 << 18
+    indptr, indices, vals = _hub_csr(torch, dev, rows, k_cols, 32, 4096, 5)
+    nnz = indices.numel()
+    assert nnz >= 1 << 23  # large enough for the sampled analysis to run
+    gpu.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+    h = sparse_matrix_t()
+    try:
+        check(MI.call("mi_sparse_s_create_csr", ct.byref(h), 0, rows, k_cols, indptr.data_ptr(), indptr.data_ptr() + 4,
+                      indices.data_ptr(), vals.data_ptr()), "create")
+        g = torch.Generator(device=dev)
+        g.manual_seed(2)
+        B = torch.rand((k_cols, n_dense), generator=g, device=dev) + 0.5
+        assert B.numel() * 4 == k_cols * n_dense * 4 >= 1 << 31
+        C = torch.empty((rows, n_dense), device=dev)
+
+        def mm(c):
+            check(MI.call("mi_sparse_s_mm", 10, 1.0, h, matrix_descr(), 101, B.data_ptr(), n_dense, n_dense, 0.0,
+                          c.data_ptr(), n_dense), "mm")
+        for _ in range(4):  # tags are analysed behind call 2 and adopted by the next call that finds them landed
+            mm(C)
+            torch.cuda.synchronize()
+        assert gpu.mi_get_counter("spmm_last_tagged") == float(want_mode)
+        assert 0.3 < gpu.mi_get_counter("spmm_hot_coverage") < 0.8
+        # (1) bit-identical to the untagged gather
+        C0 = torch.empty_like(C)
+        gpu.mi_set_option("spmm_hot_kb", 0)
+        try:
+            mm(C0)
+            torch.cuda.synchronize()
+            assert gpu.mi_get_counter("spmm_last_tagged") == 0.0
+        finally:
+            gpu.mi_set_option("spmm_hot_kb", 8192)
+        assert torch.equal(C, C0)
+        # (2) sampled rows against fp64, every one of them referencing columns in the upper half of B
+        ip = indptr.to(torch.int64)
+        sel = torch.randint(0, rows, (48,), device=dev).tolist() + [0, rows - 1]
+        upper = 0
+        for r in sel:
+            lo, hi = int(ip[r]), int(ip[r + 1])
+            if hi == lo:
+                assert float(C[r].abs().max()) == 0.0
+                continue
+            cols = indices[lo:hi].long()
+            upper += int((cols >= k_cols // 2).sum())
+            want = (vals[lo:hi].double()[:, None] * B[cols].double()).sum(0)
+            assert ((C[r].double() - want).abs() / want.abs()).max().item() <= F32_TOL, r
+        assert upper >= 100
+        # (3) no silent zeros anywhere: every non-empty row of a positive product is positive in every column
+        lens = ip[1:] - ip[:-1]
+        assert bool((C[lens > 0] > 0).all())
+    finally:
+        if h:
+            MI.call("mi_sparse_destroy", h)
+        gpu.mi_set_stream(0)
+        gpu.mi_set_option("pool_trim", 1)
+        B = C = C0 = None
+        torch.cuda.empty_cache()

@@ -293,14 +293,26 @@ inline bool __hip_atomic_compare_exchange_strong(T* p, T* expected, T desired, i
 inline float __hip_atomic_fetch_add(float* p, float x, int, int) { return emu_atomic_fadd(p, x); }
 inline double __hip_atomic_fetch_add(double* p, double x, int, int) { return emu_atomic_fadd(p, x); }
 
-// buffer resource + raw 16-byte buffer load (the cache-policy immediate `aux` has no host meaning)
-struct __amdgpu_buffer_rsrc_t { const char* base; };
+// buffer resource + 16-byte buffer loads (the cache-policy immediate `aux` has no host meaning).  The RANGE CHECK is
+// emulated: an out-of-range access returns zeros, as the hardware does -- a resource built too small shows up here.
+struct __amdgpu_buffer_rsrc_t { const char* base; unsigned stride; unsigned num_records; };
 typedef unsigned mi_u32x4 __attribute__((vector_size(16)));
-inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return __amdgpu_buffer_rsrc_t{(const char*)p}; }
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short stride, int num_records, int)
+{
+    return __amdgpu_buffer_rsrc_t{(const char*)p, (unsigned)(unsigned short)stride & 0x3fffu, (unsigned)num_records};
+}
 inline mi_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int)
 {
-    mi_u32x4 v;
+    mi_u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned long long)voff + 16ull > (unsigned long long)r.num_records) return v;  // raw buffer: records are bytes
     std::memcpy(&v, r.base + voff + soff, 16);
+    return v;
+}
+inline mi_u32x4 mi_struct_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int vindex, int voffset, int soff, int)
+{
+    mi_u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned)vindex >= r.num_records || (unsigned)voffset + 16u > r.stride) return v;  // structured: records are rows
+    std::memcpy(&v, r.base + (unsigned long long)(unsigned)vindex * r.stride + (unsigned)voffset + (unsigned)soff, 16);
     return v;
 }
 

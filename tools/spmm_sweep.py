@@ -3,7 +3,7 @@
 
     python tools/spmm_sweep.py [--workload rmat|uniform] [--launches K] [--variants "S:hot_kb:chunk,..."]
 
-Every variant = (spmm_slices, spmm_hot_kb, spmm_chunk[, spmm_flat]).  For each one the plan is rebuilt (untimed), the
+Every variant = spmm_slices:spmm_hot_kb:spmm_chunk[:option=value ...] (any mi_set_option knob, e.g. spmm_stream_nt=1).  For each one the plan is rebuilt (untimed), the
 product is checked against the first variant's result, and K launches are timed with the hipEvents the
 library records around the main kernel (profile_events).  Under `rocprofv3 --kernel-trace --pmc ...` the same
 script gives per-dispatch counters: the k_spmm dispatches appear in the order printed here, K + 1 per
@@ -50,7 +50,7 @@ def main():
     C = torch.empty((n, N), device=dev, dtype=tdt)
     nnz = int(indices.numel())
     if args.variants:
-        variants = [tuple(int(x) for x in v.split(":")) for v in args.variants.split(",")]
+        variants = [tuple(int(x) if "=" not in x else x for x in v.split(":")) for v in args.variants.split(",")]
     else:
         variants = [(s, h, 256) for s in (1, 2, 4, 8) for h in (0, 2048, 3072, 4096, 8192)]
     alg = nnz * (4 + vals.element_size()) + (n + 1) * 8 + 2 * n * N * vals.element_size()
@@ -59,8 +59,9 @@ def main():
                       "launches_per_variant": args.launches + 1, "algorithmic_bytes": alg}), flush=True)
     for var in variants:
         s, hot, chunk = var[:3]
-        flat = var[3] if len(var) > 3 else 0
-        sda.mi_set_option("spmm_flat", flat)
+        extra = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in var[3:])
+        for name, value in extra.items():
+            sda.mi_set_option(name, value)
         sda.mi_set_option("spmm_slices", s)
         sda.mi_set_option("spmm_hot_kb", hot)
         sda.mi_set_option("spmm_chunk", chunk)
@@ -91,12 +92,14 @@ def main():
         torch.cuda.synchronize()
         k_ms = sda.mi_get_counter("spmm_kernel_ms") / max(1.0, sda.mi_get_counter("spmm_kernel_launches"))
         sda.mi_set_option("profile_events", 0)
-        print(json.dumps({"slices": s, "hot_kb": hot, "chunk": chunk, "flat": flat, "kernel_ms": round(k_ms, 4),
+        print(json.dumps({"slices": s, "hot_kb": hot, "chunk": chunk, "extra": extra, "kernel_ms": round(k_ms, 4),
                           "step_ms_with_event_sync": round(e0.elapsed_time(e1) / args.launches, 4),
-                          "tagged": bool(sda.mi_get_counter("spmm_last_tagged")),
+                          "tagged": int(sda.mi_get_counter("spmm_last_tagged")),
                           "hot_coverage": round(sda.mi_get_counter("spmm_hot_coverage"), 4),
                           "alg_GBps": round(alg / k_ms / 1e6, 1), "max_rel_diff_vs_first": err}), flush=True)
         MI.call("mi_sparse_destroy", h)
+        for name in extra:
+            sda.mi_set_option(name, 0)
 
 
 if __name__ == "__main__":
