@@ -153,6 +153,40 @@ def spmm(a, b, alpha=1.0, beta=0.0, c=None, op=OP_N):
     return out
 
 
+def spmv(a, x, alpha=1.0, beta=0.0, y=None, op=OP_N):
+    """alpha * op(a) @ x + beta * y for a 1-D x through the oracle's own `csr_mv` entry point
+    (restates mkl_sparse_?_mv, reference _sparse_vector.py:87-95).  Returns a new 1-D array."""
+    a = _as_csr(a)
+    dt = _np.dtype(a.dtype)
+    x = _np.ascontiguousarray(_np.asarray(x).ravel())
+    assert x.dtype == dt, (x.dtype, dt)
+    m, k = a.shape
+    n_out = m if op == OP_N else k
+    assert x.size == (k if op == OP_N else m)
+    out = _np.zeros(n_out, dtype=dt)
+    rs, re, col, val = _csr_parts(a)
+    f = _fn("csr_mv", dt)
+    f.restype = _ct.c_int
+    if _is_complex(dt):
+        cplx = _C8 if dt == _np.complex64 else _C16
+        f.argtypes = [_ct.c_int, cplx, _ct.c_int64, _ct.c_int64] + [_ct.c_void_p] * 5 + [cplx, _ct.c_void_p]
+        st = f(op, cplx(1.0, 0.0), m, k, _p(rs), _p(re), _p(col), _p(val), _p(x), cplx(0.0, 0.0), _p(out))
+        if st:
+            raise ValueError("oracle csr_mv returned %d" % st)
+        out *= dt.type(alpha)
+        if y is not None and beta != 0:
+            out += dt.type(beta) * _np.asarray(y).ravel()
+        return out
+    ct = _ct.c_float if dt == _np.float32 else _ct.c_double
+    f.argtypes = [_ct.c_int, ct, _ct.c_int64, _ct.c_int64] + [_ct.c_void_p] * 5 + [ct, _ct.c_void_p]
+    if y is not None and beta != 0:
+        out[...] = _np.asarray(y).ravel()
+    st = f(op, alpha, m, k, _p(rs), _p(re), _p(col), _p(val), _p(x), beta if y is not None else 0.0, _p(out))
+    if st:
+        raise ValueError("oracle csr_mv returned %d" % st)
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # SpGEMM
 # --------------------------------------------------------------------------------------------
@@ -394,6 +428,11 @@ def dot_product(a, b, cast=False, reorder_output=False, dense=False, out=None, o
     beta = 1.0 if out_scalar is None else out_scalar
     empty = min(*a.shape, *b.shape) == 0 or (sa and a.nnz == 0 and a.data.size == 0) or (
         sb and b.nnz == 0 and b.data.size == 0)
+    if (sa != sb) and empty and (a.ndim == 1 or b.ndim == 1):  # vector product of an empty operand: zeros of the vector's shape convention
+        if out is not None:
+            return out
+        dt0 = _np.float32 if (a.dtype == b.dtype and a.dtype == _np.float32) else _np.float64
+        return _np.zeros((b.shape[1],) if a.ndim == 1 else (a.shape[0],), dtype=dt0)
     if sa and sb:
         if empty:
             if dense:
@@ -415,7 +454,15 @@ def dot_product(a, b, cast=False, reorder_output=False, dense=False, out=None, o
         dt = _np.float32 if (a.dtype == b.dtype and a.dtype == _np.float32) else _np.float64
         return _np.zeros((a.shape[0], b.shape[1]), dtype=dt)
     dt = _common_dtype(a, b, cast)
-    if sa:
+    # sparse x dense VECTOR (reference sparse_dot.py:96-121 -> _sparse_vector.py:105-174): the result takes the
+    # vector's shape convention -- (n,) for a 1-D vector, (n, 1) for a column on the right, (1, n) for a row on the left
+    if sb and not sa and (a.ndim == 1 or (a.ndim == 2 and a.shape[0] == 1)):
+        r = spmv(b.astype(dt), _np.asarray(a).astype(dt, copy=False), 1.0, beta, out, OP_T)
+        r = r if a.ndim == 1 else r.reshape(1, -1)
+    elif sa and not sb and (b.ndim == 1 or (b.ndim == 2 and b.shape[1] == 1)):
+        r = spmv(a.astype(dt), _np.asarray(b).astype(dt, copy=False), 1.0, beta, out, OP_N)
+        r = r if b.ndim == 1 else r.reshape(-1, 1)
+    elif sa:
         bb = _np.asarray(b).astype(dt, copy=False)
         r = spmm(a.astype(dt), bb, 1.0, beta, out, OP_N)
     elif sb:

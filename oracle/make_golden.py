@@ -28,7 +28,9 @@ import scipy.sparse as sps
 
 import sparse_dot_mkl as ref  # the reference (PYTHONPATH=/root/reference)
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "golden_v1.npz")
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.path.join(GOLDEN_DIR, "golden_v1.npz")
+OUT_SPMV = os.path.join(GOLDEN_DIR, "golden_spmv_v1.npz")  # `make_golden.py --spmv`: the sparse x vector cases (round 3)
 
 ARR = {}
 CASES = []
@@ -101,8 +103,8 @@ def add(name, fn, a, b=None, out=None, raises=None, **kwargs):
     entry["b"] = put(name + "/b", b)
     call_kwargs = dict(kwargs)
     if out is not None:
-        fill, order, dtype = out
-        shape = out_shape(fn, a, b, kwargs)
+        fill, order, dtype = out[:3]
+        shape = tuple(out[3]) if len(out) > 3 else out_shape(fn, a, b, kwargs)
         call_kwargs["out"] = np.full(shape, fill, dtype=dtype, order=order)
         entry["out"] = {"fill": fill, "order": order, "dtype": np.dtype(dtype).name, "shape": list(shape)}
     # the reference may mutate index dtypes / ordering of its inputs in place: hand it copies
@@ -264,14 +266,62 @@ def main():
                     np.asarray(d2.astype(dt), order=ob))
         add(f"gemm/{tag}/out", "dot", d1.astype(dt), d2.astype(dt), out=(1.0, "C", dt), out_scalar=3.0)
 
+    write(OUT)
+
+
+def write(path):
     manifest = json.dumps({"version": 1, "cases": CASES, "generator": "oracle/make_golden.py",
                            "reference": "sparse_dot_mkl " + ref.__version__,
                            "mkl": ref.mkl_get_version_string(),
                            "numpy": np.__version__, "scipy": __import__("scipy").__version__})
     ARR["__manifest__"] = np.frombuffer(manifest.encode("utf-8"), dtype=np.uint8)
-    np.savez_compressed(OUT, **ARR)
-    print("wrote", os.path.abspath(OUT), "cases:", len(CASES), "bytes:", os.path.getsize(OUT))
+    np.savez_compressed(path, **ARR)
+    print("wrote", os.path.abspath(path), "cases:", len(CASES), "bytes:", os.path.getsize(path))
+
+
+def main_spmv():
+    """Sparse x dense VECTOR (reference _sparse_vector.py:28-174 -> mkl_sparse_?_mv; dispatcher sparse_dot.py:96-121):
+    1-D vs (n, 1) vs (1, n) vectors, vector on the left (op = T), out / out_scalar, CSR / CSC / BSR, s / d / c / z."""
+    SEED = 86
+    m1 = sps.random(60, 90, density=0.08, format="csr", dtype=np.float64, random_state=SEED)
+    rng = np.random.default_rng(11)
+    mc = (m1 + 1j * sps.random(60, 90, density=0.08, format="csr", dtype=np.float64, random_state=SEED + 7)).tocsr()
+    for dt in (np.float32, np.float64, np.complex64, np.complex128):
+        tag = np.dtype(dt).name
+        cplx = np.dtype(dt).kind == "c"
+        base = (mc if cplx else m1).astype(dt)
+        vr = rng.random(90) + (1j * rng.random(90) if cplx else 0)   # right-hand vector, len = columns
+        vl = rng.random(60) + (1j * rng.random(60) if cplx else 0)   # left-hand vector, len = rows
+        vr, vl = vr.astype(dt), vl.astype(dt)
+        for fmt in ("csr", "csc", "bsr"):
+            a = base.asformat(fmt) if fmt != "bsr" else base.tobsr(blocksize=(10, 10))
+            add(f"spmv/{tag}/{fmt}/right_1d", "dot", a, vr.copy())
+            add(f"spmv/{tag}/{fmt}/right_col", "dot", a, vr.reshape(-1, 1).copy())
+            add(f"spmv/{tag}/{fmt}/left_1d", "dot", vl.copy(), a)
+            add(f"spmv/{tag}/{fmt}/left_row", "dot", vl.reshape(1, -1).copy(), a)
+            if fmt != "bsr":
+                add(f"spmv/{tag}/{fmt}/right_1d_out", "dot", a, vr.copy(), out=(1.0, "C", dt, (60,)), out_scalar=3.0)
+                add(f"spmv/{tag}/{fmt}/right_col_out", "dot", a, vr.reshape(-1, 1).copy(), out=(1.0, "C", dt, (60, 1)),
+                    out_scalar=3.0)
+                add(f"spmv/{tag}/{fmt}/left_1d_out", "dot", vl.copy(), a, out=(2.0, "C", dt, (90,)), out_scalar=-0.5)
+                add(f"spmv/{tag}/{fmt}/left_row_out", "dot", vl.reshape(1, -1).copy(), a, out=(2.0, "C", dt, (1, 90)),
+                    out_scalar=-0.5)
+    v64 = rng.random(90)
+    add("spmv/cast/f32xf64", "dot", m1.astype(np.float32), v64.copy(), cast=True)
+    add("spmv/cast/f64xf32_left", "dot", rng.random(60).astype(np.float32), m1, cast=True)
+    add("spmv/nocast_raises", "dot", m1.astype(np.float32), v64.copy(), raises="ValueError")
+    add("spmv/misaligned_raises", "dot", m1, v64[:-1].copy(), raises="ValueError")
+    add("spmv/array_cls", "dot", sps.csr_array(m1), v64.copy())
+    add("spmv/empty_sparse", "dot", sps.csr_matrix((60, 90), dtype=np.float64), v64.copy())
+    add("spmv/one_row", "dot", m1[0:1, :].tocsr(), v64.copy())
+    add("spmv/one_col", "dot", m1[:, 0:1].tocsr(), v64[:1].copy())
+    hub = sps.random(300, 2000, density=0.004, format="lil", dtype=np.float64, random_state=5)
+    hub[7, :] = rng.random(2000)          # one row holding every column (cut across chunks on the GPU)
+    hub = hub.tocsr()
+    add("spmv/hub_row", "dot", hub, rng.random(2000))
+    add("spmv/hub_row_left", "dot", rng.random(300), hub)
+    write(OUT_SPMV)
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main_spmv() if "--spmv" in sys.argv else main())

@@ -1,11 +1,14 @@
-"""Loader for tests/golden/golden_v1.npz (written by oracle/make_golden.py)."""
+"""Loader for the golden vectors written by oracle/make_golden.py: tests/golden/golden_v1.npz (rounds 1-2) and
+tests/golden/golden_spmv_v1.npz (`--spmv`, the sparse x vector cases added in round 3)."""
 import json
 import os
 
 import numpy as np
 import scipy.sparse as sps
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz")
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN = os.path.join(_DIR, "golden_v1.npz")
+GOLDEN_FILES = [GOLDEN, os.path.join(_DIR, "golden_spmv_v1.npz")]
 
 _CLS = {
     ("csr", "matrix"): sps.csr_matrix, ("csr", "array"): sps.csr_array,
@@ -18,9 +21,20 @@ _cache = {}
 
 def _load():
     if "z" not in _cache:
-        z = np.load(GOLDEN)
-        _cache["z"] = z
-        _cache["manifest"] = json.loads(bytes(z["__manifest__"]).decode("utf-8"))
+        arrays, merged = {}, None
+        for path in GOLDEN_FILES:
+            z = np.load(path)
+            m = json.loads(bytes(z["__manifest__"]).decode("utf-8"))
+            for k in z.files:
+                if k != "__manifest__":
+                    assert k not in arrays, k  # array keys carry the case name: unique across files
+                    arrays[k] = z[k]
+            if merged is None:
+                merged = m
+            else:
+                merged["cases"] = merged["cases"] + m["cases"]
+        _cache["z"] = arrays
+        _cache["manifest"] = merged
     return _cache["z"], _cache["manifest"]
 
 
