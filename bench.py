@@ -32,7 +32,11 @@ north_star's pipeline end to end -- RCCL broadcast of B from rank 0, the local k
 writing straight into this rank's slice of C, all-gatherv of the output row blocks -- everything device
 resident.  `value` is computed from that step (total work is fixed: "scaling": "strong"); `compute_only_ms`
 (the kernels alone, max over ranks) and the single collectives are reported beside it.  At N = 1 the step is
-the kernel alone, i.e. the single-GPU line.
+the kernel alone, i.e. the single-GPU line.  The same step is also timed in its xGMI-shaped forms (`variants`: grouped
+point-to-point all-gatherv + scatter / all-gather broadcast, and the column-panel pipeline that overlaps them with the
+kernel); `value` is the best form's, every form is listed.  With 8 ranks BASELINE configs[4] (2^24 x 2^24 x 256) runs as
+`secondary.spmm_config5_8gpu`.  A watchdog prints the contract line and exits if one of these never-before-run RCCL
+paths does not come back.
 """
 import argparse
 import ctypes as ct
@@ -422,6 +426,82 @@ def secondary_gram(torch, abi, dev, with_cpu):
     return out
 
 
+def secondary_config5(torch, dist, dev, abi, rank, world, allreduce_max, steps=3):
+    """BASELINE configs[4]: R-MAT CSR 2^24 x 2^24 (scale 24, 32 edges/row, ~5.2e8 nnz) x dense 2^24 x 256 fp32, the left matrix
+    row-partitioned over the 8 ranks (every rank generates the same matrix and keeps its nnz-balanced block), B broadcast
+    from rank 0, C all-gathered -- timed end to end like the headline step, plus the kernels alone."""
+    from sparse_dot_amd import distributed as D
+    scale, N = 24, 256
+    indptr, indices, vals, n = rmat_csr(torch, scale, 32, 7, dev)
+    nnz = int(indices.numel())
+    ip64 = indptr.to(torch.int64)
+    del indptr
+    bounds = D.partition_rows(ip64.cpu().numpy(), world)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    lo, hi = int(ip64[r0]), int(ip64[r1])
+    blk_ptr = (ip64[r0:r1 + 1] - lo).to(torch.int32).contiguous()
+    blk_idx, blk_val = indices[lo:hi].clone(), vals[lo:hi].clone()
+    sample = []
+    if rank == 0:  # rows of every block, checked against fp64 after the timed steps
+        g = torch.Generator(device="cpu")
+        g.manual_seed(3)
+        for r in torch.randint(0, n, (24,), generator=g).tolist() + [int(b) for b in bounds[:-1]]:
+            a, b = int(ip64[r]), int(ip64[r + 1])
+            sample.append((r, indices[a:b].clone(), vals[a:b].clone()))
+    del indices, vals, ip64
+    torch.cuda.empty_cache()
+    h = abi.create("s", blk_ptr, blk_idx, blk_val, r1 - r0, n)
+    gb = torch.Generator(device=dev)
+    gb.manual_seed(9)
+    B = torch.rand((n, N), generator=gb, device=dev, dtype=torch.float32) if rank == 0 else torch.zeros((n, N), device=dev)
+    C = torch.empty((n, N), device=dev, dtype=torch.float32)
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def compute():
+        if r1 > r0:
+            abi.mm("s", h, B, C[r0:r1], N)
+
+    def step():
+        D.broadcast_rows(B, 0, None, "scatter_allgather").wait()
+        compute()
+        D.gather_rows(C, bounds, None, "p2p")
+
+    def timed(fn, k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        barrier()
+        return (time.perf_counter() - t0) / k
+    step()
+    step()
+    t_e2e = allreduce_max(timed(step, steps))
+    compute()
+    t_cmp = allreduce_max(timed(compute, steps))
+    t_b = allreduce_max(timed(lambda: D.broadcast_rows(B, 0, None, "scatter_allgather").wait(), 2))
+    t_g = allreduce_max(timed(lambda: D.gather_rows(C, bounds, None, "p2p"), 2))
+    worst = 0.0
+    for r, cols, v in sample:
+        if cols.numel() == 0:
+            worst = max(worst, float(C[r].abs().max()))
+            continue
+        want = (v.double()[:, None] * B[cols.long()].double()).sum(0)
+        worst = max(worst, float(((C[r].double() - want).abs() / want.abs().clamp(min=1e-30)).max()))
+    assert worst < 1e-5, "configs[4] fails the fp32 parity bar: %g" % worst
+    abi.destroy(h)
+    return {"workload": "BASELINE configs[4]: R-MAT CSR %dx%d (%d nnz) x dense %dx%d fp32, %d nnz-balanced row blocks" % (n, n, nnz, n, N, world),
+            "value": round(2.0 * nnz * N / t_e2e / 1e9, 2), "unit": "GFLOP/s", "end_to_end_ms": round(t_e2e * 1e3, 3),
+            "compute_only_ms": round(t_cmp * 1e3, 3), "compute_only_value": round(2.0 * nnz * N / t_cmp / 1e9, 2),
+            "bcast_scatter_allgather_ms": round(t_b * 1e3, 3), "gather_p2p_ms": round(t_g * 1e3, 3),
+            "parity_max_rel_err_sample": worst, "block_rows_rank0": r1 - r0,
+            "note": "step = scatter + all-gather broadcast of B (17.2 GB) -> local kernel -> point-to-point all-gatherv of C "
+                    "(17.2 GB), max over ranks, %d steps; compute_only = the kernels alone" % steps}
+
+
 def host_api_figure(sda):
     """dot_product_mkl on HOST arrays (the reference's calling convention), one call each: handle created and
     destroyed inside, operands cross PCIe both ways."""
@@ -446,7 +526,7 @@ def host_api_figure(sda):
 # the north_star's partitioned SpMM (N >= 1 ranks); device agnostic so that the gloo test can drive it on CPU
 # ------------------------------------------------------------------------------------------------
 def run_partitioned(torch, dist, dev, indptr, indices, vals, n, B, steps, warmup, make_local, gather_mode="bcast",
-                    sync=None, group=None):
+                    sync=None, group=None, bcast_mode="bcast", variants=True, gather_group=None, panels=4):
     """Split (indptr, indices, vals) into world row blocks, keep this rank's block resident, and time
     (a) the local kernels alone and (b) the end-to-end step  bcast(B) -> kernel -> all-gatherv(C).
 
@@ -476,12 +556,15 @@ def run_partitioned(torch, dist, dev, indptr, indices, vals, n, B, steps, warmup
         if r1 > r0:
             mm(B, mine)
 
-    def step_end_to_end():
-        if dist and world > 1:
-            dist.broadcast(B, src=D._src_global(0, group), group=group)
-        step_compute()
-        if dist and world > 1:
-            D.gather_rows(C, bounds, group, gather_mode)
+    def make_step(bmode, gmode):
+        def step():
+            if dist and world > 1:
+                D.broadcast_rows(B, 0, group, bmode).wait()
+            step_compute()
+            if dist and world > 1:
+                D.gather_rows(C, bounds, group, gmode)
+        return step
+    step_end_to_end = make_step(bcast_mode, gather_mode)
 
     def timed_loop(fn, k):
         barrier()
@@ -498,12 +581,57 @@ def run_partitioned(torch, dist, dev, indptr, indices, vals, n, B, steps, warmup
         step_compute()
     t_cmp = timed_loop(step_compute, steps)
     res = {"bounds": bounds, "block_rows": r1 - r0, "block_nnz": hi - lo, "t_end_to_end": t_e2e, "t_compute": t_cmp, "C": C,
-           "free": free, "mm": mm}
+           "free": free, "mm": mm, "timed_loop": timed_loop, "make_step": make_step}
     if dist and world > 1:
-        res["t_bcast"] = timed_loop(lambda: dist.broadcast(B, src=D._src_global(0, group), group=group), max(2, steps // 4))
-        res["t_gather_bcast"] = timed_loop(lambda: D.gather_rows(C, bounds, group, "bcast"), max(2, steps // 4))
-        res["t_gather_padded"] = timed_loop(lambda: D.gather_rows(C, bounds, group, "padded"), max(2, steps // 4))
+        k4 = max(2, steps // 4)
+        res["t_bcast"] = timed_loop(lambda: D.broadcast_rows(B, 0, group, "bcast").wait(), k4)
+        res["t_gather_bcast"] = timed_loop(lambda: D.gather_rows(C, bounds, group, "bcast"), k4)
+        res["t_gather_padded"] = timed_loop(lambda: D.gather_rows(C, bounds, group, "padded"), k4)
     return res
+
+
+def run_variants(torch, dist, dev, res, n, B, steps, warmup, group=None, gather_group=None, panels=4, check=None):
+    """The xGMI-shaped forms of the same step (sparse_dot_amd/distributed.py), each timed like the contract's loop
+    (barrier + synchronise on both sides of exactly `steps` steps):
+      p2p        scatter + all-gather broadcast of B, kernel, all-gatherv of C as one grouped send / receive batch
+      pipelined  B and C held as `panels` column panels: broadcast(p + 2) | kernel(p) | all-gatherv(p - 1) overlap
+    Returns {name: seconds per step} plus the single collectives; every variant's C is checked by `check`."""
+    from sparse_dot_amd import distributed as D
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    bounds, C, mm, timed_loop = res["bounds"], res["C"], res["mm"], res["timed_loop"]
+    out = {}
+    k4 = max(2, steps // 4)
+    if rank != 0:
+        B.zero_()  # only the root holds B: the checks below then also prove the broadcasts
+    out["t_bcast_scatter_allgather"] = timed_loop(lambda: D.broadcast_rows(B, 0, group, "scatter_allgather").wait(), k4)
+    out["t_gather_p2p"] = timed_loop(lambda: D.gather_rows(C, bounds, group, "p2p"), k4)
+    step = res["make_step"]("scatter_allgather", "p2p")
+    C.zero_()
+    for _ in range(max(1, warmup)):
+        step()
+    out["p2p"] = timed_loop(step, steps)
+    if check:
+        check(C, "p2p")
+    N = B.shape[1]
+    P = panels if (N % panels == 0 and (N // panels) % 4 == 0) else 1
+    if P > 1:
+        w = N // P
+        Bp = B.view(n, P, w).permute(1, 0, 2).contiguous()  # panel-major copy of B (valid on rank 0, zeros elsewhere)
+        Cp = torch.zeros((P, n, w), dtype=B.dtype, device=dev)
+        if rank != 0:
+            Bp.zero_()
+
+        def pstep():
+            D.pipelined_panels(mm, Bp, Cp, bounds, rank, src=0, group=group, bcast_mode="scatter_allgather",
+                               gather_mode="p2p", gather_group=gather_group, depth=2)
+        for _ in range(max(1, warmup)):
+            pstep()
+        out["pipelined"] = timed_loop(pstep, steps)
+        out["pipelined_panels"] = P
+        if check:
+            check(Cp.permute(1, 0, 2).reshape(n, N), "pipelined")
+        del Bp, Cp
+    return out
 
 
 def main():
@@ -517,7 +645,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--secondary", default="all", help="comma list of: uniform,spgemm,spgemm_rmat,gram,host_api (default all)")
-    ap.add_argument("--gather-mode", default="bcast", choices=["bcast", "padded"])
+    ap.add_argument("--gather-mode", default="bcast", choices=["bcast", "padded", "p2p"])
+    ap.add_argument("--bcast-mode", default="bcast", choices=["bcast", "scatter_allgather"])
+    ap.add_argument("--no-variants", action="store_true", help="N > 1: skip the p2p / pipelined forms and configs[4]")
+    ap.add_argument("--panels", type=int, default=4, help="N > 1: column panels of the pipelined form")
+    ap.add_argument("--variant-timeout", type=int, default=240)
+    ap.add_argument("--config5-timeout", type=int, default=900)
     ap.add_argument("--chunk", type=int, default=0, help="override the SpMM work-item chunk (tuning)")
     ap.add_argument("--unroll", type=int, default=0, help="override the SpMM load unroll 4|8 (tuning)")
     ap.add_argument("--hot-kb", type=int, default=-1, help="override the hot-set budget in KiB, 0 = no tagging (tuning)")
@@ -606,6 +739,20 @@ def main():
             full.copy_(hfull)
             return full
         D.gather_rows = _gather_host
+        _orig_brows, _orig_p2p = D.broadcast_rows, D.gather_rows_p2p
+
+        def _brows_host(t, src=0, group=None, mode="scatter_allgather"):
+            hcopy = t.cpu()
+            _orig_brows(hcopy, src, group, mode).wait()
+            t.copy_(hcopy)
+            return D._Pending()
+
+        def _p2p_host(full, bounds, group=None):
+            hfull = full.cpu()
+            _orig_p2p(hfull, bounds, group).wait()
+            full.copy_(hfull)
+            return D._Pending()
+        D.broadcast_rows, D.gather_rows_p2p = _brows_host, _p2p_host
 
     # ---- first call on a fresh handle vs steady state (single GPU only: the inspector's visible cost) ----
     plan = None
@@ -638,7 +785,7 @@ def main():
                         "of the process (one-time arena / cache growth included)."}
 
     res = run_partitioned(torch, dist, dev, indptr, indices, vals, n, B, args.steps, args.warmup, make_local,
-                          gather_mode=args.gather_mode, sync=torch.cuda.synchronize)
+                          gather_mode=args.gather_mode, sync=torch.cuda.synchronize, bcast_mode=args.bcast_mode)
     C = res["C"]
 
     def allreduce_max(x):
@@ -723,10 +870,91 @@ def main():
             line["compute_only_value"] = round(2.0 * nnz * N / t_cmp / 1e9, 2)
             line["block_rows_rank0"] = blk_rows
 
+    # ---- N > 1: the xGMI-shaped forms of the same step, and BASELINE configs[4] on 8 ranks ----
+    # The contract line above is complete at this point.  The forms below drive RCCL paths that no build session could
+    # run (one GPU there): a watchdog prints the line as it stands and ends the process if they do not come back.
+    if dist and world > 1 and not args.no_variants:
+        import threading
+
+        def _bail():
+            if rank == 0:
+                line.setdefault("variants", {})["error"] = "timed out after %d s; the contract line is the basic form" % args.variant_timeout
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.variant_timeout, _bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            def check(Cx, name):
+                if rank != 0:
+                    return
+                sel = torch.randint(0, n, (32,), device=dev)
+                ip = indptr.to(torch.int64)
+                for r in sel.tolist():
+                    lo, hi = int(ip[r]), int(ip[r + 1])
+                    if hi == lo:
+                        continue
+                    want = (vals[lo:hi].double()[:, None] * Bref[indices[lo:hi].long()].double()).sum(0)
+                    err = float(((Cx[r].double() - want).abs() / want.abs().clamp(min=1e-30)).max())
+                    assert err < 1e-5, "variant %s fails the fp32 parity bar: %g" % (name, err)
+            Bref = B.clone() if rank == 0 else None
+            ggroup = dist.new_group(list(range(world))) if backend == "nccl" else None  # second communicator: the all-gathervs get their own stream
+            var = run_variants(torch, dist, dev, res, n, B, args.steps, args.warmup, gather_group=ggroup, panels=args.panels,
+                               check=check)
+            tv = {k: allreduce_max(v) for k, v in sorted(var.items()) if k != "pipelined_panels"}
+            if rank == 0:
+                forms = {"basic": t_step}
+                forms.update({k: tv[k] for k in ("p2p", "pipelined") if k in tv})
+                best = min(forms, key=forms.get)
+                line["variants"] = {
+                    "end_to_end_ms": {k: round(v * 1e3, 4) for k, v in forms.items()},
+                    "value_GFLOPs": {k: round(2.0 * nnz * N / v / 1e9, 2) for k, v in forms.items()},
+                    "best": best, "pipelined_panels": var.get("pipelined_panels"),
+                    "note": "basic = dist.broadcast(B) + kernel + all-gatherv [%s]; p2p = scatter + all-gather broadcast and "
+                            "all-gatherv as grouped point-to-point batches (all xGMI links of a GPU at once); pipelined = column "
+                            "panels, broadcast(p+2) | kernel(p) | all-gatherv(p-1) overlapped.  `value` is the best form's." % args.gather_mode}
+                line["collectives"].update({k: round(tv[k] * 1e3, 3) for k in ("t_bcast_scatter_allgather", "t_gather_p2p") if k in tv})
+                line["value"] = line["variants"]["value_GFLOPs"][best]
+                line["ms_per_step"] = line["end_to_end_ms"] = line["variants"]["end_to_end_ms"][best]
+        except AssertionError:
+            raise
+        except Exception as exc:  # noqa: BLE001 -- an experimental form must not cost the contract line
+            if rank == 0:
+                line.setdefault("variants", {})["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+        dog.cancel()
+
     # ---- release the primary workload before the secondaries (they need most of the HBM) ----
     res["free"]()
     del res, C
     handles.clear()
+    if dist and world == 8 and backend == "nccl" and not args.no_variants and not args.no_secondary and args.workload == "rmat":
+        import threading
+
+        def _bail5():
+            if rank == 0:
+                line.setdefault("secondary", {})["spmm_config5_8gpu"] = {"error": "timed out after %d s" % args.config5_timeout}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.config5_timeout, _bail5)
+        dog.daemon = True
+        dog.start()
+        try:
+            del B, indptr, indices, vals
+            torch.cuda.empty_cache()
+            entry = secondary_config5(torch, dist, dev, abi, rank, world, allreduce_max)
+            if rank == 0:
+                line.setdefault("secondary", {})["spmm_config5_8gpu"] = entry
+        except AssertionError:
+            raise
+        except Exception as exc:  # noqa: BLE001
+            if rank == 0:
+                line.setdefault("secondary", {})["spmm_config5_8gpu"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        dog.cancel()
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     want_sec = set(args.secondary.split(",")) if args.secondary != "all" else {"uniform", "spgemm", "spgemm_rmat", "gram", "host_api"}
     with_cpu = not args.no_cpu
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "rmat":

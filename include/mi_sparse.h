@@ -472,7 +472,7 @@ const char *mi_sparse_last_error(void);
 /* Tuning / diagnostic knob: name -> integer value; unknown names return INVALID_VALUE.  Used by
  * bench.py / tools to A/B kernel variants; defaults are the shipped choice.  Names:
  *   spmm_chunk, spmm_unroll, spmm_hot_kb, spmm_hot_force, spmm_force_generic,
- *   spmm_slices (XCD-affine column slices: 0 = by row width, 1 / 2 / 4 / 8), spmm_stream_nt, spmm_tag_struct, spmm_plan_sync
+ *   spmm_slices (XCD-affine column slices: 0 = by row width, 1 / 2 / 4 / 8), spmm_tag_struct, spmm_plan_sync
  *                                                                               (SpMM kernel variants)
  *   spgemm_lds_parts, spgemm_slice_table, spgemm_slice_table_max, spgemm_part_log2s_bias,
  *   spgemm_force_global, spgemm_global_mode                                     (SpGEMM big-row paths)

@@ -7,7 +7,12 @@ TEST / MEASUREMENT INFRASTRUCTURE -- never imported by the product package.  Thi
 own shim (the reference's Python does not travel to the GPU box); it binds the three symbols the
 reference's SpMM path uses (reference sparse_dot_mkl/_sparse_dense.py:111-123,
 _mkl_interface/_common.py:310-319, 671-680), plus mkl_sparse_spmm (_sparse_sparse.py:35-40),
-mkl_sparse_?_syrkd (_gram_matrix.py:149-157) and MKL_Set_Num_Threads.  LP64 (32-bit index) interface.
+mkl_sparse_?_syrkd (_gram_matrix.py:149-157), mkl_sparse_order / mkl_sparse_?_export_csr (_common.py:387-500, 683) and
+MKL_Set_Num_Threads.  LP64 (32-bit index) interface by default; `interface=1` selects ILP64
+(MKL_Set_Interface_Layer(1), reference _cfunctions.py:774-782).
+
+The same binding drives `sparse_dot_amd/libmi_mkl_rt.so` -- the MKL-named face of the build -- in
+tests/test_gpu_mkl_alias.py: a library that answers these calls like MKL does is a drop-in behind `$MKL_RT`.
 """
 import ctypes as _ct
 import ctypes.util as _ctu
@@ -41,16 +46,19 @@ def find_mkl():
 class MklSpmm:
     """C := A @ B with A CSR (int32 indices), B / C row-major, via mkl_sparse_?_mm."""
 
-    def __init__(self, path=None):
+    def __init__(self, path=None, interface=0):
         path = path or find_mkl()
         if path is None:
             raise OSError("libmkl_rt not found")
         self.path = path
         self.lib = _ct.CDLL(path)
+        self.interface = int(interface)
         try:
-            self.lib.MKL_Set_Interface_Layer(_ct.c_int(0))  # LP64
+            self.lib.MKL_Set_Interface_Layer(_ct.c_int(self.interface))  # 0 = LP64, 1 = ILP64
         except AttributeError:
             pass
+        self.idt = _np.int64 if self.interface else _np.int32       # MKL_INT as numpy dtype ...
+        self.cint = _ct.c_longlong if self.interface else _ct.c_int  # ... and as ctypes argument
         self.lib.MKL_Get_Max_Threads.restype = _ct.c_int
 
     def threads(self):
@@ -64,14 +72,14 @@ class MklSpmm:
     def make(self, a):
         dt = _np.dtype(a.dtype)
         letter = {"float32": "s", "float64": "d"}[dt.name]
-        indptr = _np.ascontiguousarray(a.indptr, dtype=_np.int32)
-        indices = _np.ascontiguousarray(a.indices, dtype=_np.int32)
+        indptr = _np.ascontiguousarray(a.indptr, dtype=self.idt)
+        indices = _np.ascontiguousarray(a.indices, dtype=self.idt)
         data = _np.ascontiguousarray(a.data)
         h = _ct.c_void_p()
         create = getattr(self.lib, "mkl_sparse_%s_create_csr" % letter)
         create.restype = _ct.c_int
-        st = create(_ct.byref(h), _ct.c_int(0), _ct.c_int(a.shape[0]), _ct.c_int(a.shape[1]),
-                    _ct.c_void_p(indptr.ctypes.data), _ct.c_void_p(indptr.ctypes.data + 4),
+        st = create(_ct.byref(h), _ct.c_int(0), self.cint(a.shape[0]), self.cint(a.shape[1]),
+                    _ct.c_void_p(indptr.ctypes.data), _ct.c_void_p(indptr.ctypes.data + indptr.itemsize),
                     _ct.c_void_p(indices.ctypes.data), _ct.c_void_p(data.ctypes.data))
         if st:
             raise RuntimeError("mkl_sparse_%s_create_csr returned %d" % (letter, st))
@@ -82,8 +90,8 @@ class MklSpmm:
         fn = getattr(self.lib, "mkl_sparse_%s_mm" % letter)
         ct = _ct.c_float if letter == "s" else _ct.c_double
         fn.restype = _ct.c_int
-        fn.argtypes = [_ct.c_int, ct, _ct.c_void_p, _Descr, _ct.c_int, _ct.c_void_p, _ct.c_int, _ct.c_int, ct,
-                       _ct.c_void_p, _ct.c_int]
+        fn.argtypes = [_ct.c_int, ct, _ct.c_void_p, _Descr, _ct.c_int, _ct.c_void_p, self.cint, self.cint, ct,
+                       _ct.c_void_p, self.cint]
         st = fn(10, 1.0, h, _Descr(20, 0, 0), 101, b.ctypes.data, b.shape[1], b.shape[1], 0.0, out.ctypes.data,
                 out.shape[1])
         if st:
@@ -97,6 +105,43 @@ class MklSpmm:
         """MKL_Set_Num_Threads (reference _mkl_interface/__init__.py:62-77); returns the resulting maximum."""
         self.lib.MKL_Set_Num_Threads(_ct.c_int(int(n)))
         return self.threads()
+
+    def spmm_handle(self, ha, hb):
+        """C := A @ B as a new library-owned handle (mkl_sparse_spmm); pair with order / export_csr / destroy."""
+        c = _ct.c_void_p()
+        self.lib.mkl_sparse_spmm.restype = _ct.c_int
+        st = self.lib.mkl_sparse_spmm(_ct.c_int(10), ha[0], hb[0], _ct.byref(c))
+        if st:
+            raise RuntimeError("mkl_sparse_spmm returned %d" % st)
+        return (c, ha[1], None)
+
+    def export_csr(self, handle):
+        """(indptr, indices, data, shape) COPIED out of a handle with mkl_sparse_?_export_csr, the way the reference
+        does it (_common.py:387-500): library-owned pointers, rows_end[-1] closes the row pointer, base must be 0."""
+        h, letter, _keep = handle
+        fn = getattr(self.lib, "mkl_sparse_%s_export_csr" % letter)
+        fn.restype = _ct.c_int
+        base, rows, cols = _ct.c_int(), self.cint(), self.cint()
+        rs, re, ci, va = (_ct.c_void_p() for _ in range(4))
+        st = fn(h, _ct.byref(base), _ct.byref(rows), _ct.byref(cols), _ct.byref(rs), _ct.byref(re), _ct.byref(ci),
+                _ct.byref(va))
+        if st:
+            raise RuntimeError("mkl_sparse_%s_export_csr returned %d" % (letter, st))
+        assert base.value == 0
+        m = int(rows.value)
+        isz = _np.dtype(self.idt).itemsize
+        vdt = _np.float32 if letter == "s" else _np.float64
+
+        def arr(ptr, count, dtype):
+            if count == 0:
+                return _np.zeros(0, dtype=dtype)
+            buf = (_ct.c_char * (count * _np.dtype(dtype).itemsize)).from_address(ptr.value)
+            return _np.frombuffer(buf, dtype=dtype).copy()
+        start = arr(rs, m, self.idt)
+        end = arr(re, m, self.idt)
+        nnz = int(end[-1]) if m else 0
+        indptr = _np.concatenate([start[:1] if m else _np.zeros(1, self.idt), end]).astype(self.idt)
+        return indptr, arr(ci, nnz, self.idt), arr(va, nnz, vdt), (m, int(cols.value))
 
     def spmm(self, ha, hb):
         """C := A @ B, both sparse: mkl_sparse_spmm, then the handle is destroyed (the multiply is what is timed;
@@ -114,7 +159,7 @@ class MklSpmm:
         fn = getattr(self.lib, "mkl_sparse_%s_syrkd" % letter)
         ct = _ct.c_float if letter == "s" else _ct.c_double
         fn.restype = _ct.c_int
-        fn.argtypes = [_ct.c_int, _ct.c_void_p, ct, ct, _ct.c_void_p, _ct.c_int, _ct.c_int]
+        fn.argtypes = [_ct.c_int, _ct.c_void_p, ct, ct, _ct.c_void_p, _ct.c_int, self.cint]
         st = fn(11, h, 1.0, 0.0, out.ctypes.data, 101, out.shape[1])
         if st:
             raise RuntimeError("mkl_sparse_%s_syrkd returned %d" % (letter, st))

@@ -474,7 +474,6 @@ struct Options {
     int64_t spmm_unroll = 4;       // 4 or 8 independent B-row loads in flight per lane
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_slices = 0;       // XCD-affine column slices of the dense operand: 0 = by row width (256-byte slices), else 1, 2, 4, 8
-    int64_t spmm_stream_nt = 0;    // 1: A's entries and the C rows (each touched once) move with the non-temporal policy
     int64_t spmm_tag_struct = 0;   // 1: the tagged gather uses structured buffer loads even when B is below 4 GiB (tests, A/B)
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;

@@ -788,8 +788,6 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.bsr_native = value;
         } else if (!strcmp(name, "staged_copies")) {
             o.staged_copies = value;
-        } else if (!strcmp(name, "spmm_stream_nt")) {
-            o.spmm_stream_nt = value;
         } else if (!strcmp(name, "spmm_tag_struct")) {
             o.spmm_tag_struct = value;
         } else if (!strcmp(name, "spmm_plan_sync")) {

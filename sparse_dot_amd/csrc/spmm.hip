@@ -131,8 +131,7 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
            const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
            const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
-           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices, int stream_nt,
-           int64_t b_rows)
+           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices, int64_t b_rows)
 {
     MI_DYN_SMEM(smem);
     constexpr int NG = WAVE / LPN;  // lane groups per wave, each on its own nonzero
@@ -208,23 +207,14 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
             s_end[k] = (int32_t)(en - P0);
         }
         const int len = (int)(P1 - P0);
-        // stream_nt: A is touched once per slice -- the non-temporal policy keeps it from displacing rows of B in L2
-        if (stream_nt) {
-            for (int k = lane; k < len; k += WAVE) {
-                const T a = nt_load(&val[P0 + k]);
-                SpEntry<T> en;
-                en.c = nt_load(&col[P0 + k]);
-                en.v = conj_a ? vt<T>::conj(a) : a;
-                s_nz[k] = en;
-            }
-        } else {
-            for (int k = lane; k < len; k += WAVE) {
-                const T a = val[P0 + k];
-                SpEntry<T> en;
-                en.c = col[P0 + k];
-                en.v = conj_a ? vt<T>::conj(a) : a;
-                s_nz[k] = en;
-            }
+        // (A and C with the non-temporal policy -- each is touched once per slice -- measured 2 % SLOWER on the headline
+        // matrix at every hot budget, profiles/r03_spmm_stream_nt_ab.log: plain loads / stores)
+        for (int k = lane; k < len; k += WAVE) {
+            const T a = val[P0 + k];
+            SpEntry<T> en;
+            en.c = col[P0 + k];
+            en.v = conj_a ? vt<T>::conj(a) : a;
+            s_nz[k] = en;
         }
     }
     __syncthreads();
@@ -322,8 +312,7 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
                             out.v[v] = vt<T>::fma(alpha, acc[v], vt<T>::mul(beta, old.v[v]));
                     }
                     if (V > 1) {
-                        if (stream_nt) nt_store16(crow, out.v);  // written once, never re-read by this kernel
-                        else *reinterpret_cast<vec<T, V>*>(crow) = out;
+                        *reinterpret_cast<vec<T, V>*>(crow) = out;
                     } else {
                         crow[0] = out.v[0];
                     }
@@ -803,12 +792,11 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
     unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
     if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
-    const int stream_nt = options().spmm_stream_nt != 0 ? 1 : 0;
 #define MI_SPMM_LAUNCH(TAGMODE, COLS)                                                                                  \
     MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz, \
                    (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,                                      \
                    (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,      \
-                   c_cs, N, alpha, beta, beta_zero, carry_val, slices, stream_nt, m.cols)
+                   c_cs, N, alpha, beta, beta_zero, carry_val, slices, m.cols)
     if constexpr (V * sizeof(T) == 16) {
         if (tag_mode == SPMM_TAG_BUFFER) {
             MI_SPMM_LAUNCH(SPMM_TAG_BUFFER, p.col_tagged.as<int32_t>());

@@ -14,9 +14,21 @@ C[i, :] depends only on A[i, :] and B):
               [c0, c1) of the n x n result, so no reduction is needed (`sharded_gram_matrix`).
 
 Backend "nccl" is RCCL over xGMI on ROCm; the same code runs on "gloo" CPU tensors, which is how
-the host logic is tested without GPUs.  All-gatherv comes in two forms (`gather_mode`):
-"bcast" -- one broadcast per rank straight into that rank's slice of the full output, no padding,
-no staging copy; "padded" -- blocks padded to the tallest one and one all_gather_into_tensor.
+the host logic is tested without GPUs.
+
+xGMI is point-to-point (every GPU has one link to every other GPU of the node), so the collectives that move the
+dense operands are built for THAT topology rather than for a ring:
+
+  * all-gatherv (`gather_rows`, `gather_mode`): "p2p" -- ONE grouped batch of sends / receives, every rank writes its
+    block straight into every peer's slice, so all world - 1 links of a GPU carry traffic at once (a ring pushes the
+    whole output through one link per GPU); "bcast" -- one broadcast per rank into its slice (world back-to-back
+    collectives); "padded" -- blocks padded to the tallest one and one all_gather_into_tensor.
+  * broadcast of B (`broadcast_rows`, `bcast_mode`): "scatter_allgather" -- the root sends slab r (1 / world of the
+    rows) to rank r over link r, then every rank forwards its slab to the others directly: the root's egress per link
+    drops from |B| to 2 |B| / world; "bcast" -- a single dist.broadcast.
+  * `ShardedCSR.dot_pipelined`: B and C held as column PANELS (panel-major, each panel contiguous); the broadcast of
+    panel p + 2, the kernel on panel p and the all-gatherv of panel p - 1 overlap (collectives on the communicator's
+    own stream, the kernel on the caller's stream).
 """
 import numpy as _np
 from scipy import sparse as _sps
@@ -92,10 +104,80 @@ def _src_global(src, group):
     return dist.get_global_rank(group, src) if group is not None else src
 
 
+class _Pending:
+    """Outstanding communication: `wait()` orders the caller behind it (NCCL: the current stream waits, the host does
+    not block; gloo: blocks)."""
+
+    def __init__(self, works=()):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        return self
+
+
+def _p2p_batch(sends, recvs, group):
+    """One grouped batch of point-to-point transfers: sends = [(tensor, group rank)], recvs likewise.  Under NCCL the
+    batch is a single ncclGroup -- every transfer runs concurrently on its own link."""
+    import torch.distributed as dist
+    ops = [dist.P2POp(dist.irecv, t, _src_global(r, group), group) for t, r in recvs if t.numel()]
+    ops += [dist.P2POp(dist.isend, t, _src_global(r, group), group) for t, r in sends if t.numel()]
+    return _Pending(dist.batch_isend_irecv(ops)) if ops else _Pending()
+
+
+def gather_rows_p2p(full, bounds, group=None):
+    """All-gatherv as one grouped send / receive batch (returns a _Pending): this rank's block goes to every peer,
+    every peer's block lands in its slice of `full`."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    b = [int(x) for x in bounds]
+    mine = full[b[rank]:b[rank + 1]]
+    sends = [(mine, r) for r in range(world) if r != rank]
+    recvs = [(full[b[r]:b[r + 1]], r) for r in range(world) if r != rank]
+    return _p2p_batch(sends, recvs, group)
+
+
+def broadcast_rows(t, src=0, group=None, mode="scatter_allgather"):
+    """Broadcast the (k, n) contiguous tensor `t` from group rank `src` (returns a _Pending).
+
+    "scatter_allgather": rows are cut into world slabs; phase 1 the root sends slab r to rank r (world - 1 links in
+    parallel), phase 2 every rank sends its slab to every other non-root rank (all links).  Per-link volume
+    2 |t| / world instead of |t|.  "bcast": dist.broadcast."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return _Pending()
+    if mode == "bcast":
+        w = dist.broadcast(t, src=_src_global(src, group), group=group, async_op=True)
+        return _Pending([w])
+    if mode != "scatter_allgather":
+        raise ValueError("bcast mode must be 'bcast' or 'scatter_allgather'")
+    k = t.shape[0]
+    cut = [k * r // world for r in range(world + 1)]
+    slab = lambda r: t[cut[r]:cut[r + 1]]  # noqa: E731
+    on_nccl = dist.get_backend(group) == "nccl"
+    if rank == src:
+        p1 = _p2p_batch([(slab(r), r) for r in range(world) if r != src], [], group)
+    else:
+        p1 = _p2p_batch([], [(slab(rank), src)], group)
+    if not on_nccl:
+        p1.wait()  # gloo: the slab must have landed before it is forwarded (NCCL orders the two batches on its stream)
+    if rank == src:  # the root already holds everything: it only hands out its own slab
+        sends, recvs = [(slab(src), r) for r in range(world) if r != src], []
+    else:
+        sends = [(slab(rank), r) for r in range(world) if r != rank and r != src]
+        recvs = [(slab(r), r) for r in range(world) if r != rank]  # the root's own slab comes from the root
+    p2 = _p2p_batch(sends, recvs, group)
+    return _Pending(p1.works + p2.works)
+
+
 def gather_rows(full, bounds, group=None, mode="bcast"):
     """All-gatherv of row blocks IN PLACE: on entry rank r has written rows bounds[r]:bounds[r+1] of
     `full` (a (rows, n) tensor present on every rank); on exit every rank holds every block.
 
+    mode "p2p": one grouped batch of sends / receives (gather_rows_p2p) -- all links at once.
     mode "bcast": one broadcast per rank directly into that rank's slice -- no padding, no staging
     copy, exactly (world - 1) / world of the output crosses the links.  mode "padded": blocks are
     copied into a buffer padded to the tallest block, one all_gather_into_tensor, and copied out --
@@ -106,13 +188,16 @@ def gather_rows(full, bounds, group=None, mode="bcast"):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     heights = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+    if mode == "p2p":
+        gather_rows_p2p(full, bounds, group).wait()
+        return full
     if mode == "bcast":
         for r in range(world):
             if heights[r]:
                 dist.broadcast(full[int(bounds[r]):int(bounds[r + 1])], src=_src_global(r, group), group=group)
         return full
     if mode != "padded":
-        raise ValueError("gather mode must be 'bcast' or 'padded'")
+        raise ValueError("gather mode must be 'p2p', 'bcast' or 'padded'")
     hmax = max(heights) if heights else 0
     if hmax == 0:
         return full
@@ -130,6 +215,31 @@ def gather_rows(full, bounds, group=None, mode="bcast"):
         if r != rank and heights[r]:
             full[int(bounds[r]):int(bounds[r + 1])] = g3[r, :heights[r]]
     return full
+
+
+def pipelined_panels(local_into, b_panels, c_panels, bounds, rank, src=0, group=None, bcast_mode="scatter_allgather",
+                     gather_mode="p2p", gather_group=None, depth=2):
+    """The panel pipeline behind ShardedCSR.dot_pipelined (bench.py drives it with its own kernel closure):
+    for every column panel p:  broadcast(panel p + depth) | local_into(B_p, C_p[rows of this rank]) | all-gatherv(C_p - 1).
+    `local_into(b_panel, c_slice)` enqueues the local product on the caller's stream."""
+    P = b_panels.shape[0]
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    ggroup = gather_group if gather_group is not None else group
+    ahead = [broadcast_rows(b_panels[p], src, group, bcast_mode) for p in range(min(depth, P))]
+    gathers = []
+    for p in range(P):
+        if p + depth < P:
+            ahead.append(broadcast_rows(b_panels[p + depth], src, group, bcast_mode))
+        ahead[p].wait()
+        if r1 > r0:
+            local_into(b_panels[p], c_panels[p][r0:r1])
+        if gather_mode == "p2p":
+            gathers.append(gather_rows_p2p(c_panels[p], bounds, ggroup))
+        else:
+            gather_rows(c_panels[p], bounds, ggroup, gather_mode)
+    for g in gathers:
+        g.wait()
+    return c_panels
 
 
 class _DeviceBlock:
@@ -224,16 +334,33 @@ class ShardedCSR:
             c = _np.ascontiguousarray(fn(self.a_block, b_t.cpu().numpy()))
             c_block_t.copy_(torch.from_numpy(c).to(c_block_t.device))
 
-    def dot(self, b_t, src=0, gather=True, gather_mode="bcast", out=None, broadcast=True):
+    def dot_pipelined(self, b_panels, c_panels=None, src=0, bcast_mode="scatter_allgather", gather_mode="p2p",
+                      gather_group=None, depth=2):
+        """C = A @ B with the dense operands held as column PANELS: `b_panels` is a (P, k, w) contiguous tensor
+        (panel p = columns p w : (p + 1) w of B, valid on rank `src`), the result a (P, rows, w) tensor of the same
+        layout (every rank receives every panel).  The broadcast of panel p + depth, the kernel on panel p and the
+        all-gatherv of panel p - 1 overlap: collectives run on the communicator's stream (`gather_group`, a second
+        process group over the same ranks, gives the all-gathervs their own), the kernel on the caller's."""
+        import torch
+        if b_panels.dim() != 3 or not b_panels.is_contiguous():
+            raise ValueError("b_panels must be a contiguous (panels, k, w) tensor")
+        P, k, w = b_panels.shape
+        if self.a_block.shape[1] != k:
+            raise ValueError("Matrix alignment error: %s * %s is not valid" % (self.a_block.shape, (k, P * w)))
+        if c_panels is None:
+            c_panels = torch.empty((P, self.rows, w), dtype=b_panels.dtype, device=b_panels.device)
+        return pipelined_panels(self.local_into, b_panels, c_panels, self.bounds, self.rank, src=src, group=self.group,
+                                bcast_mode=bcast_mode, gather_mode=gather_mode, gather_group=gather_group, depth=depth)
+
+    def dot(self, b_t, src=0, gather=True, gather_mode="bcast", out=None, broadcast=True, bcast_mode="bcast"):
         """C = A @ B.  `b_t`: (k, n) contiguous tensor on this rank's device, holding B on rank `src`
         (contents are overwritten by the broadcast elsewhere).  Returns the full (rows, n) tensor when
         gather=True (every rank), else this rank's (h, n) block; everything stays on the device."""
         import torch
-        import torch.distributed as dist
         if self.a_block.shape[1] != b_t.shape[0]:
             raise ValueError("Matrix alignment error: %s * %s is not valid" % (self.a_block.shape, tuple(b_t.shape)))
         if broadcast:
-            dist.broadcast(b_t, src=_src_global(src, self.group), group=self.group)  # RCCL broadcast of dense B
+            broadcast_rows(b_t, src, self.group, bcast_mode).wait()  # RCCL broadcast of dense B
         n = b_t.shape[1]
         r0, r1 = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
         if not gather:

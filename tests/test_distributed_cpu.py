@@ -133,6 +133,57 @@ def _worker_spgemm_gram(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_p2p_and_pipeline(rank, world, port, q):
+    """The xGMI-shaped collectives (grouped point-to-point all-gatherv, scatter + all-gather broadcast) and the
+    panel-pipelined product, on world = 3 so that the "forward my slab to the other non-root ranks" leg exists."""
+    dist = _setup(rank, world, port)
+    try:
+        import torch
+        from sparse_dot_amd import distributed as D
+        from oracle import cpu_oracle
+        rng = np.random.default_rng(5)
+        a = _skewed_matrix()
+        b = rng.random((127, 12))
+        want = a @ b
+        bounds = D.partition_rows(a.indptr, world)
+        mine = D.row_block(a, int(bounds[rank]), int(bounds[rank + 1]))
+        spmm = lambda x, y: cpu_oracle.spmm(x, y)  # noqa: E731
+        ok = True
+        # broadcast_rows from a non-zero root, both forms (tall and shorter-than-world tensors)
+        for src in (0, 2):
+            for mode in ("scatter_allgather", "bcast"):
+                for shape in ((127, 12), (2, 5), (0, 4)):
+                    ref = torch.arange(shape[0] * shape[1], dtype=torch.float64).reshape(shape) + 7.0
+                    t = ref.clone() if rank == src else torch.zeros(shape, dtype=torch.float64)
+                    D.broadcast_rows(t, src=src, mode=mode).wait()
+                    ok = ok and torch.equal(t, ref)
+        # all-gatherv, all three forms agree
+        for mode in ("p2p", "bcast", "padded"):
+            full = torch.zeros((a.shape[0], 12), dtype=torch.float64)
+            full[int(bounds[rank]):int(bounds[rank + 1])] = torch.from_numpy(want[bounds[rank]:bounds[rank + 1]])
+            D.gather_rows(full, bounds, None, mode)
+            ok = ok and np.array_equal(full.numpy(), want)
+        with D.ShardedCSR(mine, bounds, local_spmm=spmm) as sh:
+            bt = torch.from_numpy(b.copy() if rank == 1 else np.zeros_like(b))
+            got = sh.dot(bt, src=1, gather_mode="p2p", bcast_mode="scatter_allgather")
+            ok = ok and np.allclose(got.numpy(), want, rtol=1e-12, atol=1e-12)
+            # panel-major operands: 3 panels of 4 columns, root 0, a second group for the gathers
+            g2 = dist.new_group(list(range(world)))
+            panels = np.ascontiguousarray(b.reshape(127, 3, 4).transpose(1, 0, 2))
+            bp = torch.from_numpy(panels.copy() if rank == 0 else np.zeros_like(panels))
+            for depth in (1, 2, 5):
+                for gmode, gg in (("p2p", g2), ("p2p", None), ("bcast", None)):
+                    if rank != 0:
+                        bp.zero_()
+                    cp = sh.dot_pipelined(bp, src=0, gather_mode=gmode, gather_group=gg, depth=depth)
+                    got = cp.numpy().transpose(1, 0, 2).reshape(a.shape[0], 12)
+                    ok = ok and np.allclose(got, want, rtol=1e-12, atol=1e-12)
+                    ok = ok and np.array_equal(bp.numpy(), panels)  # every rank ends up holding B
+        q.put((rank, bool(ok), int(bounds[rank + 1] - bounds[rank])))
+    finally:
+        dist.destroy_process_group()
+
+
 def _run(worker, world=2):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -162,6 +213,11 @@ def test_bench_partitioned_step_world2_gloo():
 def test_sharded_spgemm_and_gram_world2_gloo():
     res = _run(_worker_spgemm_gram)
     assert res[0][2][1] == res[1][2][0]  # the two output bands are adjacent
+
+
+def test_p2p_collectives_and_pipelined_product_world3_gloo():
+    res = _run(_worker_p2p_and_pipeline, world=3)
+    assert sum(r[2] for r in res) == 342
 
 
 def test_partition_rows_balances_work():

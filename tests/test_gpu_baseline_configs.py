@@ -306,7 +306,7 @@ def test_spmm_tagged_gather_large_dense_operand(gpu, k_cols, n_dense, want_mode)
     gpu.mi_set_option("pool_trim", 1)
     torch.cuda.empty_cache()
     rows = 1 << 18
-    indptr, indices, vals = _hub_csr(torch, dev, rows, k_cols, 32, 4096, 5)
+    indptr, indices, vals = _hub_csr(torch, dev, rows, k_cols, 36, 4096, 5)
     nnz = indices.numel()
     assert nnz >= 1 << 23  # large enough for the sampled analysis to run
     gpu.mi_set_stream(torch.cuda.current_stream().cuda_stream)

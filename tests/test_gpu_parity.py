@@ -117,14 +117,12 @@ def test_spmm_hot_cold_tagged_gather(gpu, oracle, dtype, n):
         assert gpu.mi_get_counter("spmm_last_tagged") == 1.0
         assert 0.0 < gpu.mi_get_counter("spmm_hot_coverage") < 1.0
         gpu.mi_set_option("spmm_tag_struct", 1)  # the structured-buffer flavour (operands beyond 4 GiB), forced
-        gpu.mi_set_option("spmm_stream_nt", 1)   # and the non-temporal A / C streams
         tagged_struct = gpu.dot_product_mkl(a, b)
         assert gpu.mi_get_counter("spmm_last_tagged") == 2.0
     finally:
         gpu.mi_set_option("spmm_hot_force", 0)
         gpu.mi_set_option("spmm_hot_kb", 8192)
         gpu.mi_set_option("spmm_tag_struct", 0)
-        gpu.mi_set_option("spmm_stream_nt", 0)
     assert np.array_equal(tagged, plain)  # cache policy must not change a single bit
     assert np.array_equal(tagged_struct, plain)
     assert rel_err(tagged, oracle.spmm(a.astype(wide), b.astype(wide))) <= tol(dtype)
