@@ -724,13 +724,6 @@ def main():
     if dist and backend != "nccl":
         # gloo dry run (both ranks on one GPU): collectives staged through the host
         import sparse_dot_amd.distributed as D
-        _orig_bcast = dist.broadcast
-
-        def _bcast_host(t, src=0, group=None):
-            hcopy = t.cpu()
-            _orig_bcast(hcopy, src=src, group=group)
-            t.copy_(hcopy)
-        dist.broadcast = _bcast_host
         _orig_gather = D.gather_rows
 
         def _gather_host(full, bounds, group=None, mode="bcast"):

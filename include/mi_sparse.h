@@ -472,13 +472,12 @@ const char *mi_sparse_last_error(void);
 /* Tuning / diagnostic knob: name -> integer value; unknown names return INVALID_VALUE.  Used by
  * bench.py / tools to A/B kernel variants; defaults are the shipped choice.  Names:
  *   spmm_chunk, spmm_unroll, spmm_hot_kb, spmm_hot_force, spmm_force_generic,
- *   spmm_slices (XCD-affine column slices: 0 = by row width, 1 / 2 / 4 / 8), spmm_tag_struct, spmm_plan_sync
+ *   spmm_slices (XCD-affine column slices: 0 = by row width, 1 / 2 / 4 / 8), spmm_plan_sync
  *                                                                               (SpMM kernel variants)
  *   spgemm_lds_parts, spgemm_slice_table, spgemm_slice_table_max, spgemm_part_log2s_bias,
  *   spgemm_force_global, spgemm_global_mode                                     (SpGEMM big-row paths)
  *   gram_sliced (1: slice-table walk when the slices are short, 2: whenever the rows are sorted, 0: never),
  *   gram_tile_kb (128 / 64), gram_persistent (-1 auto, 0: one workgroup per tile, k: k workgroups per LDS slot),
- *   gram_cluster (workgroups per tile queue, 0 = static order), gram_rowtiles     (dense gram variants)
  *   bsr_native (0: BSR handles multiply through their CSR expansion), staged_copies (0: plain hipMemcpy for
  *   pageable host arrays)
  *   pool_enable (0: hipFree released device blocks at once), pool_max_mb (cap on cached bytes,

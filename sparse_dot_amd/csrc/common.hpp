@@ -168,15 +168,6 @@ __device__ __forceinline__ void nt_store16(T* dst, const T* src)
     __builtin_memcpy(&v, src, 16);  // registers -> one 16-byte vector (no memory traffic after optimisation)
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
 }
-__device__ __forceinline__ u32x4 nt_load16(const u32x4* p) { return __builtin_nontemporal_load(p); }
-
-// 16-byte STRUCTURED buffer load (`buffer_load_dwordx4 v, v[index:offset], s[rsrc], soffset idxen offen`): address =
-// base + index * stride + offset, formed by the hardware in 64 bits.  clang has builtins for the raw form only, so
-// the LLVM intrinsic is bound by name; `aux` (cache policy: 0 default, 2 non-temporal) must be a literal.
-#ifndef MI_HIP_EMU
-extern "C" __device__ u32x4 mi_struct_buffer_load_b128(__amdgpu_buffer_rsrc_t rsrc, int vindex, int voffset, int soffset,
-                                                      int aux) __asm("llvm.amdgcn.struct.ptr.buffer.load.v4i32");
-#endif
 
 // value of lane `src` when `src` is the SAME in every lane: v_readlane_b32 -- a scalar result, nothing goes through the
 // LDS queue (as __shfl = ds_bpermute it is an LDS-pipeline instruction per 32 bits and the value stays in a VGPR)
@@ -474,7 +465,6 @@ struct Options {
     int64_t spmm_unroll = 4;       // 4 or 8 independent B-row loads in flight per lane
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_slices = 0;       // XCD-affine column slices of the dense operand: 0 = by row width (256-byte slices), else 1, 2, 4, 8
-    int64_t spmm_tag_struct = 0;   // 1: the tagged gather uses structured buffer loads even when B is below 4 GiB (tests, A/B)
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)
@@ -485,8 +475,6 @@ struct Options {
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory
     int64_t trace_phases = 0;      // print host wall-clock per SpGEMM phase to stderr (diagnostics; synchronises)
-    int64_t gram_cluster = 0;      // sliced dense gram: workgroups per cluster pulling the tiles of their output rows from a queue (0: static order -- cuts the HBM fetch by a quarter, measured no faster)
-    int64_t gram_rowtiles = 0;     // sliced dense gram: one workgroup walks all tiles of an output row (<= 16 tiles per row)
     int64_t gram_sliced = 1;       // dense gram: slice table + 8 lanes per selected row when rows of X are sorted and slices are short (<= 12 entries on average); 2: whenever sorted; 0: never
     int64_t gram_persistent = -1;   // dense gram: workgroups per LDS slot of the chip walking the tile list (0: one workgroup per tile; -1: 1 for the sliced walk, 4 for the whole-row walk)
     int64_t gram_tile_kb = 128;    // dense gram, outputs wider than one 64 KiB tile: LDS tile of 128 (default) or 64 KiB
@@ -498,7 +486,7 @@ struct Options {
 struct Counters {
     double spmm_kernel_ms = 0.0;
     double spmm_kernel_launches = 0.0;
-    double spmm_last_tagged = 0.0;    // the last SpMM's gather: 0 plain, 1 hot / cold tagged buffer loads, 2 tagged structured buffer loads (operands beyond 4 GiB)
+    double spmm_last_tagged = 0.0;    // 1 when the last SpMM used the hot / cold tagged gather
     double spmm_hot_coverage = 0.0;   // share of nonzeros on hot columns in the last SpMM's plan
     double spmm_last_slices = 1.0;    // column slices the last SpMM ran with
     double spmm_plan_ms = 0.0;        // host wall time spent building plans (partition + fix-up schedule), accumulated

@@ -17,12 +17,6 @@ namespace mi {
 // same column), and the finished tile is written to HBM exactly once, coalesced, with beta applied
 // on the way -- no global atomics, no separate scaling pass.  Tiles start at the diagonal (only
 // col >= row is produced).
-#ifndef MI_GRAM_SUB
-#define MI_GRAM_SUB 8
-#endif
-#ifndef MI_GRAM_NT_STORE
-#define MI_GRAM_NT_STORE 1
-#endif
 // Finished tile -> C.  Row-major with beta = 0 (the reference's call): 16-byte NON-TEMPORAL stores -- the tile is
 // never read again by this kernel, and a wave's stores sit in the same in-order counter (vmcnt) as its next loads, so
 // the faster they retire the sooner the next tile's first loads are seen to complete.
@@ -31,7 +25,7 @@ __device__ __forceinline__ void syrkd_write_tile(const T* acc, T* crow, int64_t 
                                                  T beta, int beta_zero, int tid, int nthreads)
 {
     constexpr int V = 16 / (int)sizeof(T);
-    if (beta_zero && c_cs == 1 && MI_GRAM_NT_STORE) {
+    if (beta_zero && c_cs == 1) {
         T* p0 = crow + j_lo;
         int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(p0) & 15)) & 15) / sizeof(T));
         if (head > j_hi - j_lo) head = j_hi - j_lo;
@@ -103,10 +97,7 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         const int cnt = (t1 - base < WAVE) ? (int)(t1 - base) : WAVE;
         // R rows per step, two steps in flight: the loads of step s + 1 are issued before the LDS atomics of step s,
         // so the walk is a pipeline of independent loads instead of one dependent round trip per step
-#ifndef MI_GRAM_R
-#define MI_GRAM_R 4
-#endif
-        constexpr int R = MI_GRAM_R;
+        constexpr int R = 4;
         struct Step {
             int64_t qs[R], qe[R];
             T ae[R], xv[R];
@@ -163,11 +154,18 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
 // The tiles lie on a GLOBAL grid (tile g = columns [g * TILE, (g + 1) * TILE); the tile holding the diagonal is cut at
 // column i) and a table gives, for every row r of X and every tile boundary, how many of the row's entries lie left of
 // it: the part of row r that falls into tile g is the contiguous slice [off[r][g], off[r][g + 1]).  A wave takes 64
-// selected rows at a time (lane = row: the entry of X^T, the row start, the two offsets -- three gathers in flight
-// together), then EIGHT LANES walk each row's slice, eight rows per step, all eight steps' loads issued before the
-// first LDS atomic.  Against the whole-row walk above (every tile pass read all 64+ entries of every selected row
-// and kept ~TILE / n of them, ~75 instructions per row): an eighth of the loads at 8 tiles per row and ~2
-// instructions per row, which is what that kernel's time was made of (a wave issues one instruction per ~4 cycles).
+// selected rows at a time (lane = row: the entry of X^T, the row start, the two offsets), then EIGHT LANES walk each
+// row's slice, eight rows per step.
+//
+// Round 3: the tile loop is a SOFTWARE PIPELINE four tiles deep.  A tile workgroup owns the LDS of its CU, so nothing
+// else hides its memory latency, and on gfx950 a wave's loads and stores retire through ONE in-order counter (vmcnt):
+// a load issued after the 128 KiB write-out of the previous tile is not seen complete before those stores have
+// drained.  Round 2's loop (zero | chain | walk | barrier | write-out) therefore paid, per tile, the store drain PLUS
+// the dependent chain  row pointer of X^T -> (r, X[r,i]) -> row start + slice offsets -> slice entries  (measured
+// 23 us per tile against 6.7 us of write bandwidth).  Now every load of the chain is issued in one burst right after
+// the barrier that ends a tile's accumulation and BEFORE that tile's stores:
+//     slice entries of tile k+1 | offsets of tile k+2 | entries of X^T for tile k+3 | row pointer for tile k+4
+// and each level is consumed one full tile later.  The write-out re-zeroes the tile as it reads it (no zeroing pass).
 __global__ void k_gram_offsets(int64_t rows, int64_t G, int64_t w, const int64_t* __restrict__ xptr,
                                const int32_t* __restrict__ xcol, int32_t* __restrict__ off)
 {
@@ -184,325 +182,216 @@ __global__ void k_gram_offsets(int64_t rows, int64_t G, int64_t w, const int64_t
     off[t] = (int32_t)(lo - b0);
 }
 
-template <typename T, int TKB>
+// Finished tile -> C, and the tile back to zero (every element a thread reads it also clears).
+template <typename T>
+__device__ __forceinline__ void syrkd_flush_tile(T* acc, T* crow, int64_t c_cs, int64_t j_lo, int64_t j_hi, int64_t tile_lo,
+                                                 T beta, int beta_zero, int tid, int nthreads)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+    if (beta_zero && c_cs == 1) {
+        T* p0 = crow + j_lo;
+        int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(p0) & 15)) & 15) / sizeof(T));
+        if (head > j_hi - j_lo) head = j_hi - j_lo;
+        const int64_t body = (j_hi - j_lo - head) / V;  // 16-byte vectors
+        if (tid < head) {
+            nt_store(p0 + tid, acc[j_lo - tile_lo + tid]);
+            acc[j_lo - tile_lo + tid] = vt<T>::zero();
+        }
+        T* a0 = acc + (j_lo - tile_lo + head);
+        for (int64_t k = tid; k < body; k += nthreads) {
+            nt_store16(p0 + head + k * V, a0 + k * V);
+#pragma unroll
+            for (int v = 0; v < V; ++v) a0[k * V + v] = vt<T>::zero();
+        }
+        const int64_t done = head + body * V;
+        if (tid < j_hi - j_lo - done) {
+            nt_store(p0 + done + tid, acc[j_lo - tile_lo + done + tid]);
+            acc[j_lo - tile_lo + done + tid] = vt<T>::zero();
+        }
+        return;
+    }
+    for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
+        T* c = crow + j * c_cs;
+        const T v = acc[j - tile_lo];
+        acc[j - tile_lo] = vt<T>::zero();
+        *c = beta_zero ? v : vt<T>::fma(beta, *c, v);
+    }
+}
+
+template <typename T, int TKB, bool TABLE>  // TABLE: several tiles per row -> slice offsets from `off`; else the slice is the row
 __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     k_syrkd_sliced(int64_t n, int64_t row0, int64_t row_end, int64_t G, const int64_t* __restrict__ tptr,
                    const int32_t* __restrict__ tcol, const T* __restrict__ tval, const int64_t* __restrict__ xptr,
                    const int32_t* __restrict__ xcol, const T* __restrict__ xval, const int32_t* __restrict__ off,
-                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual,
-                   unsigned long long* __restrict__ queue, int cs)
+                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual)
 {
     constexpr int TILE = syrkd_tile<T, TKB>();
-    constexpr int SUB = MI_GRAM_SUB;  // lanes per selected row
+    constexpr int SUB = 8;            // lanes per selected row
     constexpr int RPS = WAVE / SUB;   // rows per step
     constexpr int NSTEP = WAVE / RPS; // steps per 64 rows, all in flight together
     __shared__ T acc[TILE];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid / WAVE, lane = tid % WAVE, nwaves = nthreads / WAVE;
     const int sub = lane % SUB, grp = lane / SUB;
-    // list position -> (output row, tile); false: nothing to do there (past the row block / left of the diagonal)
+    // list position -> (output row, tile); the positions left of the diagonal / past the row block hold nothing.
+    // Workgroup b runs on XCD b % 8 (observed; speed only): all tiles of one output row go to the SAME XCD back to back.
+    struct Pos {
+        int64_t i, g, vb;
+        bool ok;
+    };
     auto decode = [&](int64_t vb, int64_t& i, int64_t& g) {
         const int64_t q = vb >> 3;
         i = row0 + (q / G) * 8 + (vb & 7);
         g = q % G;
         return i < row_end && g * TILE + TILE > i;
     };
-    auto next_valid = [&](int64_t vb, int64_t& i, int64_t& g) {
-        while (vb < n_virtual && !decode(vb, i, g)) vb += gridDim.x;
-        return vb;
+    auto seek = [&](int64_t vb) {
+        Pos p;
+        p.i = row0;
+        p.g = 0;
+        while (vb < n_virtual && !decode(vb, p.i, p.g)) vb += gridDim.x;
+        p.vb = vb;
+        p.ok = vb < n_virtual;
+        if (!p.ok) {  // a harmless, valid position: every load below stays unconditional
+            p.i = row0;
+            p.g = 0;
+        }
+        return p;
     };
-    // The dependent chain  row pointer of X^T -> (r, X[r,i]) -> start of row r and its slice offsets  costs three memory
-    // round trips of ~3.5 us each under load (measured per phase with wall_clock64: 10.4 of a tile's 27 us), and a tile
-    // workgroup is alone on its CU: nothing else hides them.  So they are fetched ONE TILE AHEAD, one level per phase of
-    // the current tile (A: before zeroing, B: before the walk, C: before the write-out), for the wave's first 64 rows.
+    auto after = [&](const Pos& p) { return p.ok ? seek(p.vb + gridDim.x) : p; };
+    // chain of a tile, one level per pipeline stage (this wave's first 64 selected rows)
     struct Head {
-        int64_t t0, t1;   // A
-        int32_t r;        // B (lane = selected row)
+        int64_t t0, t1;   // A: extent of column i in X^T
+        int32_t r;        // B: lane = selected row
         T a;
-        int64_t s;        // C: start of the slice
-        int32_t len;      //    its length (0 for lanes past the end)
+        int64_t s;        // C: start of the row's slice in this tile ...
+        int32_t len;      //    ... and its length (0 for lanes past the end / positions that hold nothing)
     };
-    auto stage_a = [&](int64_t i, Head& h) {
-        h.t0 = tptr[i];
-        h.t1 = tptr[i + 1];
+    auto stage_a = [&](const Pos& p, Head& h) {
+        h.t0 = tptr[p.i];
+        h.t1 = tptr[p.i + (p.ok ? 1 : 0)];  // an empty extent for positions that hold nothing (no branch around a load)
     };
     auto stage_b = [&](Head& h) {
         const int64_t base = h.t0 + (int64_t)wave * WAVE;
-        const int64_t p = base + lane < h.t1 ? base + lane : (h.t0 < h.t1 ? h.t1 - 1 : 0);  // always a valid entry
-        h.r = tcol[p];
-        h.a = vt<T>::mul(alpha, tval[p]);
+        int64_t q = base + lane < h.t1 ? base + lane : h.t1 - 1;  // always a valid entry ...
+        if (q < 0) q = 0;                                          // ... (the kernel is only launched with nnz > 0)
+        h.r = tcol[q];
+        h.a = vt<T>::mul(alpha, tval[q]);
     };
     auto stage_c = [&](int64_t g, Head& h) {
         const int64_t base = h.t0 + (int64_t)wave * WAVE;
         const bool valid = base + lane < h.t1;
         const int64_t xb = xptr[h.r];
-        int32_t o0, o1;
-        if (off) {
+        // (a run-time branch on `off` around these loads made the compiler drain vmcnt to 0 at the join -- right after
+        // the burst of slice loads: hence the template flag)
+        if constexpr (TABLE) {
             const int32_t* orow = off + (int64_t)h.r * (G + 1) + g;
-            o0 = orow[0];
-            o1 = orow[1];
-        } else {  // one tile per row: the slice is the row
-            o0 = 0;
-            o1 = (int32_t)(xptr[h.r + 1] - xb);
+            const int32_t o0 = orow[0], o1 = orow[1];
+            h.s = xb + o0;
+            h.len = valid ? o1 - o0 : 0;
+        } else {
+            h.s = xb;
+            h.len = valid ? (int32_t)(xptr[h.r + 1] - xb) : 0;
         }
-        h.s = xb + o0;
-        h.len = valid ? o1 - o0 : 0;
     };
-    // RPS rows per step, SUB lanes per row; the first SUB entries of every row of all NSTEP steps are in flight together
-    auto walk64 = [&](int64_t s, int32_t len, T a, int64_t j_lo, int64_t tile_lo, int64_t safe) {
-        // entries sub and sub + SUB of every row of all NSTEP steps are loaded before the first LDS atomic: a slice
-        // longer than SUB entries used to cost its step one more DEPENDENT round trip, one step after the other
-        // (with ~8 entries per slice nearly every step of 8 rows has such a row: 8 serial round trips per 64 rows)
-        int32_t jv[2][NSTEP], ln[NSTEP];
-        int64_t sk[NSTEP];
-        T av[NSTEP], xv[2][NSTEP];
+    // entries sub (and sub + SUB) of every row's slice, all NSTEP steps: 2 HH NSTEP loads per lane, issued together, none
+    // of them touched before `accumulate` (masked lanes read entry 0)
+    constexpr int HH = sizeof(T) <= 4 ? 2 : 1;  // halves of SUB entries requested ahead (registers: 8-byte values get one)
+    struct Slices {
+        int32_t jv[HH][NSTEP];
+        T xv[HH][NSTEP];
+    };
+    auto load_slices = [&](const Head& h, Slices& S) {
 #pragma unroll
         for (int k = 0; k < NSTEP; ++k) {
             const int src = k * RPS + grp;
-            sk[k] = __shfl(s, src);
-            ln[k] = __shfl(len, src);
-            av[k] = __shfl(a, src);
+            const int64_t sk = __shfl(h.s, src);
+            const int32_t ln = __shfl(h.len, src);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bool ok = sub + h * SUB < ln[k];
-                const int64_t qq = ok ? sk[k] + sub + h * SUB : safe;
-                jv[h][k] = xcol[qq];
-                xv[h][k] = xval[qq];
-                if (!ok) jv[h][k] = -1;
+            for (int hh = 0; hh < HH; ++hh) {
+                const int64_t qq = sub + hh * SUB < ln ? sk + sub + hh * SUB : 0;
+                S.jv[hh][k] = xcol[qq];
+                S.xv[hh][k] = xval[qq];
             }
         }
+    };
+    auto accumulate = [&](const Slices& S, const Head& h, int64_t j_lo, int64_t tile_lo) {
+        int32_t ln[NSTEP];
+        int64_t sk[NSTEP];
+        T av[NSTEP];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int k = 0; k < NSTEP; ++k) {
+            const int src = k * RPS + grp;
+            ln[k] = __shfl(h.len, src);
+            av[k] = __shfl(h.a, src);
+            sk[k] = __shfl(h.s, src);
+        }
+#pragma unroll
+        for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
             for (int k = 0; k < NSTEP; ++k)
-                if (jv[h][k] >= j_lo) atomic_accum(&acc[jv[h][k] - tile_lo], vt<T>::mul(av[k], xv[h][k]));
+                if (sub + hh * SUB < ln[k] && S.jv[hh][k] >= j_lo)
+                    atomic_accum(&acc[S.jv[hh][k] - tile_lo], vt<T>::mul(av[k], S.xv[hh][k]));
 #pragma unroll
-        for (int k = 0; k < NSTEP; ++k) {  // slices longer than 2 SUB entries
-            for (int e = sub + 2 * SUB; e < ln[k]; e += SUB) {
+        for (int k = 0; k < NSTEP; ++k) {  // slices longer than HH * SUB entries
+            for (int e = sub + HH * SUB; e < ln[k]; e += SUB) {
                 const int64_t j = xcol[sk[k] + e];
                 if (j >= j_lo) atomic_accum(&acc[j - tile_lo], vt<T>::mul(av[k], xval[sk[k] + e]));
             }
         }
     };
-    // Order of the tiles.  queue == nullptr: static, list position vb = blockIdx.x + k * gridDim.x.  Otherwise CLUSTERS of
-    // `cs` workgroups of one XCD (cluster id = XCD + 8 * c) own the output rows i = id (mod #clusters) and pull their
-    // tiles in row-major order from a per-cluster counter: at any moment the cs workgroups of a cluster work on
-    // neighbouring items, i.e. on the tiles of one or two output rows, which all gather from the SAME ~1000 rows of X.
-    // With the static order the workgroups drift apart (tiles left of the diagonal cost nothing, the first tile of a
-    // row is partial) until the 32 workgroups of an XCD sit on 32 different output rows: 32 x 512 KB of X rows against
-    // a 4 MB L2, every tile fetched its slices from HBM again (measured: walk 75 of 117 ms, 600 GB at 5.2 TB/s).
-    const int xcd = (int)(blockIdx.x & 7u);
-    const int64_t cid = queue ? xcd + 8 * (int64_t)((blockIdx.x >> 3) / cs) : 0;
-    const int64_t nclus = queue ? 8 * (int64_t)((gridDim.x >> 3) / cs) : 1;
-    auto decode_k = [&](int64_t k, int64_t& i, int64_t& g) {
-        for (int64_t b = row0 / TILE; b < G && b * TILE < row_end; ++b) {
-            const int64_t lo = row0 > b * TILE ? row0 : b * TILE;
-            const int64_t hi = row_end < (b + 1) * TILE ? row_end : (b + 1) * TILE;
-            const int64_t first = lo + (((cid - lo) % nclus) + nclus) % nclus;  // first row of the band owned by this cluster
-            if (first >= hi) continue;
-            const int64_t cnt = (hi - first + nclus - 1) / nclus, nt = G - b;
-            if (k < cnt * nt) {
-                i = first + (k / nt) * nclus;
-                g = b + k % nt;
-                return true;
-            }
-            k -= cnt * nt;
-        }
-        return false;
-    };
-    __shared__ unsigned long long s_next;
-    int64_t i = 0, g = 0, ni = 0, ng = 0;
-    int64_t vb = 0;
-    bool have;
-    if (queue) {
-        if (tid == 0) s_next = atomicAdd(&queue[cid], 1ull);
-        __syncthreads();
-        have = decode_k((int64_t)s_next, i, g);
-        __syncthreads();
-    } else {
-        vb = next_valid(blockIdx.x, i, g);
-        have = vb < n_virtual;
-    }
-    Head cur, nxt;
-    if (have) {
-        stage_a(i, cur);
-        stage_b(cur);
-        stage_c(g, cur);
-    }
-    while (have) {
-        if (queue && tid == 0) s_next = atomicAdd(&queue[cid], 1ull);  // next item: read by everybody after the barrier
+
+    // ---- prologue: fill the pipeline (blocking chains, once per workgroup) ----
+    Pos p0 = seek(blockIdx.x), p1 = after(p0), p2 = after(p1), p3 = after(p2), p4 = after(p3);
+    Head h0, h1, h2, h3, h4;
+    stage_a(p0, h0);
+    stage_b(h0);
+    stage_c(p0.g, h0);
+    stage_a(p1, h1);
+    stage_b(h1);
+    stage_c(p1.g, h1);
+    stage_a(p2, h2);
+    stage_b(h2);
+    stage_a(p3, h3);
+    for (int k = tid; k < TILE; k += nthreads) acc[k] = vt<T>::zero();
+    Slices S;
+    load_slices(h0, S);
+    __syncthreads();
+    while (p0.ok) {
+        const int64_t i = p0.i, g = p0.g;
         const int64_t tile_lo = g * TILE;
         const int64_t j_lo = i > tile_lo ? i : tile_lo;
         const int64_t j_hi = tile_lo + TILE < n ? tile_lo + TILE : n;
-        for (int k = tid; k < (int)(j_hi - tile_lo); k += nthreads) acc[k] = vt<T>::zero();
-        __syncthreads();
-        bool more;
-        if (queue) {
-            more = decode_k((int64_t)s_next, ni, ng);
-        } else {
-            vb = next_valid(vb + gridDim.x, ni, ng);
-            more = vb < n_virtual;
-        }
-        if (more) stage_a(ni, nxt);
-        const int64_t t0 = cur.t0, t1 = cur.t1;
-        if (t0 + (int64_t)wave * WAVE < t1) walk64(cur.s, cur.len, cur.a, j_lo, tile_lo, t0);
-        for (int64_t base = t0 + (int64_t)(wave + nwaves) * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {
-            // further rows of a long list: fetched here, the chain exposed
+        // (1) this tile's products into LDS: its slice entries were requested one tile ago, before that tile's stores
+        accumulate(S, h0, j_lo, tile_lo);
+        for (int64_t base = h0.t0 + (int64_t)(wave + nwaves) * WAVE; base < h0.t1; base += (int64_t)nwaves * WAVE) {
+            // further rows of a long list (more than 64 * nwaves nonzeros in column i): fetched here, the chain exposed
             Head h;
             h.t0 = base - (int64_t)wave * WAVE;  // so that stage_b / stage_c address `base`
-            h.t1 = t1;
+            h.t1 = h0.t1;
             stage_b(h);
             stage_c(g, h);
-            walk64(h.s, h.len, h.a, j_lo, tile_lo, t0);
+            Slices S2;
+            load_slices(h, S2);
+            accumulate(S2, h, j_lo, tile_lo);
         }
-        if (more) stage_b(nxt);
         __syncthreads();
-        if (more) stage_c(ng, nxt);
-        syrkd_write_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, tile_lo, beta, beta_zero, tid, nthreads);
-        __syncthreads();  // the tile (and s_next) are reused
-        i = ni;
-        g = ng;
-        cur = nxt;
-        have = more;
-    }
-}
-
-// ---- sliced, ROW-persistent: one workgroup walks ALL tiles of an output row (G <= GRAM_GMAX tiles per row) --------
-// The head of the chain (entry of X^T, start of row r) is the same for every tile of the row and the G + 1 slice
-// offsets of a row of X are one 4 (G + 1)-byte record: a lane fetches them ONCE per output row into registers (one row
-// ahead, spread over the phases of the current row's first tile), and a tile is then zero -> one round trip for the
-// slice entries -> barrier -> write-out, with no gather of its own.  The tiles of a row are adjacent slices of the same
-// rows of X, so three of four are cache hits on the line the previous tile brought in.
-constexpr int GRAM_GMAX = 16;  // instantiated for <= 8 and <= 16 tiles per row (offsets live in registers)
-
-template <typename T, int TKB, int GMAX>
-__global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
-    k_syrkd_rowtiles(int64_t n, int64_t row0, int64_t row_end, int G, const int64_t* __restrict__ tptr,
-                     const int32_t* __restrict__ tcol, const T* __restrict__ tval, const int64_t* __restrict__ xptr,
-                     const int32_t* __restrict__ xcol, const T* __restrict__ xval, const int32_t* __restrict__ off,
-                     T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero)
-{
-    constexpr int TILE = syrkd_tile<T, TKB>();
-    constexpr int SUB = MI_GRAM_SUB;
-    constexpr int RPS = WAVE / SUB;
-    constexpr int NSTEP = WAVE / RPS;
-    __shared__ T acc[TILE];
-    const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int wave = tid / WAVE, lane = tid % WAVE, nwaves = nthreads / WAVE;
-    const int sub = lane % SUB, grp = lane / SUB;
-    struct Head {
-        int64_t t0, t1;            // A
-        int32_t r;                 // B (lane = selected row)
-        T a;
-        int64_t xb;                // C: start of row r of X ...
-        int32_t o[GMAX + 1];        //    ... and its entries left of every tile boundary
-        bool valid;
-    };
-    auto stage_a = [&](int64_t i, Head& h) {
-        h.t0 = tptr[i];
-        h.t1 = tptr[i + 1];
-    };
-    auto stage_b = [&](Head& h) {
-        const int64_t base = h.t0 + (int64_t)wave * WAVE;
-        const int64_t p = base + lane < h.t1 ? base + lane : (h.t0 < h.t1 ? h.t1 - 1 : 0);  // always a valid entry
-        h.valid = base + lane < h.t1;
-        h.r = tcol[p];
-        h.a = vt<T>::mul(alpha, tval[p]);
-    };
-    auto stage_c = [&](Head& h) {
-        h.xb = xptr[h.r];
-        const int32_t* orow = off + (int64_t)h.r * (G + 1);
-#pragma unroll
-        for (int k = 0; k <= GMAX; ++k) h.o[k] = orow[k <= G ? k : G];
-    };
-    auto slice_of = [&](const Head& h, int g, int64_t& s, int32_t& len) {
-        int32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < GMAX; ++k)
-            if (k == g) {
-                lo = h.o[k];
-                hi = h.o[k + 1];
-            }
-        s = h.xb + lo;
-        len = h.valid ? hi - lo : 0;
-    };
-    auto walk64 = [&](int64_t s, int32_t len, T a, int64_t j_lo, int64_t tile_lo, int64_t safe) {
-        // entries sub and sub + SUB of every row of all NSTEP steps are loaded before the first LDS atomic: a slice
-        // longer than SUB entries used to cost its step one more DEPENDENT round trip, one step after the other
-        // (with ~8 entries per slice nearly every step of 8 rows has such a row: 8 serial round trips per 64 rows)
-        int32_t jv[2][NSTEP], ln[NSTEP];
-        int64_t sk[NSTEP];
-        T av[NSTEP], xv[2][NSTEP];
-#pragma unroll
-        for (int k = 0; k < NSTEP; ++k) {
-            const int src = k * RPS + grp;
-            sk[k] = __shfl(s, src);
-            ln[k] = __shfl(len, src);
-            av[k] = __shfl(a, src);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bool ok = sub + h * SUB < ln[k];
-                const int64_t qq = ok ? sk[k] + sub + h * SUB : safe;
-                jv[h][k] = xcol[qq];
-                xv[h][k] = xval[qq];
-                if (!ok) jv[h][k] = -1;
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int k = 0; k < NSTEP; ++k)
-                if (jv[h][k] >= j_lo) atomic_accum(&acc[jv[h][k] - tile_lo], vt<T>::mul(av[k], xv[h][k]));
-#pragma unroll
-        for (int k = 0; k < NSTEP; ++k) {  // slices longer than 2 SUB entries
-            for (int e = sub + 2 * SUB; e < ln[k]; e += SUB) {
-                const int64_t j = xcol[sk[k] + e];
-                if (j >= j_lo) atomic_accum(&acc[j - tile_lo], vt<T>::mul(av[k], xval[sk[k] + e]));
-            }
-        }
-    };
-    int64_t i = row0 + blockIdx.x;
-    Head cur, nxt;
-    if (i < row_end) {
-        stage_a(i, cur);
-        stage_b(cur);
-        stage_c(cur);
-    }
-    for (; i < row_end; i += gridDim.x) {
-        const int64_t ni = i + gridDim.x;
-        const bool more = ni < row_end;
-        const int g_first = (int)(i / TILE);
-        if (more) stage_a(ni, nxt);
-        const int64_t t0 = cur.t0, t1 = cur.t1;
-        for (int g = g_first; g < G; ++g) {
-            const int64_t tile_lo = (int64_t)g * TILE;
-            const int64_t j_lo = i > tile_lo ? i : tile_lo;
-            const int64_t j_hi = tile_lo + TILE < n ? tile_lo + TILE : n;
-            for (int k = tid; k < (int)(j_hi - tile_lo); k += nthreads) acc[k] = vt<T>::zero();
-            __syncthreads();
-            if (more && g == g_first) stage_b(nxt);
-            if (t0 + (int64_t)wave * WAVE < t1) {
-                int64_t s;
-                int32_t len;
-                slice_of(cur, g, s, len);
-                walk64(s, len, cur.a, j_lo, tile_lo, t0);
-            }
-            for (int64_t base = t0 + (int64_t)(wave + nwaves) * WAVE; base < t1; base += (int64_t)nwaves * WAVE) {
-                // further rows of a long list: fetched here, per tile, the chain exposed
-                const int64_t p = base + lane < t1 ? base + lane : t1 - 1;
-                const int32_t r = tcol[p];
-                const T a = vt<T>::mul(alpha, tval[p]);
-                const int64_t xb = xptr[r];
-                const int32_t* orow = off + (int64_t)r * (G + 1) + g;
-                const int32_t o0 = orow[0], o1 = orow[1];
-                walk64(xb + o0, base + lane < t1 ? o1 - o0 : 0, a, j_lo, tile_lo, t0);
-            }
-            if (more && g == g_first) stage_c(nxt);
-            __syncthreads();
-            syrkd_write_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, tile_lo, beta, beta_zero, tid, nthreads);
-            __syncthreads();  // the tile is reused
-        }
-        cur = nxt;
+        // (2) one burst of loads for the tiles ahead, THEN this tile's stores
+        load_slices(h1, S);
+        stage_c(p2.g, h2);
+        stage_b(h3);
+        stage_a(p4, h4);
+        syrkd_flush_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, tile_lo, beta, beta_zero, tid, nthreads);
+        __syncthreads();  // the tile is zero again
+        p0 = p1;
+        p1 = p2;
+        p2 = p3;
+        p3 = p4;
+        p4 = after(p4);
+        h0 = h1;
+        h1 = h2;
+        h2 = h3;
+        h3 = h4;
     }
 }
 
@@ -582,41 +471,16 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
 #define MI_SYRKD_ARGS                                                                                               \
     (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, (const int32_t*)x.col,   \
         (const T*)x.val
-        if (sliced && off && tiles_per_row <= GRAM_GMAX && options().gram_rowtiles) {
-            // one workgroup per output row, persistent over rows: grid = LDS slots of the chip (a multiple of 8: row i on XCD i % 8)
-            c.ensure();
-            int64_t rgrid = (int64_t)c.cus * (wide ? 1 : 2) * (persistent > 0 ? persistent : 1);
-            rgrid = (rgrid + 7) / 8 * 8;
-            if (rgrid > nr) rgrid = nr;
-#define MI_ROWTILES(TKB_, GM_, THREADS_)                                                                              \
-    MI_LAUNCH((k_syrkd_rowtiles<T, TKB_, GM_>), dim3((unsigned)rgrid), dim3(THREADS_), c.stream, n, row0, row1,         \
-              (int)tiles_per_row, MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero)
+        if (sliced) {
+#define MI_SLICED(TKB_, TABLE_, THREADS_)                                                                              \
+    MI_LAUNCH((k_syrkd_sliced<T, TKB_, TABLE_>), dim3((unsigned)grid), dim3(THREADS_), c.stream, n, row0, row1,          \
+              tiles_per_row, MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks)
             if (wide) {
-                if (tiles_per_row <= 8) MI_ROWTILES(128, 8, 1024); else MI_ROWTILES(128, 16, 1024);
+                if (off) MI_SLICED(128, true, 1024); else MI_SLICED(128, false, 1024);
             } else {
-                if (tiles_per_row <= 8) MI_ROWTILES(64, 8, 512); else MI_ROWTILES(64, 16, 512);
+                if (off) MI_SLICED(64, true, 512); else MI_SLICED(64, false, 512);
             }
-#undef MI_ROWTILES
-        } else if (sliced) {
-            // clusters of `cs` workgroups per XCD pulling the tiles of their output rows from a queue (see the kernel)
-            unsigned long long* queue = nullptr;
-            const int cs = (int)options().gram_cluster;
-            if (cs > 0 && persistent > 0 && off) {
-                const int64_t slots = (int64_t)c.cus * (wide ? 1 : 2) * persistent;
-                const int64_t gq = slots / (8 * cs) * (8 * cs);
-                if (gq >= 8 * cs && gq <= nblocks) {
-                    grid = gq;
-                    const int64_t nclus = gq / cs;
-                    queue = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * (size_t)nclus));
-                    MI_HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long) * (size_t)nclus, c.stream));
-                }
-            }
-            if (wide)
-                MI_LAUNCH((k_syrkd_sliced<T, 128>), dim3((unsigned)grid), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
-                          MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks, queue, cs);
-            else
-                MI_LAUNCH((k_syrkd_sliced<T, 64>), dim3((unsigned)grid), dim3(512), c.stream, n, row0, row1, tiles_per_row,
-                          MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks, queue, cs);
+#undef MI_SLICED
         } else if (wide) {
             MI_LAUNCH((k_syrkd_lds<T, 128>), dim3((unsigned)grid), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
                       MI_SYRKD_ARGS, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);

@@ -772,11 +772,6 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
                 mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_slices must be 0 (automatic), 1, 2, 4 or 8");
             o.spmm_slices = value;
-        } else if (!strcmp(name, "gram_cluster")) {
-            if (value < 0 || value > 64) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "gram_cluster must be in [0, 64]");
-            o.gram_cluster = value;
-        } else if (!strcmp(name, "gram_rowtiles")) {
-            o.gram_rowtiles = value;
         } else if (!strcmp(name, "gram_sliced")) {
             o.gram_sliced = value;
         } else if (!strcmp(name, "gram_persistent")) {
@@ -788,8 +783,6 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.bsr_native = value;
         } else if (!strcmp(name, "staged_copies")) {
             o.staged_copies = value;
-        } else if (!strcmp(name, "spmm_tag_struct")) {
-            o.spmm_tag_struct = value;
         } else if (!strcmp(name, "spmm_plan_sync")) {
             o.spmm_plan_sync = value;
         } else if (!strcmp(name, "spmm_hot_force")) {

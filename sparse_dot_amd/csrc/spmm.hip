@@ -120,18 +120,19 @@ __host__ __device__ constexpr size_t spmm_wave_lds(int ch)
 //             resource spans the whole 32-bit offset range (num_records = 0xffffffff): the range check
 //             returns ZERO for any offset at or beyond num_records, so a smaller constant silently
 //             drops rows of B (tests/test_gpu_baseline_configs.py::test_spmm_tagged_gather_large_dense_operand).
-//   TAG == 2: STRUCTURED buffer loads (`buffer_load_dwordx4 ... idxen offen`): the hardware forms
-//             base + column * stride + offset in 64 bits, so B may exceed 4 GiB (BASELINE configs[4]: 17 GB) and the
-//             address costs no VALU multiply; needs a row stride below 16 KiB (14-bit stride field).
-//             (Two global loads that differ only in the non-temporal hint are merged by the compiler, which
-//             drops the hint -- the buffer forms carry the policy as an immediate and stay apart.)
-constexpr int SPMM_TAG_NONE = 0, SPMM_TAG_BUFFER = 1, SPMM_TAG_STRUCT = 2;
+// Operands of 4 GiB and more (BASELINE configs[4]: B = 17 GB) gather UNTAGGED.  Tried in round 3 and dropped:
+//   * structured buffer loads (index * stride formed by the hardware): gfx950 forms index * stride + offset in 32 bits,
+//     rows of B beyond 4 GiB wrapped around (caught by test_config5_shape_single_gpu, profiles/r03_gpu_session_b.log);
+//   * 64-bit global loads with the non-temporal hint on the cold ones: two global loads that differ only in the hint
+//     are merged by the compiler and the hint is dropped -- through a second pointer argument, an under-aligned vector
+//     type or a select of pointers alike (the policy is an immediate only on the buffer forms).
+constexpr int SPMM_TAG_NONE = 0, SPMM_TAG_BUFFER = 1;
 template <typename T, int V, int LPN, int U, int TAG>
 __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ? 8 : 1)
     k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
            const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
            const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
-           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices, int64_t b_rows)
+           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices)
 {
     MI_DYN_SMEM(smem);
     constexpr int NG = WAVE / LPN;  // lane groups per wave, each on its own nonzero
@@ -225,9 +226,6 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     const int nproc = n_owned + has_trail;
     __amdgpu_buffer_rsrc_t b_rsrc;
     if constexpr (TAG == SPMM_TAG_BUFFER) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0xffffffff, 0x00020000);
-    // structured: record = one row of B (stride bytes), num_records = rows of B (range check: index < records, offset + 16 <= stride)
-    if constexpr (TAG == SPMM_TAG_STRUCT)
-        b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, (short)(b_rs * (int64_t)sizeof(T)), (int)b_rows, 0x00020000);
 
     for (int64_t j0 = jlo; j0 < jhi; j0 += (int64_t)LPN * V) {
         const int64_t jc = j0 + (int64_t)li * V;  // first column of this lane
@@ -261,13 +259,6 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
                         u32x4 r;
                         if (nz[u].c < 0) r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 2);  // nt
                         else r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 0);
-                        b[u] = __builtin_bit_cast(vec<T, V>, r);
-                    } else if constexpr (TAG == SPMM_TAG_STRUCT) {
-                        const int32_t cidx = nz[u].c & 0x7fffffff;
-                        const int boff = (int)((col_ok ? jc : jlo) * (int64_t)sizeof(T));
-                        u32x4 r;
-                        if (nz[u].c < 0) r = mi_struct_buffer_load_b128(b_rsrc, cidx, boff, 0, 2);  // nt
-                        else r = mi_struct_buffer_load_b128(b_rsrc, cidx, boff, 0, 0);
                         b[u] = __builtin_bit_cast(vec<T, V>, r);
                     } else {
                         const T* src = bcol + (int64_t)nz[u].c * b_rs;
@@ -796,14 +787,10 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
     MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz, \
                    (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,                                      \
                    (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,      \
-                   c_cs, N, alpha, beta, beta_zero, carry_val, slices, m.cols)
+                   c_cs, N, alpha, beta, beta_zero, carry_val, slices)
     if constexpr (V * sizeof(T) == 16) {
         if (tag_mode == SPMM_TAG_BUFFER) {
             MI_SPMM_LAUNCH(SPMM_TAG_BUFFER, p.col_tagged.as<int32_t>());
-            return;
-        }
-        if (tag_mode == SPMM_TAG_STRUCT) {
-            MI_SPMM_LAUNCH(SPMM_TAG_STRUCT, p.col_tagged.as<int32_t>());
             return;
         }
     }
@@ -906,14 +893,8 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         plan_after_product(h, transposed, m, hot_rows);
         return;
     }
-    // tagged (hot / cold) gather: raw buffer loads while 32-bit byte offsets reach all of B, structured ones beyond
-    // (row stride below 16 KiB); wider rows of a > 4 GiB operand gather untagged
-    const bool raw_ok = dense_bytes_below_4g(m.cols, ldb, sizeof(T));
-    const bool struct_ok = ldb * (int64_t)sizeof(T) <= 16383 && m.cols <= 0x7fffffff;
-    const int tag_mode = !(p.tagged && vec_ok)                              ? SPMM_TAG_NONE
-                         : (raw_ok && !(options().spmm_tag_struct && struct_ok)) ? SPMM_TAG_BUFFER
-                         : struct_ok                                         ? SPMM_TAG_STRUCT
-                                                                             : SPMM_TAG_NONE;
+    // tagged (hot / cold) gather: raw buffer loads, i.e. 32-bit byte offsets must reach all of B
+    const int tag_mode = (p.tagged && vec_ok && dense_bytes_below_4g(m.cols, ldb, sizeof(T))) ? SPMM_TAG_BUFFER : SPMM_TAG_NONE;
     counters().spmm_last_tagged = (double)tag_mode;
     counters().spmm_hot_coverage = p.hot_coverage;
     if (!vec_ok) slices = 1;

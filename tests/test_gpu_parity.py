@@ -116,15 +116,10 @@ def test_spmm_hot_cold_tagged_gather(gpu, oracle, dtype, n):
         tagged = gpu.dot_product_mkl(a, b)
         assert gpu.mi_get_counter("spmm_last_tagged") == 1.0
         assert 0.0 < gpu.mi_get_counter("spmm_hot_coverage") < 1.0
-        gpu.mi_set_option("spmm_tag_struct", 1)  # the structured-buffer flavour (operands beyond 4 GiB), forced
-        tagged_struct = gpu.dot_product_mkl(a, b)
-        assert gpu.mi_get_counter("spmm_last_tagged") == 2.0
     finally:
         gpu.mi_set_option("spmm_hot_force", 0)
         gpu.mi_set_option("spmm_hot_kb", 8192)
-        gpu.mi_set_option("spmm_tag_struct", 0)
     assert np.array_equal(tagged, plain)  # cache policy must not change a single bit
-    assert np.array_equal(tagged_struct, plain)
     assert rel_err(tagged, oracle.spmm(a.astype(wide), b.astype(wide))) <= tol(dtype)
 
 
@@ -1196,13 +1191,10 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
             return h
         h = mk(ip, idx, val)
         one, zero = (ct.c_float(1.0), ct.c_float(0.0)) if dtype == np.float32 else (ct.c_double(1.0), ct.c_double(0.0))
-        # (sliced, tile KiB, persistent, rowtiles): rowtiles = one workgroup walks all tiles of an output row
-        # cluster = workgroups per cluster pulling tiles from a queue (0: static tile order)
-        for sliced, tile_kb, persistent, rowtiles, cluster in ((2, 128, -1, 1, 8), (2, 64, 4, 1, 8), (2, 128, -1, 0, 8), (2, 64, 4, 0, 4),
-                                                               (2, 128, 1, 0, 0), (2, 128, 0, 0, 8), (0, 128, -1, 0, 8), (0, 64, 1, 0, 8),
-                                                               (1, 128, -1, 0, 16)):
-            gpu.mi_set_option("gram_cluster", cluster)
-            gpu.mi_set_option("gram_rowtiles", rowtiles)
+        # (sliced, tile KiB, persistent): sliced 2 = the pipelined slice walk, 0 = the whole-row walk; persistent = workgroups
+        # per LDS slot walking the tile list (0: one workgroup per tile, -1: default)
+        for sliced, tile_kb, persistent in ((2, 128, -1), (2, 64, 4), (2, 64, -1), (2, 128, 1), (2, 128, 0), (2, 64, 0),
+                                            (0, 128, -1), (0, 64, 1), (1, 128, -1)):
             gpu.mi_set_option("gram_sliced", sliced)
             gpu.mi_set_option("gram_tile_kb", tile_kb)
             gpu.mi_set_option("gram_persistent", persistent)
@@ -1214,8 +1206,6 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         gpu.mi_set_option("gram_sliced", 2)
         gpu.mi_set_option("gram_tile_kb", 128)
         gpu.mi_set_option("gram_persistent", -1)
-        gpu.mi_set_option("gram_rowtiles", 0)
-        gpu.mi_set_option("gram_cluster", 8)   # the band through the cluster queue
         # a band of output rows that starts inside a tile
         r0, r1 = 20001, 20001 + 4099
         band = torch.full((r1 - r0, n), -7.0, device=dev, dtype=tdt)
@@ -1259,8 +1249,6 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         gpu.mi_set_option("gram_sliced", 1)
         gpu.mi_set_option("gram_tile_kb", 128)
         gpu.mi_set_option("gram_persistent", -1)
-        gpu.mi_set_option("gram_rowtiles", 0)
-        gpu.mi_set_option("gram_cluster", 0)
         for h in handles:
             MI.call("mi_sparse_destroy", h)
         gpu.mi_set_stream(0)

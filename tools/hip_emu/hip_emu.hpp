@@ -308,14 +308,6 @@ inline mi_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, 
     std::memcpy(&v, r.base + voff + soff, 16);
     return v;
 }
-inline mi_u32x4 mi_struct_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int vindex, int voffset, int soff, int)
-{
-    mi_u32x4 v = {0u, 0u, 0u, 0u};
-    if ((unsigned)vindex >= r.num_records || (unsigned)voffset + 16u > r.stride) return v;  // structured: records are rows
-    std::memcpy(&v, r.base + (unsigned long long)(unsigned)vindex * r.stride + (unsigned)voffset + (unsigned)soff, 16);
-    return v;
-}
-
 // matrix-core instructions: every lane publishes its A / B operand, then computes the accumulator
 // registers it owns (fragment layouts: csrc/dense.hip header comment)
 typedef float mi_f32x16 __attribute__((vector_size(64)));

@@ -3,7 +3,7 @@
 
     python tools/spmm_sweep.py [--workload rmat|uniform] [--launches K] [--variants "S:hot_kb:chunk,..."]
 
-Every variant = spmm_slices:spmm_hot_kb:spmm_chunk[:option=value ...] (any mi_set_option knob, e.g. spmm_tag_struct=1).  For each one the plan is rebuilt (untimed), the
+Every variant = spmm_slices:spmm_hot_kb:spmm_chunk[:option=value ...] (any mi_set_option knob, e.g. spmm_unroll=8).  For each one the plan is rebuilt (untimed), the
 product is checked against the first variant's result, and K launches are timed with the hipEvents the
 library records around the main kernel (profile_events).  Under `rocprofv3 --kernel-trace --pmc ...` the same
 script gives per-dispatch counters: the k_spmm dispatches appear in the order printed here, K + 1 per
