@@ -268,6 +268,53 @@ def measured_copy_gbs(torch, dev):
     return best
 
 
+def measure_traffic_live(timeout_s=150):
+    """HBM bytes per launch of the dominant SpMM kernel from rocprofv3 PMC counters, collected NOW: two separate
+    `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE, WRITE_SIZE -- MI355X_MICROARCH.md, HBM section) over
+    tools/spmm_sweep.py, which launches this very configuration (same generator, seeds, library defaults) in a child
+    process.  gfx950 corrections as the guide prescribes: FETCH_SIZE (KB) x 2 for wide coalesced reads, WRITE_SIZE (KB)
+    as is.  Returns (bytes, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    launches = 3
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "spmm_sweep.py"), "--launches", str(launches), "--variants", "0:8192:256",
+                   "--adopt-tags"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            acc = defaultdict(float)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_spmm<" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        acc[int(row["Dispatch_Id"])] += float(row["Counter_Value"])
+            ids = sorted(acc)
+            if len(ids) < launches:
+                return None, "no k_spmm dispatches in the %s pass" % counter
+            tail = ids[-launches:]  # the timed launches (the warm-up / plan launches come first)
+            out[counter] = sum(acc[k] for k in tail) / len(tail)
+        nbytes = out["FETCH_SIZE"] * 1024.0 * 2.0 + out["WRITE_SIZE"] * 1024.0
+        return nbytes, ("rocprofv3 --pmc, two passes in this run: FETCH_SIZE %.0f KB x 2 (gfx950 correction) + WRITE_SIZE %.0f KB, "
+                        "mean of the last %d k_spmm launches" % (out["FETCH_SIZE"], out["WRITE_SIZE"], launches))
+    except Exception as exc:  # noqa: BLE001
+        return None, "%s: %s" % (type(exc).__name__, str(exc)[:200])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def load_traffic(name):
     """HBM bytes per launch from this round's committed PMC summary (separate rocprofv3 --pmc passes; the counters
     cannot be collected from inside this process)."""
@@ -359,6 +406,28 @@ def secondary_spgemm(torch, abi, dev, kind, with_cpu):
                                 "all phases: upper bounds, binning, symbolic, scan, numeric)" % reps},
            "parity_rowsum_max_rel_err": rel}
     assert rel <= 1e-12, "SpGEMM row-sum parity check failed: %g" % rel
+    out["first_call_note"] = ("first_call_ms is the first product in THIS process, after earlier workloads returned large blocks to the "
+                              "driver: a block that was hipFree'd and is allocated again costs seconds on this driver "
+                              "(tools/probes/alloc_probe.hip); first_call_fresh_process is what a one-shot caller pays")
+    if kind == "rmat":
+        for h in (ha, hb, hc):
+            abi.destroy(h)
+        ha = hb = hc = None
+        del a, b, av, bv, b1, ab1, c1, ones, colnnz_a, rownnz_b
+        abi.sda.mi_set_option("pool_trim", 1)
+        torch.cuda.empty_cache()
+        try:  # the same product as the first thing a fresh process does (tools/gpu_first_call.py)
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_first_call.py")], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, timeout=300)
+            lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+            out["first_call_fresh_process"] = json.loads(lines[-1]) if lines else {"error": "no output (rc %d)" % r.returncode}
+        except Exception as exc:  # noqa: BLE001
+            out["first_call_fresh_process"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+        if with_cpu:
+            out["cpu_baseline"] = {"value": None, "note": "nnz(C) = %d exceeds MKL's LP64 index range and the reference's "
+                                                          "INT_MAX guard (_common.py:166-172): not runnable on the CPU path" % nnzc}
+        return out
     if with_cpu and nnzc < 2**31 - 1:
         import scipy.sparse as sps
         ah = sps.csr_matrix((av.cpu().numpy(), a[1].cpu().numpy(), a[0].cpu().numpy()), shape=(n, n))
@@ -643,6 +712,7 @@ def main():
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--ncols", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 in this run (use the committed summary)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--secondary", default="all", help="comma list of: uniform,spgemm,spgemm_rmat,gram,host_api (default all)")
     ap.add_argument("--gather-mode", default="bcast", choices=["bcast", "padded", "p2p"])
@@ -808,14 +878,19 @@ def main():
     blk_nnz, blk_rows = res["block_nnz"], res["block_rows"]
     alg_bytes = blk_nnz * 8 + (blk_rows + 1) * 8 + n * N * 4 + blk_rows * N * 4  # this rank's launch
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    kernel_name = sda.mi_get_last_kernel()  # what the library launched (not what this script expects)
     traffic, traffic_src = (None, None)
     if world == 1 and args.workload == "rmat" and N == 128 and args.scale == 20:
-        traffic, traffic_src = load_traffic("spmm_traffic.json")
-    lpn = max(4, min(64, (N // slices) // 4))
+        if not args.no_pmc:
+            traffic, traffic_src = measure_traffic_live()
+        if traffic is None:
+            why = traffic_src
+            traffic, traffic_src = load_traffic("spmm_traffic.json")
+            if traffic_src and why:
+                traffic_src += " (committed PMC summary; live collection unavailable: %s)" % why
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "k_spmm<float,4,%d,%d,%s> x %d column slices" % (lpn, args.unroll or 4, "true" if tagged else "false", slices),
-                "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes}
+                "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes}
     if world == 1:
         copy_gbs = measured_copy_gbs(torch, dev)
         roofline["measured_copy_GBps"] = round(copy_gbs, 1)

@@ -489,6 +489,10 @@ mi_sparse_status_t mi_sparse_set_option(const char *name, int64_t value);
  * "spmm_kernel_ms" (sum of durations) and "spmm_kernel_launches"; "reset" (any value pointer)
  * zeroes them.  Unknown names return INVALID_VALUE. */
 mi_sparse_status_t mi_sparse_get_counter(const char *name, double *value);
+/* Name of the dominant kernel the calling thread launched last, as the library instantiated it -- e.g.
+ * "mi::k_spmm<float, V=4, LPN=16, U=4, TAG=1> x 2 column slices" -- so that measurement tools report what ran rather
+ * than what they expect to have run.  Empty string before the first launch. */
+mi_sparse_status_t mi_sparse_get_last_kernel(char *buf, int len);
 
 #ifdef __cplusplus
 }

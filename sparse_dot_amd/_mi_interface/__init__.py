@@ -64,6 +64,13 @@ def mi_get_counter(name):
     return v.value
 
 
+def mi_get_last_kernel():
+    """Name of the dominant kernel this thread launched last, as the library instantiated it."""
+    buf = _ct.create_string_buffer(256)
+    _check_return_value(MI.call("mi_sparse_get_last_kernel", buf, 256), "mi_sparse_get_last_kernel")
+    return buf.value.decode()
+
+
 def mi_interface_integer_dtype():
     """Index dtype of results built from int32 inputs (int64 inputs / huge results give int64)."""
     return _np.int32

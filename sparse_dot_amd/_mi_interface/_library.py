@@ -153,6 +153,7 @@ def _bind(lib):
     add("mi_sparse_last_error", [], _ct.c_char_p)
     add("mi_sparse_set_option", [_ct.c_char_p, _i64])
     add("mi_sparse_get_counter", [_ct.c_char_p, _ct.POINTER(_ct.c_double)])
+    add("mi_sparse_get_last_kernel", [_ct.c_char_p, _int])
     return table
 
 

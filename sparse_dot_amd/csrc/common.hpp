@@ -142,6 +142,14 @@ struct alignas(V * sizeof(T) >= 16 ? 16 : V * sizeof(T)) vec {
     T v[V];
 };
 
+// one sparse entry as a record -- column + value side by side, so that ONE 8-byte (float) / 16-byte (double, complex
+// float) load or LDS read fetches both.  Staged nonzeros of A in the SpMM kernel; packed copy of X for the dense gram.
+template <typename T>
+struct alignas(sizeof(T) >= 16 ? 16 : 8) SpEntry {
+    int32_t c;
+    T v;
+};
+
 // streaming (touched-once) loads: non-temporal for the types the builtin takes, plain for the complex structs
 template <typename T>
 __device__ __forceinline__ T nt_load(const T* p)
@@ -337,10 +345,13 @@ struct Csr {
     DevBuf ptr_own, col_own, val_own;  // storage when the library owns it (else aliases caller HBM)
     bool valid = false;
     bool sorted = false;  // column indices known to be ascending inside every row
-    // dense gram (gram.hip): entries of every row left of each tile boundary, int32[rows * (cols / w + 2)], built on first
+    // dense gram (gram.hip): ABSOLUTE position of the first entry of every row at or right of each tile boundary, int32[rows * (cols / w + 2)], built on first
     // use for tile width gram_off_w (structure only: unaffected by set_values)
     DevBuf gram_off;
     int64_t gram_off_w = 0;
+    // dense gram, sliced walk: packed (column, value) records of every entry in storage order (SpEntry<T>[nnz]); follows
+    // the VALUES, so mi_sparse_?_set_values and mi_sparse_order drop it
+    DevBuf gram_rec;
 };
 
 // block form kept next to the CSR expansion on handles created from BSR arrays: the SpMM block kernel (bsr.hip) reads it
@@ -494,6 +505,13 @@ struct Counters {
     double bsr_native_calls = 0.0;    // products served by the BSR block kernel
 };
 Counters& counters();  // per host thread
+void note_kernel(const char* fmt, ...);
+const char* last_kernel_name();  // records the dominant kernel of the current call (mi_sparse_get_last_kernel)
+template <typename T>
+inline const char* type_name()
+{
+    return type_char<T>::value == 's' ? "float" : type_char<T>::value == 'd' ? "double" : type_char<T>::value == 'c' ? "cfloat" : "cdouble";
+}
 
 // bsr.hip
 template <typename T>

@@ -152,20 +152,22 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
 
 // ---- sliced variant (rows of X sorted): the default ------------------------------------------------------------
 // The tiles lie on a GLOBAL grid (tile g = columns [g * TILE, (g + 1) * TILE); the tile holding the diagonal is cut at
-// column i) and a table gives, for every row r of X and every tile boundary, how many of the row's entries lie left of
-// it: the part of row r that falls into tile g is the contiguous slice [off[r][g], off[r][g + 1]).  A wave takes 64
-// selected rows at a time (lane = row: the entry of X^T, the row start, the two offsets), then EIGHT LANES walk each
-// row's slice, eight rows per step.
+// column i).  A wave takes 64 selected rows at a time (lane = row), then EIGHT LANES walk each row's slice, eight rows
+// per step, all steps' loads issued before the first LDS atomic.
 //
-// Round 3: the tile loop is a SOFTWARE PIPELINE four tiles deep.  A tile workgroup owns the LDS of its CU, so nothing
-// else hides its memory latency, and on gfx950 a wave's loads and stores retire through ONE in-order counter (vmcnt):
-// a load issued after the 128 KiB write-out of the previous tile is not seen complete before those stores have
-// drained.  Round 2's loop (zero | chain | walk | barrier | write-out) therefore paid, per tile, the store drain PLUS
-// the dependent chain  row pointer of X^T -> (r, X[r,i]) -> row start + slice offsets -> slice entries  (measured
-// 23 us per tile against 6.7 us of write bandwidth).  Now every load of the chain is issued in one burst right after
-// the barrier that ends a tile's accumulation and BEFORE that tile's stores:
-//     slice entries of tile k+1 | offsets of tile k+2 | entries of X^T for tile k+3 | row pointer for tile k+4
-// and each level is consumed one full tile later.  The write-out re-zeroes the tile as it reads it (no zeroing pass).
+// What the kernel is made of is L2 / HBM LINE REQUESTS, not bytes (profiles/r03_fetch_size_calibration.log: a gather
+// from beyond the caches costs a 128-byte line fill however few bytes it uses; counters of round 2's kernel at the
+// literal configs[3]: 4.8 k L2 read requests per tile -- per selected row one line each for its row pointer, its
+// slice offsets, its column indices and its values -- 2.2e9 of them reaching HBM = 284 GB for a 2 GB matrix).  Round 3
+// lays the data out so that a (row, tile) pair costs TWO lines instead of four:
+//   * `off[r][g]` holds ABSOLUTE positions (row start + entries left of tile boundary g): no load of the row pointer;
+//   * the entries of X are read from a packed copy of (column, value) RECORDS (SpEntry<T>, 8 bytes for float): a slice
+//     of 8 entries is one 64-byte run in one array instead of 32 + 32 bytes in two.
+// Both are built once per handle (k_gram_offsets, k_gram_pack) and cached on it.
+// The tile loop prefetches the dependent chain  row pointer of X^T -> (r, X[r,i]) -> slice offsets  three tiles deep
+// (one level per tile, all loads of a tile's burst issued together after the barrier that ends the accumulation), and
+// the write-out re-zeroes the tile as it reads it.  Requesting the slice ENTRIES a tile ahead as well was measured
+// 17 % slower (124 vs 106 ms, profiles/r03_gram_variants.log) and is not done.
 __global__ void k_gram_offsets(int64_t rows, int64_t G, int64_t w, const int64_t* __restrict__ xptr,
                                const int32_t* __restrict__ xcol, int32_t* __restrict__ off)
 {
@@ -173,13 +175,23 @@ __global__ void k_gram_offsets(int64_t rows, int64_t G, int64_t w, const int64_t
     if (t >= rows * (G + 1)) return;
     const int64_t r = t / (G + 1), g = t - r * (G + 1);
     int64_t lo = xptr[r], hi = xptr[r + 1];
-    const int64_t b0 = lo;
     const int64_t key = g * w;  // first position with column >= key (g == G: past every column)
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
         if ((int64_t)xcol[mid] < key) lo = mid + 1; else hi = mid;
     }
-    off[t] = (int32_t)(lo - b0);
+    off[t] = (int32_t)lo;  // absolute (the sliced walk is only chosen for nnz < 2^31)
+}
+
+template <typename T>
+__global__ void k_gram_pack(int64_t nnz, const int32_t* __restrict__ col, const T* __restrict__ val, SpEntry<T>* __restrict__ rec)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        SpEntry<T> e;
+        e.c = col[k];
+        e.v = val[k];
+        rec[k] = e;
+    }
 }
 
 // Finished tile -> C, and the tile back to zero (every element a thread reads it also clears).
@@ -218,23 +230,25 @@ __device__ __forceinline__ void syrkd_flush_tile(T* acc, T* crow, int64_t c_cs, 
     }
 }
 
-template <typename T, int TKB, bool TABLE>  // TABLE: several tiles per row -> slice offsets from `off`; else the slice is the row
+template <typename T, int TKB, bool TABLE>  // TABLE: several tiles per row -> slice bounds from `off`; else the slice is the row
 __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     k_syrkd_sliced(int64_t n, int64_t row0, int64_t row_end, int64_t G, const int64_t* __restrict__ tptr,
                    const int32_t* __restrict__ tcol, const T* __restrict__ tval, const int64_t* __restrict__ xptr,
-                   const int32_t* __restrict__ xcol, const T* __restrict__ xval, const int32_t* __restrict__ off,
-                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual)
+                   const SpEntry<T>* __restrict__ rec, const int32_t* __restrict__ off, T* __restrict__ C, int64_t c_rs,
+                   int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual)
 {
     constexpr int TILE = syrkd_tile<T, TKB>();
     constexpr int SUB = 8;            // lanes per selected row
     constexpr int RPS = WAVE / SUB;   // rows per step
     constexpr int NSTEP = WAVE / RPS; // steps per 64 rows, all in flight together
+    constexpr int HH = sizeof(T) <= 4 ? 2 : 1;  // halves of SUB entries requested together (registers: 8-byte values get one)
     __shared__ T acc[TILE];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid / WAVE, lane = tid % WAVE, nwaves = nthreads / WAVE;
     const int sub = lane % SUB, grp = lane / SUB;
     // list position -> (output row, tile); the positions left of the diagonal / past the row block hold nothing.
-    // Workgroup b runs on XCD b % 8 (observed; speed only): all tiles of one output row go to the SAME XCD back to back.
+    // Workgroup b runs on XCD b % 8 (observed; speed only): all tiles of one output row go to the SAME XCD back to back, so
+    // the lines of X that the row's nonzeros select are fetched from HBM once and then served by that XCD's L2.
     struct Pos {
         int64_t i, g, vb;
         bool ok;
@@ -264,7 +278,7 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         int64_t t0, t1;   // A: extent of column i in X^T
         int32_t r;        // B: lane = selected row
         T a;
-        int64_t s;        // C: start of the row's slice in this tile ...
+        int32_t s;        // C: start of the row's slice in this tile (absolute position in `rec`) ...
         int32_t len;      //    ... and its length (0 for lanes past the end / positions that hold nothing)
     };
     auto stage_a = [&](const Pos& p, Head& h) {
@@ -281,89 +295,71 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     auto stage_c = [&](int64_t g, Head& h) {
         const int64_t base = h.t0 + (int64_t)wave * WAVE;
         const bool valid = base + lane < h.t1;
-        const int64_t xb = xptr[h.r];
-        // (a run-time branch on `off` around these loads made the compiler drain vmcnt to 0 at the join -- right after
-        // the burst of slice loads: hence the template flag)
+        // (a run-time branch on `off` around these loads made the compiler drain vmcnt to 0 at the join: a template flag)
+        int64_t o0, o1;
         if constexpr (TABLE) {
             const int32_t* orow = off + (int64_t)h.r * (G + 1) + g;
-            const int32_t o0 = orow[0], o1 = orow[1];
-            h.s = xb + o0;
-            h.len = valid ? o1 - o0 : 0;
+            o0 = orow[0];
+            o1 = orow[1];
         } else {
-            h.s = xb;
-            h.len = valid ? (int32_t)(xptr[h.r + 1] - xb) : 0;
+            o0 = xptr[h.r];
+            o1 = xptr[h.r + 1];
         }
+        h.s = (int32_t)o0;
+        h.len = valid ? (int32_t)(o1 - o0) : 0;
     };
-    // entries sub (and sub + SUB) of every row's slice, all NSTEP steps: 2 HH NSTEP loads per lane, issued together, none
-    // of them touched before `accumulate` (masked lanes read entry 0)
-    constexpr int HH = sizeof(T) <= 4 ? 2 : 1;  // halves of SUB entries requested ahead (registers: 8-byte values get one)
-    struct Slices {
-        int32_t jv[HH][NSTEP];
-        T xv[HH][NSTEP];
-    };
-    auto load_slices = [&](const Head& h, Slices& S) {
-#pragma unroll
-        for (int k = 0; k < NSTEP; ++k) {
-            const int src = k * RPS + grp;
-            const int64_t sk = __shfl(h.s, src);
-            const int32_t ln = __shfl(h.len, src);
-#pragma unroll
-            for (int hh = 0; hh < HH; ++hh) {
-                const int64_t qq = sub + hh * SUB < ln ? sk + sub + hh * SUB : 0;
-                S.jv[hh][k] = xcol[qq];
-                S.xv[hh][k] = xval[qq];
-            }
-        }
-    };
-    auto accumulate = [&](const Slices& S, const Head& h, int64_t j_lo, int64_t tile_lo) {
-        int32_t ln[NSTEP];
-        int64_t sk[NSTEP];
+    // one tile's share of 64 selected rows: entries sub (and sub + SUB) of every row's slice for all NSTEP steps are loaded
+    // before the first LDS atomic (masked lanes read record 0)
+    auto walk64 = [&](const Head& h, int64_t j_lo, int64_t tile_lo) {
+        int32_t ln[NSTEP], sk[NSTEP];
         T av[NSTEP];
+        SpEntry<T> e[HH][NSTEP];
 #pragma unroll
         for (int k = 0; k < NSTEP; ++k) {
             const int src = k * RPS + grp;
+            sk[k] = __shfl(h.s, src);
             ln[k] = __shfl(h.len, src);
             av[k] = __shfl(h.a, src);
-            sk[k] = __shfl(h.s, src);
+#pragma unroll
+            for (int hh = 0; hh < HH; ++hh) e[hh][k] = rec[sub + hh * SUB < ln[k] ? sk[k] + sub + hh * SUB : 0];
         }
 #pragma unroll
         for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
             for (int k = 0; k < NSTEP; ++k)
-                if (sub + hh * SUB < ln[k] && S.jv[hh][k] >= j_lo)
-                    atomic_accum(&acc[S.jv[hh][k] - tile_lo], vt<T>::mul(av[k], S.xv[hh][k]));
+                if (sub + hh * SUB < ln[k] && e[hh][k].c >= j_lo)
+                    atomic_accum(&acc[e[hh][k].c - tile_lo], vt<T>::mul(av[k], e[hh][k].v));
 #pragma unroll
         for (int k = 0; k < NSTEP; ++k) {  // slices longer than HH * SUB entries
-            for (int e = sub + HH * SUB; e < ln[k]; e += SUB) {
-                const int64_t j = xcol[sk[k] + e];
-                if (j >= j_lo) atomic_accum(&acc[j - tile_lo], vt<T>::mul(av[k], xval[sk[k] + e]));
+            for (int q = sub + HH * SUB; q < ln[k]; q += SUB) {
+                const SpEntry<T> x = rec[sk[k] + q];
+                if (x.c >= j_lo) atomic_accum(&acc[x.c - tile_lo], vt<T>::mul(av[k], x.v));
             }
         }
     };
 
     // ---- prologue: fill the pipeline (blocking chains, once per workgroup) ----
-    Pos p0 = seek(blockIdx.x), p1 = after(p0), p2 = after(p1), p3 = after(p2), p4 = after(p3);
-    Head h0, h1, h2, h3, h4;
+    Pos p0 = seek(blockIdx.x), p1 = after(p0), p2 = after(p1), p3 = after(p2);
+    Head h0, h1, h2, h3;
     stage_a(p0, h0);
     stage_b(h0);
     stage_c(p0.g, h0);
     stage_a(p1, h1);
     stage_b(h1);
-    stage_c(p1.g, h1);
     stage_a(p2, h2);
-    stage_b(h2);
-    stage_a(p3, h3);
     for (int k = tid; k < TILE; k += nthreads) acc[k] = vt<T>::zero();
-    Slices S;
-    load_slices(h0, S);
     __syncthreads();
     while (p0.ok) {
         const int64_t i = p0.i, g = p0.g;
         const int64_t tile_lo = g * TILE;
         const int64_t j_lo = i > tile_lo ? i : tile_lo;
         const int64_t j_hi = tile_lo + TILE < n ? tile_lo + TILE : n;
-        // (1) this tile's products into LDS: its slice entries were requested one tile ago, before that tile's stores
-        accumulate(S, h0, j_lo, tile_lo);
+        // (1) the chain of the tiles ahead, one level each: issued together, consumed one tile later
+        stage_c(p1.g, h1);
+        stage_b(h2);
+        stage_a(p3, h3);
+        // (2) this tile's products into LDS
+        walk64(h0, j_lo, tile_lo);
         for (int64_t base = h0.t0 + (int64_t)(wave + nwaves) * WAVE; base < h0.t1; base += (int64_t)nwaves * WAVE) {
             // further rows of a long list (more than 64 * nwaves nonzeros in column i): fetched here, the chain exposed
             Head h;
@@ -371,27 +367,19 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
             h.t1 = h0.t1;
             stage_b(h);
             stage_c(g, h);
-            Slices S2;
-            load_slices(h, S2);
-            accumulate(S2, h, j_lo, tile_lo);
+            walk64(h, j_lo, tile_lo);
         }
         __syncthreads();
-        // (2) one burst of loads for the tiles ahead, THEN this tile's stores
-        load_slices(h1, S);
-        stage_c(p2.g, h2);
-        stage_b(h3);
-        stage_a(p4, h4);
+        // (3) the finished tile out, and back to zero
         syrkd_flush_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, tile_lo, beta, beta_zero, tid, nthreads);
-        __syncthreads();  // the tile is zero again
+        __syncthreads();
         p0 = p1;
         p1 = p2;
         p2 = p3;
-        p3 = p4;
-        p4 = after(p4);
+        p3 = after(p3);
         h0 = h1;
         h1 = h2;
         h2 = h3;
-        h3 = h4;
     }
 }
 
@@ -443,6 +431,7 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         if (sliced && !x.sorted) {
             if (rows_sorted(x)) x.sorted = true; else sliced = false;
         }
+        if (x.nnz >= ((int64_t)1 << 31) - 64) sliced = false;  // 32-bit absolute positions in the slice table
         const size_t need = sizeof(int32_t) * (size_t)x.rows * (size_t)(tiles_per_row + 1);
         if (need > ((size_t)16 << 30)) sliced = false;  // slice table out of proportion (very tall X, very wide output)
         // persistent grid: gram_persistent workgroups per LDS slot (one 128 KiB or two 64 KiB tiles per CU), a multiple of 8
@@ -468,13 +457,26 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
             }
             off = x.gram_off.as<int32_t>();
         }
+        const SpEntry<T>* rec = nullptr;
+        if (sliced) {  // packed (column, value) records of X, cached on the handle
+            if (!x.gram_rec.p) {
+                x.gram_rec.alloc(sizeof(SpEntry<T>) * (size_t)x.nnz);
+                const int64_t pg = ceil_div(x.nnz, 256) < 65536 ? ceil_div(x.nnz, 256) : 65536;
+                MI_LAUNCH((k_gram_pack<T>), dim3((unsigned)pg), dim3(256), c.stream, x.nnz, (const int32_t*)x.col, (const T*)x.val,
+                          x.gram_rec.as<SpEntry<T>>());
+            }
+            rec = x.gram_rec.as<SpEntry<T>>();
+        }
 #define MI_SYRKD_ARGS                                                                                               \
     (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, (const int32_t*)x.col,   \
         (const T*)x.val
+        note_kernel("mi::%s<%s, TKB=%d%s>", sliced ? "k_syrkd_sliced" : "k_syrkd_lds", type_name<T>(), wide ? 128 : 64,
+                    sliced ? (off ? ", TABLE=1" : ", TABLE=0") : "");
         if (sliced) {
 #define MI_SLICED(TKB_, TABLE_, THREADS_)                                                                              \
     MI_LAUNCH((k_syrkd_sliced<T, TKB_, TABLE_>), dim3((unsigned)grid), dim3(THREADS_), c.stream, n, row0, row1,          \
-              tiles_per_row, MI_SYRKD_ARGS, off, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks)
+              tiles_per_row, (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, rec, off, dC,   \
+              c_rs, c_cs, alpha, beta, beta_zero, nblocks)
             if (wide) {
                 if (off) MI_SLICED(128, true, 1024); else MI_SLICED(128, false, 1024);
             } else {

@@ -406,6 +406,9 @@ bool rows_sorted(const Csr& a)
 
 void sort_csr(char vtype, Csr& a)
 {
+    a.gram_rec.release();  // caches that follow the storage order of the entries (dense gram)
+    a.gram_off.release();
+    a.gram_off_w = 0;
     // already sorted? (scipy's canonical matrices are)
     if (rows_sorted(a)) {
         a.sorted = true;

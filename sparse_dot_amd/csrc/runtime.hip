@@ -566,6 +566,16 @@ Counters& counters()
     return c;
 }
 
+static thread_local char t_last_kernel[192] = "";
+void note_kernel(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_last_kernel, sizeof t_last_kernel, fmt, ap);
+    va_end(ap);
+}
+const char* last_kernel_name() { return t_last_kernel; }
+
 // ---- exclusive scan ----------------------------------------------------------------------------
 // Three-kernel scan: per-block sums -> single-block scan of the sums -> add back.  n is at most a
 // few tens of millions (row counts), so this is never the bottleneck.
@@ -817,6 +827,14 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
         } else {
             mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown option '%s'", name);
         }
+    });
+}
+
+mi_sparse_status_t mi_sparse_get_last_kernel(char* buf, int len)
+{
+    return mi::guarded([&] {
+        if (!buf || len <= 0) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL buffer");
+        snprintf(buf, (size_t)len, "%s", mi::last_kernel_name());
     });
 }
 

@@ -1809,7 +1809,8 @@ static int set_values_generic(mi_sparse_matrix_t A, const T* values)
             else
                 copy_h2d(primary.val, values, sizeof(T) * (size_t)primary.nnz);
         }
-        // the derived representation (and nothing else: plans depend on the pattern only) is stale
+        // the derived representation and the packed records of the dense gram (nothing else: plans depend on the pattern only) are stale
+        primary.gram_rec.release();
         Csr& other = created_csc ? h->csr : h->csrT;
         other = Csr();
         c.sync();

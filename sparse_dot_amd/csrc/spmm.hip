@@ -96,14 +96,6 @@ __global__ void k_spmm_plan_tasks(const int64_t* ptr, const int32_t* chunk_row, 
     tasks[3 * t + 2] = (int32_t)last;
 }
 
-// one staged nonzero of A: column + value side by side so a lane group fetches both with ONE
-// LDS read (ds_read_b64 for float, ds_read_b128 for double / complex float)
-template <typename T>
-struct alignas(sizeof(T) >= 16 ? 16 : (sizeof(T) == 8 ? 8 : 8)) SpEntry {
-    int32_t c;
-    T v;
-};
-
 // LDS bytes one wave needs for a chunk of CH items
 template <typename T>
 __host__ __device__ constexpr size_t spmm_wave_lds(int ch)
@@ -783,6 +775,8 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
     unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
     if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
+    note_kernel("mi::k_spmm<%s, V=%d, LPN=%d, U=%d, TAG=%d> x %d column slice%s", type_name<T>(), V, LPN, U,
+                (V * sizeof(T) == 16) ? tag_mode : 0, slices, slices > 1 ? "s" : "");
 #define MI_SPMM_LAUNCH(TAGMODE, COLS)                                                                                  \
     MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz, \
                    (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,                                      \
@@ -883,6 +877,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         // SpMV: lanes over nonzeros (k_spmv); same plan, carries and fix-up as the wide kernel
         const size_t pw = ((size_t)(p.chunk + SPMM_SPLIT) * sizeof(T) + (size_t)(p.chunk + 2) * sizeof(int32_t) + 15) & ~size_t(15);
         counters().spmm_last_tagged = 0.0;
+        note_kernel("mi::k_spmv<%s>", type_name<T>());
         MI_LAUNCH_SMEM((k_spmv<T>), dim3((unsigned)ceil_div(p.nchunks, SPMM_WAVES)), dim3(SPMM_WAVES * WAVE),
                        pw * SPMM_WAVES, c.stream, m.rows, m.nnz, (const int64_t*)m.ptr, (const int32_t*)m.col,
                        (const T*)m.val, (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs,

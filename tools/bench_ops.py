@@ -6,6 +6,8 @@ parity checks (the oracle would take minutes to hours at these sizes).
 
     python tools/bench_ops.py spgemm [--scale 20 --per-row 16 --kind uniform|rmat]
     python tools/bench_ops.py gram   [--rows-log2 20 --cols 16384 --per-row 64 --dense]
+    python tools/bench_ops.py bsr    [--rows-log2 18 --block 4 --ncols 128]   BSR x dense: block kernel vs CSR expansion
+    python tools/bench_ops.py sp2m   [--scale 20 --per-row 16]                staged product: full vs numeric-only re-run
 
 Prints one JSON line per run.
 SpGEMM checks:  C 1 == A (B 1)   (row sums, via SpMV on the same library, fp64 1e-12 rel);
@@ -25,7 +27,9 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("op", choices=["spgemm", "gram"])
+    ap.add_argument("op", choices=["spgemm", "gram", "bsr", "sp2m"])
+    ap.add_argument("--block", type=int, default=4, help="bsr: block size")
+    ap.add_argument("--ncols", type=int, default=128, help="bsr: dense columns")
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--per-row", type=int, default=None)
     ap.add_argument("--kind", default="uniform", choices=["uniform", "rmat"])
@@ -92,7 +96,119 @@ def main():
                                     y.data_ptr()), "mv")
 
     out = {"op": args.op}
-    if args.op == "spgemm":
+    if args.op == "bsr":
+        # BSR x dense: 2^rows_log2 block rows, 8 random blocks per block row, bs x bs blocks, fp32,
+        # row-major dense N columns.  The SAME handle through the block kernel (k_bsr_spmm) and through its CSR expansion.
+        bs, N = args.block, args.ncols
+        mb = 1 << args.rows_log2
+        per = args.per_row or 8
+        ipb, idxb, _, _, _ = make("uniform", args.rows_log2, mb, per, 5, torch.float32)
+        nblocks = int(idxb.numel())
+        g = torch.Generator(device=dev)
+        g.manual_seed(6)
+        vals = torch.rand(nblocks * bs * bs, generator=g, device=dev, dtype=torch.float32) + 0.5
+        h = sparse_matrix_t()
+        _check_return_value(MI.call("mi_sparse_s_create_bsr", ct.byref(h), 0, 101, mb, mb, bs, ipb.data_ptr(), ipb.data_ptr() + 4,
+                                    idxb.data_ptr(), vals.data_ptr()), "create_bsr")
+        m = mb * bs
+        B = torch.rand((m, N), generator=g, device=dev, dtype=torch.float32) + 0.5
+        C = torch.empty((m, N), device=dev, dtype=torch.float32)
+        res = {}
+        ref = None
+        for native in (1, 0):
+            sda.mi_set_option("bsr_native", native)
+            sda.mi_get_counter("reset")
+            for _ in range(3):
+                _check_return_value(MI.call("mi_sparse_s_mm", 10, 1.0, h, matrix_descr(), 101, B.data_ptr(), N, N, 0.0, C.data_ptr(), N), "mm")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.reps * 5):
+                _check_return_value(MI.call("mi_sparse_s_mm", 10, 1.0, h, matrix_descr(), 101, B.data_ptr(), N, N, 0.0, C.data_ptr(), N), "mm")
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / (args.reps * 5)
+            used_native = sda.mi_get_counter("bsr_native_calls") > 0
+            assert used_native == bool(native), (native, used_native)
+            if ref is None:
+                ref = C.clone()
+            nnz = nblocks * bs * bs
+            # algorithmic bytes: block form = values + one index per BLOCK; expansion = values + one index per VALUE
+            ab = nnz * 4 + (nblocks * 4 if native else nnz * 4) + (mb + 1) * 8 + 2 * m * N * 4
+            res["block_kernel" if native else "csr_expansion"] = {
+                "ms": round(t * 1e3, 4), "gflops": round(2.0 * nnz * N / t / 1e9, 1), "algorithmic_bytes": ab,
+                "algorithmic_GBps": round(ab / t / 1e9, 1), "frac_of_8TBps": round(ab / t / 1e9 / 8000.0, 4),
+                "max_rel_diff_vs_block_kernel": float(((C - ref).abs() / ref.abs().clamp(min=1e-30)).max())}
+        sda.mi_set_option("bsr_native", 1)
+        # parity of the block kernel: block row sums (B = ones) against the values reduced on the host side of the GPU
+        B.fill_(1.0)
+        _check_return_value(MI.call("mi_sparse_s_mm", 10, 1.0, h, matrix_descr(), 101, B.data_ptr(), N, N, 0.0, C.data_ptr(), N), "mm")
+        torch.cuda.synchronize()
+        blk_rows = torch.repeat_interleave(torch.arange(mb, device=dev), (ipb[1:] - ipb[:-1]).long())
+        want = torch.zeros((mb, bs), device=dev, dtype=torch.float64)
+        want.index_add_(0, blk_rows, vals.view(nblocks, bs, bs).double().sum(2))
+        err = float(((C[:, 0].double().view(mb, bs) - want).abs() / want.clamp(min=1e-30)).max())
+        out.update({"config": "BSR 2^%d x 2^%d block rows, %d blocks/row, %dx%d blocks fp32 x dense %d x %d" % (args.rows_log2, args.rows_log2, per, bs, bs, m, N),
+                    "blocks": nblocks, "nnz": nblocks * bs * bs, **res, "rowsum_max_rel_err": err,
+                    "speedup_block_vs_expansion": round(res["csr_expansion"]["ms"] / res["block_kernel"]["ms"], 3),
+                    "checks": {"rowsum_1e-5": err <= 1e-5, "variants_agree_1e-5": res["csr_expansion"]["max_rel_diff_vs_block_kernel"] <= 1e-5}})
+        MI.call("mi_sparse_destroy", h)
+    elif args.op == "sp2m":
+        # staged product: symbolic + numeric once, then new values on the SAME pattern -> numeric only
+        per_row = args.per_row or 16
+        dt = torch.float64
+        a = make(args.kind, args.scale, 1 << args.scale, per_row, 21 if args.kind == "rmat" else 1, dt)
+        b = make(args.kind, args.scale, 1 << args.scale, per_row, 23 if args.kind == "rmat" else 2, dt)
+        ha = handle("d", *a[:3], a[3], a[4])
+        hb = handle("d", *b[:3], b[3], b[4])
+
+        def sp2m(req, hc):
+            _check_return_value(MI.call("mi_sparse_sp2m", 10, matrix_descr(), ha, 10, matrix_descr(), hb, req, ct.byref(hc)), "sp2m %d" % req)
+        full, count, fin = [], [], []
+        hc = None
+        for rep in range(args.reps + 1):
+            if hc is not None:
+                MI.call("mi_sparse_destroy", hc)
+            hc = sparse_matrix_t()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sp2m(90, hc)                       # FULL_MULT
+            torch.cuda.synchronize()
+            if rep:
+                full.append(time.perf_counter() - t0)
+        MI.call("mi_sparse_destroy", hc)
+        hc = sparse_matrix_t()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sp2m(91, hc)                           # NNZ_COUNT (symbolic)
+        torch.cuda.synchronize()
+        count.append(time.perf_counter() - t0)
+        for rep in range(args.reps + 1):
+            a2 = a[2] * (rep + 2.0)
+            _check_return_value(MI.call("mi_sparse_d_set_values", ha, a2.data_ptr()), "set_values")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sp2m(92, hc)                       # FINALIZE_MULT on the unchanged pattern
+            torch.cuda.synchronize()
+            if rep:
+                fin.append(time.perf_counter() - t0)
+        # parity of the re-run: C 1 == A2 (B 1)
+        m, n, nnzc, _, _, _ = dev_csr(hc, dt)
+        ones = torch.ones(n, device=dev, dtype=dt)
+        b1 = torch.empty(b[3], device=dev, dtype=dt)
+        ab1 = torch.empty(m, device=dev, dtype=dt)
+        c1 = torch.empty(m, device=dev, dtype=dt)
+        spmv("d", hb, ones, b1)
+        spmv("d", ha, b1, ab1)
+        spmv("d", hc, ones, c1)
+        torch.cuda.synchronize()
+        rel = float(((c1 - ab1).abs() / ab1.abs().clamp(min=1e-300)).max())
+        tf, tn = sorted(full)[len(full) // 2], sorted(fin)[len(fin) // 2]
+        out.update({"config": "%s 2^%d x 2^%d, %d/row fp64 x same, staged (mi_sparse_sp2m)" % (args.kind, args.scale, args.scale, per_row),
+                    "nnzC": int(nnzc), "full_mult_ms": round(tf * 1e3, 3), "nnz_count_ms": round(count[0] * 1e3, 3),
+                    "finalize_only_ms": round(tn * 1e3, 3), "pattern_reuse_saves": round(1.0 - tn / tf, 3),
+                    "rowsum_max_rel_err_after_set_values": rel, "checks": {"rowsum_1e-12": rel <= 1e-12}})
+        for h in (ha, hb, hc):
+            MI.call("mi_sparse_destroy", h)
+    elif args.op == "spgemm":
         per_row = args.per_row or 16
         dt = torch.float64
         a = make(args.kind, args.scale, 1 << args.scale, per_row, 21 if args.kind == "rmat" else 1, dt)
