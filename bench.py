@@ -448,6 +448,11 @@ def secondary_gram(torch, abi, dev, with_cpu):
     note = ""
     for ncols in (262144, 131072, 65536):
         try:
+            need = ncols * ncols * 4 + (8 << 30)
+            for _ in range(40):  # memory released by the previous secondary (and its child process) comes back asynchronously
+                if torch.cuda.mem_get_info(dev)[0] >= need:
+                    break
+                time.sleep(0.5)
             C = torch.zeros((ncols, ncols), device=dev, dtype=torch.float32)
             break
         except Exception as e:  # noqa: BLE001
