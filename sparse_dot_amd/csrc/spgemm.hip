@@ -38,9 +38,14 @@ __device__ __forceinline__ int64_t lower_bound_col(const int32_t* __restrict__ c
 // ---- phase 0: upper bounds -----------------------------------------------------------------------
 // `upper`: 0 = full product, 1 = upper triangle only (products with column < row are dropped one by one),
 // 2 = upper triangle and the rows of B are sorted (the dropped part of every B row is skipped by a search).
+// Round 3: the extent of B's row for every nonzero of A -- (first entry that counts, number of entries), the lower
+// triangle already cut off -- is WRITTEN OUT here (ext0 / extlen, 12 bytes per nonzero of A, streamed) and read back by the
+// symbolic and numeric kernels.  bptr[k] for a random k is a 128-byte line fill for 16 useful bytes, and it was gathered
+// three times (here, symbolic, numeric): with 16-entry rows of B that was one line in 2.5 (symbolic) / 4.5 (numeric).
 __global__ void __launch_bounds__(256)
     k_row_ub(int64_t rows, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
-             const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub)
+             const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub,
+             int64_t* __restrict__ ext0, int32_t* __restrict__ extlen)
 {
     // 8 lanes per row
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,6 +59,8 @@ __global__ void __launch_bounds__(256)
             const int64_t b1 = bptr[k + 1];
             if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, (int32_t)row);
             s += b1 - b0;
+            ext0[p] = b0;
+            extlen[p] = (int32_t)(b1 - b0);
         }
     }
     s += __shfl_xor(s, 1);
@@ -181,7 +188,7 @@ constexpr int LDS_UNROLL = MI_LDS_UNROLL;
 template <typename T, int LOG2S, int THREADS, bool NUMERIC>
 __global__ void __launch_bounds__(THREADS)
     k_spgemm_lds(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
-                 const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
+                 const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
                  const int32_t* __restrict__ bcol, const T* __restrict__ bval, int gw, int upper,
                  int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
                  T* __restrict__ cval)
@@ -209,14 +216,10 @@ __global__ void __launch_bounds__(THREADS)
     if (NUMERIC) out0 = cptr[row];  // needed last: issued first so that its latency is hidden
     for (int64_t base = a0; base < a1; base += THREADS) {
         int len = 0;
-        if (base + tid < a1) {
-            const int32_t kk = acol[base + tid];
-            int64_t b0 = bptr[kk];
-            const int64_t b1 = bptr[kk + 1];
-            if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, row);  // sorted B: skip the lower triangle
-            qlo[tid] = b0;
+        if (base + tid < a1) {  // extent of B's row for this nonzero: precomputed by k_row_ub (coalesced, no gather of bptr)
+            qlo[tid] = ext0[base + tid];
+            len = extlen[base + tid];
             if (NUMERIC) a_s[tid] = aval[base + tid];
-            len = (int)(b1 - b0);
         }
         block_scan_inclusive<THREADS>(len, inc, wave_tot, tid);
         const int total = inc[THREADS - 1];
@@ -585,8 +588,8 @@ static inline size_t bitmap_lds_bytes(int64_t ncols)
 template <bool BOUNDS>
 __global__ void __launch_bounds__(1024)
     k_spgemm_bitmap(int64_t nbig, const int32_t* __restrict__ row_list, int64_t ncols,
-                    const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
-                    const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int gw, int upper,
+                    const int64_t* __restrict__ aptr, const int64_t* __restrict__ ext0,
+                    const int32_t* __restrict__ extlen, const int32_t* __restrict__ bcol, int gw, int upper,
                     int64_t* __restrict__ row_nnz, const int64_t* __restrict__ boff, int64_t cap,
                     int32_t* __restrict__ bounds, int64_t* __restrict__ boff_by_row, unsigned long long* work_counter)
 {
@@ -619,11 +622,9 @@ __global__ void __launch_bounds__(1024)
         int64_t b0_n = 0, b1_n = 0;
         auto fetch = [&](int64_t p) {
             b0_n = b1_n = 0;
-            if (p < a1) {
-                const int32_t kk = acol[p];
-                b0_n = bptr[kk];
-                b1_n = bptr[kk + 1];
-                if (upper == 2 && b0_n < b1_n) b0_n = lower_bound_col(bcol, b0_n, b1_n, row);  // sorted B: skip the lower triangle
+            if (p < a1) {  // precomputed extents (k_row_ub): the lower triangle is already cut off
+                b0_n = ext0[p];
+                b1_n = b0_n + extlen[p];
             }
         };
         fetch(a0 + tid);
@@ -1186,6 +1187,7 @@ struct BigRows {
     bool have_bounds = false;  // symbolic phase ran the bitmap kernel and stored the range starts
     DevBuf boff_by_row;        // int64[A.rows]: offset of a big row's range starts in `bounds`
     DevBuf bounds;             // int32: range starts, P_max = ceil(min(ub, cols) / cap) slots per big row
+    DevBuf ext0, extlen;       // per nonzero of A: first counted entry of B's row (int64) and their number (int32) -- k_row_ub
 };
 
 template <typename T, bool NUMERIC>
@@ -1206,12 +1208,15 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
 #define MI_SPGEMM_ARGS(list)                                                                                       \
     (const int32_t*)list, (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,   \
         (const int32_t*)B.col, (const T*)B.val
+#define MI_SPGEMM_LDS_ARGS(list)                                                                                   \
+    (const int32_t*)list, (const int64_t*)A.ptr, (const int64_t*)big.ext0.as<int64_t>(),                           \
+        (const int32_t*)big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val
     if (!force_global) {
 #define MI_SPGEMM_BIN(k, LOG2S, THREADS, GW)                                                                       \
     if (b.n[k]) {                                                                                                  \
         launch_batched(b.n[k], THREADS, [&](int64_t off, int64_t nb) {                                             \
             MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC>), dim3((unsigned)nb), dim3(THREADS), c.stream,       \
-                      MI_SPGEMM_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);                   \
+                      MI_SPGEMM_LDS_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);               \
         });                                                                                                        \
         b.n[k] = 0;                                                                                                \
     }
@@ -1270,14 +1275,16 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                     big.bounds.alloc(sizeof(int32_t) * (size_t)(n_bounds + 1));
                     MI_LAUNCH_SMEM((k_spgemm_bitmap<true>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
                                    c.stream, nbig, (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr,
-                                   (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, gw, upper, row_nnz,
+                                   (const int64_t*)big.ext0.as<int64_t>(), (const int32_t*)big.extlen.as<int32_t>(),
+                                   (const int32_t*)B.col, gw, upper, row_nnz,
                                    (const int64_t*)item_off, big.cap, big.bounds.as<int32_t>(),
                                    big.boff_by_row.as<int64_t>(), counter);
                     big.have_bounds = true;
                 } else {
                     MI_LAUNCH_SMEM((k_spgemm_bitmap<false>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
                                    c.stream, nbig, (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr,
-                                   (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, gw, upper, row_nnz,
+                                   (const int64_t*)big.ext0.as<int64_t>(), (const int32_t*)big.extlen.as<int32_t>(),
+                                   (const int32_t*)B.col, gw, upper, row_nnz,
                                    (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, counter);
                 }
             } else {
@@ -1441,6 +1448,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
         }
     }
 #undef MI_SPGEMM_ARGS
+#undef MI_SPGEMM_LDS_ARGS
     MI_HIP_CHECK(hipGetLastError());
 }
 
@@ -1491,9 +1499,12 @@ static void spgemm_symbolic(const Csr& A, const Csr& B, bool upper, Csr& C, Spge
     st.row_nnz.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
     int64_t* row_nnz = st.row_nnz.as<int64_t>();
     MI_HIP_CHECK(hipMemsetAsync(row_nnz, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
+    big.ext0.alloc(sizeof(int64_t) * (size_t)(A.nnz + 1));
+    big.extlen.alloc(sizeof(int32_t) * (size_t)(A.nnz + 1));
     if (A.rows > 0)
         MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows,
-                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, ub);
+                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, ub,
+                  big.ext0.as<int64_t>(), big.extlen.as<int32_t>());
     const int64_t max_ub = device_max(ub, A.rows);
     mark("row upper bounds");
     run_phase<T, false>(A, B, st.upper_mode, ub, max_ub, row_nnz, nullptr, nullptr, nullptr, big);
