@@ -279,6 +279,8 @@ mi_sparse_status_t mi_sparse_get_info(mi_sparse_matrix_t A, int64_t *rows, int64
 /* mkl_sparse_?_export_bsr (reference _cfunctions.py:567-579; call site _common.py:540-551): the handle's matrix
  * re-blocked with the block size it was created with (create_bsr) or produced with (mi_sparse_spmm of two BSR handles
  * of one block size); blocks row-major (*block_layout = 101), library-owned host arrays valid until destroy.
+ * A handle created from BSR arrays and not ordered since exports those arrays unchanged (block order, block layout,
+ * explicit zeros -- what MKL's aliasing handle gives back; reference tests/test_mkl.py:230-249).
  * rows / cols / block_size are in BLOCKS.  Handles without a block size: NOT_SUPPORTED. */
 mi_sparse_status_t mi_sparse_s_export_bsr(mi_sparse_matrix_t A, int *base, int *block_layout, int32_t *rows,
                                             int32_t *cols, int32_t *block_size, int32_t **rows_start,

@@ -388,6 +388,7 @@ struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.h
     int chunk = 0;
     int64_t nchunks = 0;
     DevBuf chunk_row;  // int32[nchunks + 1]
+    DevBuf chunk_desc; // SpmmChunk[nchunks] (spmm.hip): first row / rows / nonzero range / carry flag of every chunk
     // static fix-up schedule: one task per long row that is cut across chunks -- (row, first chunk,
     // last chunk) whose carries are added, in chunk order, to the row its owner wrote.  Built on the
     // device in one pass; the count stays on the device (n_tasks_dev) and reaches the host
@@ -430,6 +431,7 @@ struct mi_sparse_matrix {
     mi::Csr csr;            // CSR of A
     mi::Csr csrT;           // CSR of A^T  (== the CSC arrays of A)
     mi::Bsr bsr;            // block form (origin 'b' only)
+    bool bsr_pristine = true;  // origin 'b': not ordered since creation -> export_bsr hands back the arrays as they were given
     // caller's HOST arrays, kept for mi_sparse_order's write-back (nullptr when device / result)
     void* user_col = nullptr;
     void* user_val = nullptr;

@@ -958,9 +958,46 @@ static int export_bsr_generic(mi_sparse_matrix_t A, int* base, int* block_layout
             fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "handle has no block size to export with (not created from / produced by BSR operands)");
         Context& c = ctx();
         c.scratch_reset();
+        const int64_t brows = h->rows / bs, bcols = h->cols / bs;
+        if (h->origin == 'b' && h->bsr.valid && h->bsr_pristine) {
+            // A handle created from BSR arrays and not ordered since exports THOSE arrays -- same block order, same
+            // layout inside the blocks, explicit zeros included -- as MKL does (its handle aliases the caller's arrays;
+            // the reference's own round-trip test compares the raw arrays: tests/test_mkl.py:230-249).
+            const Bsr& bb = h->bsr;
+            const int64_t nblocks = bb.nblocks;
+            if (sizeof(I) == 4 && (nblocks > INT32_MAX || brows > INT32_MAX || bcols > INT32_MAX))
+                fail(MI_SPARSE_STATUS_ALLOC_FAILED, "matrix does not fit 32-bit indices; use the _64 entry point");
+            HostExport& e = h->exp_bsr;
+            e.ptr.resize(sizeof(I) * (size_t)(brows + 1));
+            e.col.resize(sizeof(I) * (size_t)(nblocks ? nblocks : 1));
+            e.val.resize(sizeof(T) * (size_t)(nblocks ? nblocks * bs * bs : 1));
+            I* dptr = static_cast<I*>(c.scratch_alloc(sizeof(I) * (size_t)(brows + 1)));
+            MI_LAUNCH((k_export_ptr<I>), grid1d(brows + 1, 256), dim3(256), c.stream, (const int64_t*)bb.ptr, brows + 1, dptr);
+            MI_HIP_CHECK(hipMemcpyAsync(e.ptr.data(), dptr, sizeof(I) * (size_t)(brows + 1), hipMemcpyDeviceToHost, c.stream));
+            if (nblocks) {
+                if (sizeof(I) == 4) {
+                    copy_d2h(e.col.data(), bb.col, sizeof(int32_t) * (size_t)nblocks);
+                } else {
+                    I* dcol = static_cast<I*>(c.scratch_alloc(sizeof(I) * (size_t)nblocks));
+                    MI_LAUNCH((k_export_col<I>), grid1d_stride(nblocks, 256), dim3(256), c.stream, (const int32_t*)bb.col, nblocks, dcol);
+                    copy_d2h(e.col.data(), dcol, sizeof(I) * (size_t)nblocks);
+                }
+                copy_d2h(e.val.data(), bb.val, sizeof(T) * (size_t)(nblocks * bs * bs));
+            }
+            c.sync();
+            if (base) *base = 0;
+            if (block_layout) *block_layout = bb.layout;
+            if (brows_out) *brows_out = (I)brows;
+            if (bcols_out) *bcols_out = (I)bcols;
+            if (bs_out) *bs_out = (I)bs;
+            if (ps) *ps = reinterpret_cast<I*>(e.ptr.data());
+            if (pe) *pe = reinterpret_cast<I*>(e.ptr.data()) + 1;
+            if (idx) *idx = reinterpret_cast<I*>(e.col.data());
+            if (values) *values = reinterpret_cast<T*>(e.val.data());
+            return;
+        }
         Csr& m = need_csr(h);
         if (!rows_sorted(m)) sort_csr(h->vtype, m);  // ordering the entries of a row does not change the matrix
-        const int64_t brows = h->rows / bs, bcols = h->cols / bs;
         int64_t* cnt = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(brows + 1)));
         int64_t* bptr = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(brows + 1)));
         int64_t nblocks = 0;
@@ -1131,6 +1168,7 @@ mi_sparse_status_t mi_sparse_order(mi_sparse_matrix_t A)
         const bool created_csc = (h->origin == 'c');
         mi::Csr& primary = created_csc ? mi::need_csrT(h) : mi::need_csr(h);
         const bool was_sorted = primary.sorted;
+        h->bsr_pristine = false;  // a BSR handle exports re-blocked (ordered) arrays from now on
         mi::sort_csr(h->vtype, primary);
         mi::Csr& other = created_csc ? h->csr : h->csrT;
         if (other.valid) mi::sort_csr(h->vtype, other);

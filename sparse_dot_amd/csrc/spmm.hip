@@ -96,6 +96,70 @@ __global__ void k_spmm_plan_tasks(const int64_t* ptr, const int32_t* chunk_row, 
     tasks[3 * t + 2] = (int32_t)last;
 }
 
+// Everything a wave needs to know about its chunk, in ONE 32-byte load (round 3): used by k_spmv, whose chunks are short
+// (one memory round trip of x gathers), so the chain  chunk_row[w], [w + 1] -> four row-pointer entries -> loads of A  was a
+// visible share of a wave's life: 0.204-0.209 -> 0.194-0.202 ms (R-MAT), 0.245 -> 0.233 ms (uniform).  k_spmm keeps
+// deriving it in the kernel: with the descriptor its time ROSE by 1 % (1.787-1.803 -> 1.810-1.829 ms, profiles/
+// r03_spmm_chunk_desc_ab.log) -- the row-pointer lines it touches first are the ones its row-end loads need next.
+// Same ownership rules as k_spmm's prologue, evaluated once in the plan.
+struct alignas(32) SpmmChunk {
+    int64_t P0, P1;    // the chunk's nonzeros: [P0, P1) in A's arrays
+    int32_t r0;        // first row it processes
+    int32_t nproc;     // rows it processes (the last one is a cut long row when has_trail)
+    int32_t has_trail; // 1: the last processed row is cut at the chunk end and leaves a carry
+    int32_t pad;
+};
+
+__global__ void k_spmm_plan_desc(const int64_t* __restrict__ ptr, const int32_t* __restrict__ chunk_row, int64_t rows,
+                                 int64_t nnz, int64_t ch, int64_t nchunks, SpmmChunk* __restrict__ desc)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nchunks) return;
+    const int64_t total = nnz + rows;
+    const int64_t s = w * ch;
+    const int64_t e = (s + ch < total) ? s + ch : total;
+    const int64_t ra = chunk_row[w];      // row holding item s
+    const int64_t rb = chunk_row[w + 1];  // row holding item e (== rows after the last item)
+    int64_t r0, P0;
+    {  // first row: a short row that began in the previous chunk was finished there; a long one is continued from item s
+        const int64_t pa = ptr[ra], pa1 = ptr[ra + 1];
+        const bool before = (pa + ra) < s;
+        const bool is_long = (pa1 - pa + 1) > SPMM_SPLIT;
+        if (before && !is_long) {
+            r0 = ra + 1;
+            P0 = pa1;
+        } else {
+            r0 = ra;
+            P0 = before ? s - ra : pa;
+        }
+    }
+    // last row: the row holding item e, if it starts inside this chunk, is finished here when short and cut (-> carry) when long
+    int64_t r_stop, P1;
+    int has_trail = 0;
+    if (rb < rows && (ptr[rb] + rb) < e) {
+        const int64_t pb = ptr[rb], pb1 = ptr[rb + 1];
+        r_stop = rb + 1;
+        if ((pb1 - pb + 1) > SPMM_SPLIT) {
+            P1 = (e - rb < pb1) ? e - rb : pb1;
+            has_trail = 1;
+        } else {
+            P1 = pb1;
+        }
+    } else {
+        r_stop = rb;
+        P1 = (rb < rows) ? ptr[rb] : nnz;
+    }
+    if (r_stop < r0) r_stop = r0;
+    SpmmChunk d;
+    d.P0 = P0;
+    d.P1 = P1 > P0 ? P1 : P0;
+    d.r0 = (int32_t)r0;
+    d.nproc = (int32_t)(r_stop - r0);
+    d.has_trail = has_trail;
+    d.pad = 0;
+    desc[w] = d;
+}
+
 // LDS bytes one wave needs for a chunk of CH items
 template <typename T>
 __host__ __device__ constexpr size_t spmm_wave_lds(int ch)
@@ -325,7 +389,7 @@ constexpr int SPMV_U = 4;  // nonzeros per lane in flight (k_spmv)
 template <typename T>
 __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
     k_spmv(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
-           const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
+           const T* __restrict__ val, const SpmmChunk* __restrict__ chunk_desc, int64_t nchunks, int ch, int conj_a,
            const T* __restrict__ x, int64_t x_s, T* __restrict__ y, int64_t y_s, T alpha, T beta, int beta_zero,
            T* __restrict__ carry_val)
 {
@@ -342,41 +406,12 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
     int64_t r0 = 0;
     int n_owned = 0, has_trail = 0, nproc = 0;
     if (active) {
-        // identical partition logic to k_spmm (see there for the ownership rules)
-        const int64_t total = nnz + rows;
-        const int64_t s = w * ch;
-        const int64_t e = (s + ch < total) ? s + ch : total;
-        const int64_t ra = chunk_row[w];
-        const int64_t rb = chunk_row[w + 1];
-        int64_t P0;
-        {
-            const int64_t pa = ptr[ra], pa1 = ptr[ra + 1];
-            const bool before = (pa + ra) < s;
-            const bool is_long = (pa1 - pa + 1) > SPMM_SPLIT;
-            if (before && !is_long) {
-                r0 = ra + 1;
-                P0 = pa1;
-            } else {
-                r0 = ra;
-                P0 = before ? s - ra : pa;
-            }
-        }
-        int64_t r_stop, P1;
-        if (rb < rows && (ptr[rb] + rb) < e) {
-            const int64_t pb = ptr[rb], pb1 = ptr[rb + 1];
-            r_stop = rb + 1;
-            if ((pb1 - pb + 1) > SPMM_SPLIT) {
-                P1 = (e - rb < pb1) ? e - rb : pb1;
-                has_trail = 1;
-            } else {
-                P1 = pb1;
-            }
-        } else {
-            r_stop = rb;
-            P1 = (rb < rows) ? ptr[rb] : nnz;
-        }
-        if (r_stop < r0) r_stop = r0;
-        nproc = (int)(r_stop - r0);
+        // identical partition to k_spmm: the chunk's descriptor (k_spmm_plan_desc)
+        const SpmmChunk d = chunk_desc[w];
+        r0 = d.r0;
+        const int64_t P0 = d.P0, P1 = d.P1;
+        has_trail = d.has_trail;
+        nproc = d.nproc;
         n_owned = nproc - has_trail;
         for (int k = lane; k < nproc; k += WAVE) {
             int64_t en = ptr[r0 + k + 1];
@@ -444,59 +479,67 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
 }
 
 // add the carries of every cut row to the row its owner wrote.  The schedule (which chunks carry
-// into which row) depends only on A and the chunk size, so it is precomputed in the plan: one lane
-// group per task sums that row's carries in chunk order (deterministic) and does one
-// read-modify-write of C.  LPN lanes x V values, the shapes of the main kernel.
+// into which row) depends only on A and the chunk size, so it is precomputed in the plan.  One WORKGROUP per task
+// (round 3; one lane group before): eight lane groups of LPN lanes x V values take the chunks first + g, first + g + 8, ...
+// with four carry loads in flight each -- a hub row is cut into hundreds of chunks, which one lane group summed in ~30
+// dependent round trips -- and group 0 combines the eight partial sums through LDS in a FIXED order and does the one
+// read-modify-write of C: the same partition and the same order as before, so the same bits, run to run.
 template <typename T, int V, int LPN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(8 * LPN)
     k_spmm_fixup(const unsigned long long* __restrict__ n_tasks_dev, const int32_t* __restrict__ tasks,
                  const T* __restrict__ carry_val, int64_t N, T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t task = t / LPN;
-    const int li = (int)(t % LPN);
+    constexpr int G = 8, U = 4;
+    __shared__ T part_s[G][LPN * V];
+    const int64_t task = blockIdx.x;
     if (task >= (int64_t)*n_tasks_dev) return;  // the count lives on the device (the grid may be an upper bound)
+    const int g = threadIdx.x / LPN, li = threadIdx.x % LPN;
     const int64_t row = tasks[3 * task], first = tasks[3 * task + 1], last = tasks[3 * task + 2];
-    for (int64_t jc = (int64_t)li * V; jc < N; jc += (int64_t)LPN * V) {
-        // eight interleaved partial sums (chunks first+g, first+g+8, ...) so that eight carry loads are
-        // in flight at once -- a hub row can be cut into hundreds of chunks -- combined in a fixed
-        // order: the result does not depend on scheduling
-        constexpr int G = 8;
-        T part[G][V];
+    for (int64_t j0 = 0; j0 < N; j0 += (int64_t)LPN * V) {
+        const int64_t jc = j0 + (int64_t)li * V;
+        const bool col_ok = jc < N;  // V divides N on the vector path
+        const int64_t jl = col_ok ? jc : j0;
+        T part[V];
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int v = 0; v < V; ++v) part[v] = vt<T>::zero();
+        for (int64_t u = first + g; u <= last; u += (int64_t)G * U) {
+            vec<T, V> cvv[U];
 #pragma unroll
-            for (int v = 0; v < V; ++v) part[g][v] = vt<T>::zero();
-        for (int64_t u = first; u <= last; u += G) {
-            vec<T, V> cvv[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int64_t uu = (u + g <= last) ? u + g : last;  // clamp; masked out below
-                if (V > 1) cvv[g] = *reinterpret_cast<const vec<T, V>*>(carry_val + uu * N + jc);
-                else cvv[g].v[0] = carry_val[uu * N + jc];
+            for (int k = 0; k < U; ++k) {
+                const int64_t uu = (u + (int64_t)k * G <= last) ? u + (int64_t)k * G : last;  // clamp; masked out below
+                if (V > 1) cvv[k] = *reinterpret_cast<const vec<T, V>*>(carry_val + uu * N + jl);
+                else cvv[k].v[0] = carry_val[uu * N + jl];
             }
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (u + g <= last) {
+            for (int k = 0; k < U; ++k) {
+                if (u + (int64_t)k * G <= last) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) part[g][v] = vt<T>::add(part[g][v], cvv[g].v[v]);
+                    for (int v = 0; v < V; ++v) part[v] = vt<T>::add(part[v], cvv[k].v[v]);
                 }
             }
         }
-        T sum[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v)
-            sum[v] = vt<T>::add(vt<T>::add(vt<T>::add(part[0][v], part[1][v]), vt<T>::add(part[2][v], part[3][v])),
-                                vt<T>::add(vt<T>::add(part[4][v], part[5][v]), vt<T>::add(part[6][v], part[7][v])));
-        T* c = C + row * c_rs + jc * c_cs;
-        if (V > 1) {
-            vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(c);
+        for (int v = 0; v < V; ++v) part_s[g][li * V + v] = part[v];
+        __syncthreads();
+        if (g == 0 && col_ok) {
+            T sum[V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) old.v[v] = vt<T>::fma(alpha, sum[v], old.v[v]);
-            *reinterpret_cast<vec<T, V>*>(c) = old;
-        } else {
-            *c = vt<T>::fma(alpha, sum[0], *c);
+            for (int v = 0; v < V; ++v) {
+                const int x = li * V + v;
+                sum[v] = vt<T>::add(vt<T>::add(vt<T>::add(part_s[0][x], part_s[1][x]), vt<T>::add(part_s[2][x], part_s[3][x])),
+                                    vt<T>::add(vt<T>::add(part_s[4][x], part_s[5][x]), vt<T>::add(part_s[6][x], part_s[7][x])));
+            }
+            T* c = C + row * c_rs + jc * c_cs;
+            if (V > 1) {
+                vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(c);
+#pragma unroll
+                for (int v = 0; v < V; ++v) old.v[v] = vt<T>::fma(alpha, sum[v], old.v[v]);
+                *reinterpret_cast<vec<T, V>*>(c) = old;
+            } else {
+                *c = vt<T>::fma(alpha, sum[0], *c);
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -738,6 +781,10 @@ static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, in
         MI_LAUNCH(k_spmm_plan_tasks, dim3((unsigned)ceil_div(p.nchunks, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
                   (const int32_t*)p.chunk_row.as<int32_t>(), m.rows, m.nnz, (int64_t)chunk, p.nchunks,
                   p.tasks.as<int32_t>(), static_cast<unsigned long long*>(p.n_tasks_dev.p));
+        p.chunk_desc.alloc(sizeof(SpmmChunk) * (size_t)(p.nchunks + 1));
+        MI_LAUNCH(k_spmm_plan_desc, dim3((unsigned)ceil_div(p.nchunks, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
+                  (const int32_t*)p.chunk_row.as<int32_t>(), m.rows, m.nnz, (int64_t)chunk, p.nchunks,
+                  p.chunk_desc.as<SpmmChunk>());
         p.n_tasks = -1;
         p.n_tasks_word.post(p.n_tasks_dev.p, sizeof(unsigned long long), c.stream);
         p.uses = 0;
@@ -880,10 +927,10 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         note_kernel("mi::k_spmv<%s>", type_name<T>());
         MI_LAUNCH_SMEM((k_spmv<T>), dim3((unsigned)ceil_div(p.nchunks, SPMM_WAVES)), dim3(SPMM_WAVES * WAVE),
                        pw * SPMM_WAVES, c.stream, m.rows, m.nnz, (const int64_t*)m.ptr, (const int32_t*)m.col,
-                       (const T*)m.val, (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs,
+                       (const T*)m.val, (const SpmmChunk*)p.chunk_desc.as<SpmmChunk>(), p.nchunks, p.chunk, conj_a, B, b_rs,
                        C, c_rs, alpha, beta, (int)(vt<T>::is_zero(beta) ? 1 : 0), carry_val);
         if (fix_tasks)
-            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(fix_tasks * 16, 256)), dim3(256), c.stream,
+            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)fix_tasks), dim3(8 * 16), c.stream,
                       n_tasks_dev, (const int32_t*)p.tasks.as<int32_t>(), (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         plan_after_product(h, transposed, m, hot_rows);
         return;
@@ -929,13 +976,13 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         const int32_t* tk = p.tasks.as<int32_t>();
         if (vec_ok) {
             if (N / V16 > 16)
-                MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)ceil_div(fix_tasks * 32, 256)), dim3(256), c.stream,
+                MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)fix_tasks), dim3(8 * 32), c.stream,
                           n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
             else
-                MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)ceil_div(fix_tasks * 8, 256)), dim3(256), c.stream,
+                MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)fix_tasks), dim3(8 * 8), c.stream,
                           n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         } else {
-            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)ceil_div(fix_tasks * 16, 256)), dim3(256), c.stream,
+            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)fix_tasks), dim3(8 * 16), c.stream,
                       n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         }
     }

@@ -109,3 +109,35 @@ def test_bsr_product_exported_as_bsr(gpu, dtype, bs):
     with SparseHandle.from_scipy(a.tocsr()) as h:
         with pytest.raises(ValueError, match="NOT_SUPPORTED"):
             h.export_bsr()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_bsr_handle_exports_the_arrays_it_was_created_from(gpu, dtype):
+    """MKL's BSR handle aliases the caller's arrays, so create -> export hands the SAME arrays back: block order as given
+    (scipy's csr -> bsr conversion leaves the blocks of a row unsorted), explicit zeros inside blocks, block layout.  The
+    reference's own round-trip test compares the raw arrays (reference tests/test_mkl.py:230-249); after mi_sparse_order
+    the export is the re-blocked, ordered matrix instead."""
+    from sparse_dot_amd._mi_interface import SparseHandle
+    m = sps.random(200, 300, density=0.1, format="csr", dtype=np.float64, random_state=50).astype(dtype)
+    a = sps.bsr_matrix(m, blocksize=(2, 2))
+    perm_a = a.copy()
+    # make sure the block order inside rows is NOT ascending somewhere
+    rng = np.random.default_rng(3)
+    for i in range(0, len(a.indptr) - 1, 7):
+        lo, hi = a.indptr[i], a.indptr[i + 1]
+        p = rng.permutation(hi - lo)
+        perm_a.indices[lo:hi] = a.indices[lo:hi][p]
+        perm_a.data[lo:hi] = a.data[lo:hi][p]
+    assert not np.array_equal(perm_a.indices, a.indices)
+    with SparseHandle.from_scipy(perm_a) as h:
+        back = h.export_bsr()
+        assert back.blocksize == (2, 2) and back.dtype == dtype
+        assert np.array_equal(back.indptr, perm_a.indptr)
+        assert np.array_equal(back.indices, perm_a.indices)   # same block order, not a re-blocked / sorted one
+        assert np.array_equal(back.data, perm_a.data)         # bit for bit, explicit zeros included
+        h.order()
+        ordered = h.export_bsr()
+    ref = perm_a.copy()
+    ref.sort_indices()
+    assert np.array_equal(ordered.indptr, ref.indptr) and np.array_equal(ordered.indices, ref.indices)
+    assert np.array_equal(ordered.toarray(), ref.toarray())
