@@ -163,6 +163,19 @@ def cpu_baseline_spmm(indptr, indices, vals, n, bmat, nrep=5):
                 "sample": "full workload (%d nnz x N=%d), median of 3 runs of the oracle's OpenMP csr_mm "
                           "(includes output allocation); %s" % (a.nnz, bmat.shape[1], note),
                 "ms": round(t * 1e3, 2)}
+    if base.get("kind") == "reference":
+        # the build's own OpenMP restatement (oracle/sparse_oracle.c, the parity checker) at all cores,
+        # reported beside MKL -- a checker being timed, not a product path
+        try:
+            from oracle import cpu_oracle
+            cpu_oracle.spmm(a[:1024], bmat)  # build + warm
+            to = _median(_timed(lambda: cpu_oracle.spmm(a, bmat), 3, warm=0))
+            variants["oracle_openmp_port"] = {"value": round(flops / to / 1e9, 2), "unit": "GFLOP/s", "cores": _host_cores(),
+                                              "ms": round(to * 1e3, 2), "kind": "port",
+                                              "sample": "the oracle's OpenMP csr_mm on the full workload (includes its output "
+                                                        "allocation), median of 3"}
+        except Exception as e:  # noqa: BLE001
+            variants["oracle_openmp_port"] = {"error": str(e)[:120]}
     ts = _timed(lambda: a @ bmat, nrep)
     variants["scipy_1_thread"] = {"value": round(flops / _median(ts) / 1e9, 2), "unit": "GFLOP/s", "cores": 1,
                                   "ms": round(_median(ts) * 1e3, 2),

@@ -479,6 +479,7 @@ const char *mi_sparse_last_error(void);
  *   spgemm_lds_parts, spgemm_slice_table, spgemm_slice_table_max, spgemm_part_log2s_bias,
  *   spgemm_force_global, spgemm_global_mode                                     (SpGEMM big-row paths)
  *   gram_sliced (1: slice-table walk when the slices are short, 2: whenever the rows are sorted, 0: never),
+ *   gram_heads (1: slice bounds travel with the entries of X^T when rows have <= 255 entries; 0: per-row table),
  *   gram_tile_kb (128 / 64), gram_persistent (-1 auto, 0: one workgroup per tile, k: k workgroups per LDS slot),
  *   bsr_native (0: BSR handles multiply through their CSR expansion), staged_copies (0: plain hipMemcpy for
  *   pageable host arrays)

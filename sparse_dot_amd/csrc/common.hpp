@@ -352,6 +352,11 @@ struct Csr {
     // dense gram, sliced walk: packed (column, value) records of every entry in storage order (SpEntry<T>[nnz]); follows
     // the VALUES, so mi_sparse_?_set_values and mi_sparse_order drop it
     DevBuf gram_rec;
+    // dense gram: as the CSR of X^T -- per entry (r, i) the start of row r in X's records and its entries left of every tile
+    // boundary (GramHead, gram.hip), built for tile width gram_head_w; as the CSR of X -- its longest row (-1: not known yet)
+    DevBuf gram_head;
+    int64_t gram_head_w = 0;
+    int64_t gram_max_row = -1;
 };
 
 // block form kept next to the CSR expansion on handles created from BSR arrays: the SpMM block kernel (bsr.hip) reads it
@@ -488,6 +493,7 @@ struct Options {
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory
     int64_t trace_phases = 0;      // print host wall-clock per SpGEMM phase to stderr (diagnostics; synchronises)
+    int64_t gram_heads = 1;        // sliced dense gram: slice bounds travel with the entries of X^T (rows of X <= 255 entries, <= 11 tiles per row); 0: per-row table
     int64_t gram_sliced = 1;       // dense gram: slice table + 8 lanes per selected row when rows of X are sorted and slices are short (<= 12 entries on average); 2: whenever sorted; 0: never
     int64_t gram_persistent = -1;   // dense gram: workgroups per LDS slot of the chip walking the tile list (0: one workgroup per tile; -1: 1 for the sliced walk, 4 for the whole-row walk)
     int64_t gram_tile_kb = 128;    // dense gram, outputs wider than one 64 KiB tile: LDS tile of 128 (default) or 64 KiB

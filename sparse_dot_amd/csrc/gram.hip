@@ -17,32 +17,11 @@ namespace mi {
 // same column), and the finished tile is written to HBM exactly once, coalesced, with beta applied
 // on the way -- no global atomics, no separate scaling pass.  Tiles start at the diagonal (only
 // col >= row is produced).
-// Finished tile -> C.  Row-major with beta = 0 (the reference's call): 16-byte NON-TEMPORAL stores -- the tile is
-// never read again by this kernel, and a wave's stores sit in the same in-order counter (vmcnt) as its next loads, so
-// the faster they retire the sooner the next tile's first loads are seen to complete.
+// Finished tile -> C (defined below).  Row-major with beta = 0 (the reference's call): 16-byte NON-TEMPORAL stores -- the
+// tile is never read again by this kernel -- and the tile is cleared on the way (every element a thread reads it zeroes).
 template <typename T>
-__device__ __forceinline__ void syrkd_write_tile(const T* acc, T* crow, int64_t c_cs, int64_t j_lo, int64_t j_hi, int64_t tile_lo,
-                                                 T beta, int beta_zero, int tid, int nthreads)
-{
-    constexpr int V = 16 / (int)sizeof(T);
-    if (beta_zero && c_cs == 1) {
-        T* p0 = crow + j_lo;
-        int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(p0) & 15)) & 15) / sizeof(T));
-        if (head > j_hi - j_lo) head = j_hi - j_lo;
-        const int64_t body = (j_hi - j_lo - head) / V;  // 16-byte vectors
-        if (tid < head) nt_store(p0 + tid, acc[j_lo - tile_lo + tid]);
-        const T* a0 = acc + (j_lo - tile_lo + head);
-        for (int64_t k = tid; k < body; k += nthreads) nt_store16(p0 + head + k * V, a0 + k * V);
-        const int64_t done = head + body * V;
-        if (tid < j_hi - j_lo - done) nt_store(p0 + done + tid, acc[j_lo - tile_lo + done + tid]);
-        return;
-    }
-    for (int64_t j = j_lo + tid; j < j_hi; j += nthreads) {
-        T* c = crow + j * c_cs;
-        const T v = acc[j - tile_lo];
-        *c = beta_zero ? v : vt<T>::fma(beta, *c, v);
-    }
-}
+__device__ __forceinline__ void syrkd_flush_tile(T* acc, T* crow, int64_t c_cs, int64_t j_lo, int64_t j_hi, int64_t tile_lo,
+                                                 T beta, int beta_zero, int tid, int nthreads);
 
 // LDS tile of one workgroup: TKB KiB of accumulators.  64 KiB (two 512-thread workgroups per CU) or 128 KiB (one
 // 1024-thread workgroup per CU): a wider tile halves the number of passes over the row's nonzeros when the output row
@@ -58,7 +37,9 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
                 int beta_zero, int64_t n_virtual)
 {
     constexpr int TILE = syrkd_tile<T, TKB>();
-    __shared__ T acc[TILE];
+    __shared__ __attribute__((aligned(16))) T acc[TILE];
+    for (int k = threadIdx.x; k < TILE; k += blockDim.x) acc[k] = vt<T>::zero();  // once: every flush leaves the tile zero again
+    __syncthreads();
     // PERSISTENT workgroups: the grid is a few workgroups per CU and each walks the (row, tile) list with stride
     // gridDim.x (a multiple of 8, so the XCD of a list position stays position % 8).  A tile workgroup owns the whole
     // LDS of its CU; launched one per tile, every tile paid a dispatch + wave launch with the CU idle in between,
@@ -75,8 +56,6 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     if (i >= row_end || j_lo >= n) continue;  // uniform for the whole workgroup
     const int64_t j_hi = (j_lo + TILE < n) ? j_lo + TILE : n;
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    for (int k = tid; k < (int)(j_hi - j_lo); k += nthreads) acc[k] = vt<T>::zero();
-    __syncthreads();
     const int wave = tid / WAVE, lane = tid % WAVE, nwaves = nthreads / WAVE;
     // Each wave takes 64 nonzeros (r, X[r,i]) of column i at a time: lane l fetches entry l and the
     // extent of X's row r (coalesced + one gather), then the wave walks those 64 rows with the
@@ -145,7 +124,7 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         }
     }
     __syncthreads();
-    syrkd_write_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, j_lo, beta, beta_zero, tid, nthreads);
+    syrkd_flush_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, j_lo, beta, beta_zero, tid, nthreads);  // out, and zero again
     __syncthreads();  // the tile is reused by the next list position
     }
 }
@@ -194,6 +173,47 @@ __global__ void k_gram_pack(int64_t nnz, const int32_t* __restrict__ col, const 
     }
 }
 
+// Slice bounds carried by the ENTRIES OF X^T (rows of X with at most 255 entries, at most 11 tiles per output row): for
+// every entry (r, i) of X^T a 16-byte record { start of row r in `rec`, entries of row r left of tile boundary 0 .. G }.
+// A tile then reads its selected rows' bounds as a COALESCED stream next to (r, X[r,i]) -- 16 bytes per selected row --
+// instead of one random 128-byte line of the per-row table each: the table line was one of the ~2.5 lines a (row, tile)
+// pair cost, and with the bounds in hand one level of the dependent chain disappears.  Built once per handle and tile
+// width from the per-row table (k_gram_heads); 16 bytes per nonzero.
+struct alignas(16) GramHead {
+    int32_t start;
+    uint32_t w[3];  // byte g of (w[0], w[1], w[2]) = entries of the row left of tile boundary g
+    __host__ __device__ __forceinline__ int left(int g) const
+    {
+        const uint32_t word = g < 4 ? w[0] : g < 8 ? w[1] : w[2];  // g is uniform: selects, no indexed register array
+        return (int)((word >> ((g & 3) * 8)) & 255u);
+    }
+};
+constexpr int GRAM_HEAD_MAXG = 11;
+
+__global__ void k_gram_heads(int64_t nnz, int64_t G, const int32_t* __restrict__ tcol, const int32_t* __restrict__ off,
+                             GramHead* __restrict__ head)
+{
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t* orow = off + (int64_t)tcol[q] * (G + 1);
+        GramHead h;
+        h.start = orow[0];
+        h.w[0] = h.w[1] = h.w[2] = 0u;
+#pragma unroll
+        for (int g = 0; g < 12; ++g) h.w[g >> 2] |= (uint32_t)((orow[g <= G ? g : G] - h.start) & 255) << ((g & 3) * 8);
+        head[q] = h;
+    }
+}
+
+__global__ void k_gram_max_row(int64_t rows, const int64_t* __restrict__ ptr, long long* __restrict__ out)
+{
+    long long m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long l = (long long)(ptr[i + 1] - ptr[i]);
+        if (l > m) m = l;
+    }
+    if (m) atomicMax(out, m);
+}
+
 // Finished tile -> C, and the tile back to zero (every element a thread reads it also clears).
 template <typename T>
 __device__ __forceinline__ void syrkd_flush_tile(T* acc, T* crow, int64_t c_cs, int64_t j_lo, int64_t j_hi, int64_t tile_lo,
@@ -210,10 +230,25 @@ __device__ __forceinline__ void syrkd_flush_tile(T* acc, T* crow, int64_t c_cs, 
             acc[j_lo - tile_lo + tid] = vt<T>::zero();
         }
         T* a0 = acc + (j_lo - tile_lo + head);
-        for (int64_t k = tid; k < body; k += nthreads) {
-            nt_store16(p0 + head + k * V, a0 + k * V);
+        if (((j_lo - tile_lo + head) % V) == 0) {
+            // the usual case (every tile right of the diagonal one): the LDS side is 16-byte aligned as well -- one
+            // ds_read_b128 + one ds_write_b128 per 16 bytes instead of four 4-byte reads and four writes (the tile is
+            // declared 16-byte aligned; LDS instructions were 22 % of the kernel's wave cycles)
+            vec<T, V>* av = reinterpret_cast<vec<T, V>*>(a0);
+            vec<T, V> z;
 #pragma unroll
-            for (int v = 0; v < V; ++v) a0[k * V + v] = vt<T>::zero();
+            for (int v = 0; v < V; ++v) z.v[v] = vt<T>::zero();
+            for (int64_t k = tid; k < body; k += nthreads) {
+                const vec<T, V> x = av[k];
+                nt_store16(p0 + head + k * V, x.v);
+                av[k] = z;
+            }
+        } else {
+            for (int64_t k = tid; k < body; k += nthreads) {
+                nt_store16(p0 + head + k * V, a0 + k * V);
+#pragma unroll
+                for (int v = 0; v < V; ++v) a0[k * V + v] = vt<T>::zero();
+            }
         }
         const int64_t done = head + body * V;
         if (tid < j_hi - j_lo - done) {
@@ -230,19 +265,21 @@ __device__ __forceinline__ void syrkd_flush_tile(T* acc, T* crow, int64_t c_cs, 
     }
 }
 
-template <typename T, int TKB, bool TABLE>  // TABLE: several tiles per row -> slice bounds from `off`; else the slice is the row
+// MODE 0: one tile per row (the slice is the row); 1: slice bounds from the per-row table `off`; 2: from the records that
+// travel with the entries of X^T (`head`)
+template <typename T, int TKB, int MODE>
 __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     k_syrkd_sliced(int64_t n, int64_t row0, int64_t row_end, int64_t G, const int64_t* __restrict__ tptr,
                    const int32_t* __restrict__ tcol, const T* __restrict__ tval, const int64_t* __restrict__ xptr,
-                   const SpEntry<T>* __restrict__ rec, const int32_t* __restrict__ off, T* __restrict__ C, int64_t c_rs,
-                   int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual)
+                   const SpEntry<T>* __restrict__ rec, const int32_t* __restrict__ off, const GramHead* __restrict__ head,
+                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual)
 {
     constexpr int TILE = syrkd_tile<T, TKB>();
     constexpr int SUB = 8;            // lanes per selected row
     constexpr int RPS = WAVE / SUB;   // rows per step
     constexpr int NSTEP = WAVE / RPS; // steps per 64 rows, all in flight together
     constexpr int HH = sizeof(T) <= 4 ? 2 : 1;  // halves of SUB entries requested together (registers: 8-byte values get one)
-    __shared__ T acc[TILE];
+    __shared__ __attribute__((aligned(16))) T acc[TILE];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid / WAVE, lane = tid % WAVE, nwaves = nthreads / WAVE;
     const int sub = lane % SUB, grp = lane / SUB;
@@ -285,19 +322,28 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         h.t0 = tptr[p.i];
         h.t1 = tptr[p.i + (p.ok ? 1 : 0)];  // an empty extent for positions that hold nothing (no branch around a load)
     };
-    auto stage_b = [&](Head& h) {
+    auto stage_b = [&](int64_t g, Head& h) {
         const int64_t base = h.t0 + (int64_t)wave * WAVE;
         int64_t q = base + lane < h.t1 ? base + lane : h.t1 - 1;  // always a valid entry ...
         if (q < 0) q = 0;                                          // ... (the kernel is only launched with nnz > 0)
-        h.r = tcol[q];
         h.a = vt<T>::mul(alpha, tval[q]);
+        if constexpr (MODE == 2) {  // the bounds arrive with the entry: 16 coalesced bytes, no further level
+            const GramHead hd = head[q];
+            const int o0 = hd.left((int)g), o1 = hd.left((int)g + 1);
+            h.r = 0;
+            h.s = hd.start + o0;
+            h.len = base + lane < h.t1 ? o1 - o0 : 0;
+        } else {
+            h.r = tcol[q];
+        }
     };
     auto stage_c = [&](int64_t g, Head& h) {
+        if constexpr (MODE == 2) return;
         const int64_t base = h.t0 + (int64_t)wave * WAVE;
         const bool valid = base + lane < h.t1;
         // (a run-time branch on `off` around these loads made the compiler drain vmcnt to 0 at the join: a template flag)
         int64_t o0, o1;
-        if constexpr (TABLE) {
+        if constexpr (MODE == 1) {
             const int32_t* orow = off + (int64_t)h.r * (G + 1) + g;
             o0 = orow[0];
             o1 = orow[1];
@@ -342,10 +388,10 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     Pos p0 = seek(blockIdx.x), p1 = after(p0), p2 = after(p1), p3 = after(p2);
     Head h0, h1, h2, h3;
     stage_a(p0, h0);
-    stage_b(h0);
+    stage_b(p0.g, h0);
     stage_c(p0.g, h0);
     stage_a(p1, h1);
-    stage_b(h1);
+    stage_b(p1.g, h1);
     stage_a(p2, h2);
     for (int k = tid; k < TILE; k += nthreads) acc[k] = vt<T>::zero();
     __syncthreads();
@@ -356,7 +402,7 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         const int64_t j_hi = tile_lo + TILE < n ? tile_lo + TILE : n;
         // (1) the chain of the tiles ahead, one level each: issued together, consumed one tile later
         stage_c(p1.g, h1);
-        stage_b(h2);
+        stage_b(p2.g, h2);
         stage_a(p3, h3);
         // (2) this tile's products into LDS
         walk64(h0, j_lo, tile_lo);
@@ -365,7 +411,7 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
             Head h;
             h.t0 = base - (int64_t)wave * WAVE;  // so that stage_b / stage_c address `base`
             h.t1 = h0.t1;
-            stage_b(h);
+            stage_b(g, h);
             stage_c(g, h);
             walk64(h, j_lo, tile_lo);
         }
@@ -447,40 +493,89 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
             while (g > 1 && gcd(g, tiles_per_row) != 1) --g;
             if (g * 8 < grid) grid = g * 8;
         }
+        // the sliced walk's two cached tables; if the device has no room for them (a 256 GiB output leaves little), the
+        // whole-row walk runs instead
         const int32_t* off = nullptr;
-        if (sliced && tiles_per_row > 1) {
-            if (x.gram_off_w != tile || !x.gram_off.p) {
-                x.gram_off.alloc(need);
-                MI_LAUNCH(k_gram_offsets, dim3((unsigned)ceil_div(x.rows * (tiles_per_row + 1), 256)), dim3(256), c.stream,
-                          x.rows, tiles_per_row, tile, (const int64_t*)x.ptr, (const int32_t*)x.col, x.gram_off.as<int32_t>());
-                x.gram_off_w = tile;
-            }
-            off = x.gram_off.as<int32_t>();
-        }
         const SpEntry<T>* rec = nullptr;
-        if (sliced) {  // packed (column, value) records of X, cached on the handle
-            if (!x.gram_rec.p) {
-                x.gram_rec.alloc(sizeof(SpEntry<T>) * (size_t)x.nnz);
-                const int64_t pg = ceil_div(x.nnz, 256) < 65536 ? ceil_div(x.nnz, 256) : 65536;
-                MI_LAUNCH((k_gram_pack<T>), dim3((unsigned)pg), dim3(256), c.stream, x.nnz, (const int32_t*)x.col, (const T*)x.val,
-                          x.gram_rec.as<SpEntry<T>>());
+        if (sliced) {
+            try {
+                if (tiles_per_row > 1 && (x.gram_off_w != tile || !x.gram_off.p)) {
+                    x.gram_off_w = 0;
+                    x.gram_off.alloc(need);
+                    MI_LAUNCH(k_gram_offsets, dim3((unsigned)ceil_div(x.rows * (tiles_per_row + 1), 256)), dim3(256), c.stream,
+                              x.rows, tiles_per_row, tile, (const int64_t*)x.ptr, (const int32_t*)x.col, x.gram_off.as<int32_t>());
+                    x.gram_off_w = tile;
+                }
+                if (!x.gram_rec.p) {  // packed (column, value) records of X
+                    x.gram_rec.alloc(sizeof(SpEntry<T>) * (size_t)x.nnz);
+                    const int64_t pg = ceil_div(x.nnz, 256) < 65536 ? ceil_div(x.nnz, 256) : 65536;
+                    MI_LAUNCH((k_gram_pack<T>), dim3((unsigned)pg), dim3(256), c.stream, x.nnz, (const int32_t*)x.col,
+                              (const T*)x.val, x.gram_rec.as<SpEntry<T>>());
+                }
+                if (tiles_per_row > 1) off = x.gram_off.as<int32_t>();
+                rec = x.gram_rec.as<SpEntry<T>>();
+            } catch (const status_error&) {
+                clear_error();
+                x.gram_rec.release();
+                sliced = false;
+                off = nullptr;
+                if (persistent > 0 && options().gram_persistent < 0) {  // the whole-row walk's default grid
+                    const int64_t slots = (int64_t)c.cus * (wide ? 1 : 2) * 4;
+                    int64_t g = slots / 8 > 0 ? slots / 8 : 1;
+                    auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t r = a % b; a = b; b = r; } return a; };
+                    while (g > 1 && gcd(g, tiles_per_row) != 1) --g;
+                    grid = g * 8 < nblocks ? g * 8 : nblocks;
+                }
             }
-            rec = x.gram_rec.as<SpEntry<T>>();
         }
 #define MI_SYRKD_ARGS                                                                                               \
     (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, (const int32_t*)x.col,   \
         (const T*)x.val
-        note_kernel("mi::%s<%s, TKB=%d%s>", sliced ? "k_syrkd_sliced" : "k_syrkd_lds", type_name<T>(), wide ? 128 : 64,
-                    sliced ? (off ? ", TABLE=1" : ", TABLE=0") : "");
+        // slice bounds travelling with the entries of X^T (rows of X of at most 255 entries, at most 11 tiles per row)
+        const GramHead* head = nullptr;
+        if (sliced && off && tiles_per_row <= GRAM_HEAD_MAXG && options().gram_heads) {
+            if (x.gram_max_row < 0) {
+                long long* dm = static_cast<long long*>(c.scratch_alloc(sizeof(long long)));
+                MI_HIP_CHECK(hipMemsetAsync(dm, 0, sizeof(long long), c.stream));
+                MI_LAUNCH(k_gram_max_row, dim3((unsigned)(ceil_div(x.rows, 256) < 4096 ? ceil_div(x.rows, 256) : 4096)), dim3(256),
+                          c.stream, x.rows, (const int64_t*)x.ptr, dm);
+                long long hm = 0;
+                MI_HIP_CHECK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, c.stream));
+                MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+                x.gram_max_row = (int64_t)hm;
+            }
+            if (x.gram_max_row <= 255) {
+                bool have = t.gram_head_w == tile && t.gram_head.p;
+                if (!have) {
+                    try {  // 16 bytes per nonzero: with a 256 GiB output on the device there may be no room -- the table still works
+                        t.gram_head.alloc(sizeof(GramHead) * (size_t)t.nnz);
+                        have = true;
+                    } catch (const status_error&) {
+                        clear_error();
+                        t.gram_head_w = 0;
+                    }
+                    if (have) {
+                        const int64_t hg = ceil_div(t.nnz, 256) < 65536 ? ceil_div(t.nnz, 256) : 65536;
+                        MI_LAUNCH(k_gram_heads, dim3((unsigned)hg), dim3(256), c.stream, t.nnz, tiles_per_row,
+                                  (const int32_t*)t.col, off, t.gram_head.as<GramHead>());
+                        t.gram_head_w = tile;
+                    }
+                }
+                if (have) head = t.gram_head.as<GramHead>();
+            }
+        }
+        const int mode = !sliced ? -1 : head ? 2 : off ? 1 : 0;
+        note_kernel("mi::%s<%s, TKB=%d%s%.0d>", sliced ? "k_syrkd_sliced" : "k_syrkd_lds", type_name<T>(), wide ? 128 : 64,
+                    sliced ? ", MODE=" : "", sliced ? mode + 0 : 0);
         if (sliced) {
-#define MI_SLICED(TKB_, TABLE_, THREADS_)                                                                              \
-    MI_LAUNCH((k_syrkd_sliced<T, TKB_, TABLE_>), dim3((unsigned)grid), dim3(THREADS_), c.stream, n, row0, row1,          \
-              tiles_per_row, (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, rec, off, dC,   \
-              c_rs, c_cs, alpha, beta, beta_zero, nblocks)
+#define MI_SLICED(TKB_, MODE_, THREADS_)                                                                               \
+    MI_LAUNCH((k_syrkd_sliced<T, TKB_, MODE_>), dim3((unsigned)grid), dim3(THREADS_), c.stream, n, row0, row1,           \
+              tiles_per_row, (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, rec, off, head, \
+              dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks)
             if (wide) {
-                if (off) MI_SLICED(128, true, 1024); else MI_SLICED(128, false, 1024);
+                if (mode == 2) MI_SLICED(128, 2, 1024); else if (mode == 1) MI_SLICED(128, 1, 1024); else MI_SLICED(128, 0, 1024);
             } else {
-                if (off) MI_SLICED(64, true, 512); else MI_SLICED(64, false, 512);
+                if (mode == 2) MI_SLICED(64, 2, 512); else if (mode == 1) MI_SLICED(64, 1, 512); else MI_SLICED(64, 0, 512);
             }
 #undef MI_SLICED
         } else if (wide) {

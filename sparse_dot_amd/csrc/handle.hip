@@ -409,6 +409,8 @@ void sort_csr(char vtype, Csr& a)
     a.gram_rec.release();  // caches that follow the storage order of the entries (dense gram)
     a.gram_off.release();
     a.gram_off_w = 0;
+    a.gram_head.release();
+    a.gram_head_w = 0;
     // already sorted? (scipy's canonical matrices are)
     if (rows_sorted(a)) {
         a.sorted = true;

@@ -782,6 +782,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
                 mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_slices must be 0 (automatic), 1, 2, 4 or 8");
             o.spmm_slices = value;
+        } else if (!strcmp(name, "gram_heads")) {
+            o.gram_heads = value;
         } else if (!strcmp(name, "gram_sliced")) {
             o.gram_sliced = value;
         } else if (!strcmp(name, "gram_persistent")) {

@@ -491,9 +491,9 @@ __global__ void __launch_bounds__(8 * LPN)
 {
     constexpr int G = 8, U = 4;
     __shared__ T part_s[G][LPN * V];
-    const int64_t task = blockIdx.x;
-    if (task >= (int64_t)*n_tasks_dev) return;  // the count lives on the device (the grid may be an upper bound)
     const int g = threadIdx.x / LPN, li = threadIdx.x % LPN;
+    const int64_t n_tasks = (int64_t)*n_tasks_dev;  // the count lives on the device (the grid may be an upper bound, and is capped)
+    for (int64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
     const int64_t row = tasks[3 * task], first = tasks[3 * task + 1], last = tasks[3 * task + 2];
     for (int64_t j0 = 0; j0 < N; j0 += (int64_t)LPN * V) {
         const int64_t jc = j0 + (int64_t)li * V;
@@ -540,6 +540,7 @@ __global__ void __launch_bounds__(8 * LPN)
             }
         }
         __syncthreads();
+    }
     }
 }
 
@@ -911,6 +912,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk, hot_rows);
     // fix-up grid: the exact task count once it has reached the host, else its upper bound
     const int64_t fix_tasks = p.n_tasks >= 0 ? p.n_tasks : p.nchunks;
+    const int64_t fix_grid = fix_tasks < ((int64_t)1 << 20) ? fix_tasks : ((int64_t)1 << 20);  // one workgroup per task, grid-stride beyond 2^20
     const unsigned long long* n_tasks_dev = static_cast<const unsigned long long*>(p.n_tasks_dev.p);
     T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)p.nchunks * (size_t)N));
     const bool row_major = (layout == MI_SPARSE_LAYOUT_ROW_MAJOR);
@@ -930,7 +932,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
                        (const T*)m.val, (const SpmmChunk*)p.chunk_desc.as<SpmmChunk>(), p.nchunks, p.chunk, conj_a, B, b_rs,
                        C, c_rs, alpha, beta, (int)(vt<T>::is_zero(beta) ? 1 : 0), carry_val);
         if (fix_tasks)
-            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)fix_tasks), dim3(8 * 16), c.stream,
+            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)fix_grid), dim3(8 * 16), c.stream,
                       n_tasks_dev, (const int32_t*)p.tasks.as<int32_t>(), (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         plan_after_product(h, transposed, m, hot_rows);
         return;
@@ -976,13 +978,13 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         const int32_t* tk = p.tasks.as<int32_t>();
         if (vec_ok) {
             if (N / V16 > 16)
-                MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)fix_tasks), dim3(8 * 32), c.stream,
+                MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)fix_grid), dim3(8 * 32), c.stream,
                           n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
             else
-                MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)fix_tasks), dim3(8 * 8), c.stream,
+                MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)fix_grid), dim3(8 * 8), c.stream,
                           n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         } else {
-            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)fix_tasks), dim3(8 * 16), c.stream,
+            MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)fix_grid), dim3(8 * 16), c.stream,
                       n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         }
     }

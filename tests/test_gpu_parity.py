@@ -1193,8 +1193,10 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         one, zero = (ct.c_float(1.0), ct.c_float(0.0)) if dtype == np.float32 else (ct.c_double(1.0), ct.c_double(0.0))
         # (sliced, tile KiB, persistent): sliced 2 = the pipelined slice walk, 0 = the whole-row walk; persistent = workgroups
         # per LDS slot walking the tile list (0: one workgroup per tile, -1: default)
-        for sliced, tile_kb, persistent in ((2, 128, -1), (2, 64, 4), (2, 64, -1), (2, 128, 1), (2, 128, 0), (2, 64, 0),
-                                            (0, 128, -1), (0, 64, 1), (1, 128, -1)):
+        # heads = 1: slice bounds travel with the entries of X^T (rows of X <= 255 entries); 0: per-row table
+        for sliced, tile_kb, persistent, heads in ((2, 128, -1, 1), (2, 64, 4, 1), (2, 64, -1, 0), (2, 128, 1, 0), (2, 128, 0, 1),
+                                                   (2, 64, 0, 1), (0, 128, -1, 1), (0, 64, 1, 1), (1, 128, -1, 1)):
+            gpu.mi_set_option("gram_heads", heads)
             gpu.mi_set_option("gram_sliced", sliced)
             gpu.mi_set_option("gram_tile_kb", tile_kb)
             gpu.mi_set_option("gram_persistent", persistent)
@@ -1249,6 +1251,7 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         gpu.mi_set_option("gram_sliced", 1)
         gpu.mi_set_option("gram_tile_kb", 128)
         gpu.mi_set_option("gram_persistent", -1)
+        gpu.mi_set_option("gram_heads", 1)
         for h in handles:
             MI.call("mi_sparse_destroy", h)
         gpu.mi_set_stream(0)
