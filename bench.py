@@ -474,6 +474,7 @@ def secondary_gram(torch, abi, dev, with_cpu):
     if C is None:
         return {"workload": "gram cfg4", "error": note}
     ip, idx, val, _ = uniform_csr(torch, m, 64, 3, dev, ncols=ncols)
+    torch.cuda.empty_cache()  # the generator's temporaries back to the driver: the library caches ~9 GB of tables next to the 256 GiB output
     h = abi.create("s", ip, idx, val, m, ncols)
     times = []
     for rep in range(3):
@@ -501,7 +502,8 @@ def secondary_gram(torch, abi, dev, with_cpu):
                         "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes,
                         "note": "nnz * 8 + (M + 1) * 8 + n (n + 1) / 2 * 4 (the triangle written once) over the "
                                 "mi_sparse_s_syrkd call (best of 2 after 1 warm-up)"},
-           "parity_diag_max_rel_err": diag_err, "lower_triangle_untouched_sample": lower_zero}
+           "parity_diag_max_rel_err": diag_err, "lower_triangle_untouched_sample": lower_zero,
+           "kernel": abi.sda.mi_get_last_kernel()}
     assert diag_err <= 1e-5 and lower_zero, "gram parity check failed (%g, %s)" % (diag_err, lower_zero)
     abi.destroy(h)
     del C
