@@ -496,7 +496,7 @@ struct Options {
     int64_t gram_heads = 1;        // sliced dense gram: slice bounds travel with the entries of X^T (rows of X <= 255 entries, <= 11 tiles per row); 0: per-row table
     int64_t gram_sliced = 1;       // dense gram: slice table + 8 lanes per selected row when rows of X are sorted and slices are short (<= 12 entries on average); 2: whenever sorted; 0: never
     int64_t gram_persistent = -1;   // dense gram: workgroups per LDS slot of the chip walking the tile list (0: one workgroup per tile; -1: 1 for the sliced walk, 4 for the whole-row walk)
-    int64_t gram_tile_kb = 128;    // dense gram, outputs wider than one 64 KiB tile: LDS tile of 128 (default) or 64 KiB
+    int64_t gram_tile_kb = 0;      // dense gram LDS tile: 0 = 152 KiB where that saves a tile per output row, else 128; 64 / 128 / 152 force
     int64_t bsr_native = 1;        // BSR handles x row-major dense: the block kernel (0: always the CSR expansion)
     int64_t staged_copies = 1;     // large pageable host <-> device copies through the parallel pinned stager (0: plain hipMemcpy)
     int64_t profile_events = 0;    // bracket the SpMM main kernel with hipEvents (diagnostics)

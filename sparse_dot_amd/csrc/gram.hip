@@ -181,11 +181,16 @@ __global__ void k_gram_pack(int64_t nnz, const int32_t* __restrict__ col, const 
 // width from the per-row table (k_gram_heads); 16 bytes per nonzero.
 struct alignas(16) GramHead {
     int32_t start;
-    uint32_t w[3];  // byte g of (w[0], w[1], w[2]) = entries of the row left of tile boundary g
+    uint32_t w0, w1, w2;  // byte g of (w0, w1, w2) = entries of the row left of tile boundary g
     __host__ __device__ __forceinline__ int left(int g) const
     {
-        const uint32_t word = g < 4 ? w[0] : g < 8 ? w[1] : w[2];  // g is uniform: selects, no indexed register array
-        return (int)((word >> ((g & 3) * 8)) & 255u);
+        // g is uniform.  All three words are USED (shifted), the select is between computed values: as `g < 4 ? w[0] : g < 8 ? w[1] : w[2]` over an
+        // array the compiler folded the selects of loads into one load at a selected address, which kept the 16-byte
+        // record in memory -- an alloca it then promoted to LDS (32 KB next to the 128 KB tile): every tile paid a
+        // ds_write_b128 + three ds_read_b32 per lane and waited for the record it had just requested.
+        const uint64_t lo = ((uint64_t)w1 << 32) | w0;
+        const uint32_t a = (uint32_t)(lo >> ((g & 7) * 8)), b = w2 >> ((g & 3) * 8);  // boundaries 0-7 / 8-11
+        return (int)((g < 8 ? a : b) & 255u);
     }
 };
 constexpr int GRAM_HEAD_MAXG = 11;
@@ -197,9 +202,12 @@ __global__ void k_gram_heads(int64_t nnz, int64_t G, const int32_t* __restrict__
         const int32_t* orow = off + (int64_t)tcol[q] * (G + 1);
         GramHead h;
         h.start = orow[0];
-        h.w[0] = h.w[1] = h.w[2] = 0u;
+        uint32_t w[3] = {0u, 0u, 0u};
 #pragma unroll
-        for (int g = 0; g < 12; ++g) h.w[g >> 2] |= (uint32_t)((orow[g <= G ? g : G] - h.start) & 255) << ((g & 3) * 8);
+        for (int g = 0; g < 12; ++g) w[g >> 2] |= (uint32_t)((orow[g <= G ? g : G] - h.start) & 255) << ((g & 3) * 8);
+        h.w0 = w[0];
+        h.w1 = w[1];
+        h.w2 = w[2];
         head[q] = h;
     }
 }
@@ -465,9 +473,17 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         T* dC = static_cast<T*>(sc.dev);
         // wide outputs (more than one 64 KiB tile per row): 128 KiB tiles, one workgroup per CU
         const bool wide = n > (int64_t)syrkd_tile<T, 64>() && options().gram_tile_kb != 64;
-        const int64_t tile = wide ? syrkd_tile<T, 128>() : syrkd_tile<T, 64>();
-        const int64_t tiles_per_row = ceil_div(n, tile);
-        const int64_t nblocks = ceil_div(nr, 8) * 8 * tiles_per_row;  // 8 rows (one per XCD) x all their tiles per group
+        // 152 KiB tiles (all a workgroup can have next to nothing else) when they save a tile per output row: every (selected
+        // row, tile) pair is a line request, so the literal configs[3] (262 144 columns) runs 7 tiles per row instead of 8
+        bool xwide = wide && options().gram_tile_kb != 128 && options().gram_sliced != 0 &&
+                     (options().gram_tile_kb == 152 || ceil_div(n, (int64_t)syrkd_tile<T, 152>()) < ceil_div(n, (int64_t)syrkd_tile<T, 128>()));
+        int64_t tile = 0, tiles_per_row = 0, nblocks = 0;
+        auto set_tile = [&]() {
+            tile = xwide ? syrkd_tile<T, 152>() : wide ? syrkd_tile<T, 128>() : syrkd_tile<T, 64>();
+            tiles_per_row = ceil_div(n, tile);
+            nblocks = ceil_div(nr, 8) * 8 * tiles_per_row;  // 8 rows (one per XCD) x all their tiles per group
+        };
+        set_tile();
         if (nblocks > 2000000000) fail(MI_SPARSE_STATUS_NOT_SUPPORTED, "gram output too large for one launch");
         // sliced walk when the rows of X are sorted (always, for a transpose built here) and a row's share of one tile is
         // short: with long slices the whole-row walk (64 lanes per row) is the faster one (2^20 x 65 536, 64 per row:
@@ -478,8 +494,13 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
             if (rows_sorted(x)) x.sorted = true; else sliced = false;
         }
         if (x.nnz >= ((int64_t)1 << 31) - 64) sliced = false;  // 32-bit absolute positions in the slice table
-        const size_t need = sizeof(int32_t) * (size_t)x.rows * (size_t)(tiles_per_row + 1);
+        size_t need = sizeof(int32_t) * (size_t)x.rows * (size_t)(tiles_per_row + 1);
         if (need > ((size_t)16 << 30)) sliced = false;  // slice table out of proportion (very tall X, very wide output)
+        if (xwide && !sliced) {  // the whole-row walk keeps its 128 KiB tiles
+            xwide = false;
+            set_tile();
+            need = sizeof(int32_t) * (size_t)x.rows * (size_t)(tiles_per_row + 1);
+        }
         // persistent grid: gram_persistent workgroups per LDS slot (one 128 KiB or two 64 KiB tiles per CU), a multiple of 8
         int64_t grid = nblocks;
         const int64_t persistent = options().gram_persistent >= 0 ? options().gram_persistent : (sliced ? 1 : 4);
@@ -519,6 +540,10 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
                 x.gram_rec.release();
                 sliced = false;
                 off = nullptr;
+                if (xwide) {
+                    xwide = false;
+                    set_tile();
+                }
                 if (persistent > 0 && options().gram_persistent < 0) {  // the whole-row walk's default grid
                     const int64_t slots = (int64_t)c.cus * (wide ? 1 : 2) * 4;
                     int64_t g = slots / 8 > 0 ? slots / 8 : 1;
@@ -565,14 +590,16 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
             }
         }
         const int mode = !sliced ? -1 : head ? 2 : off ? 1 : 0;
-        note_kernel("mi::%s<%s, TKB=%d%s%.0d>", sliced ? "k_syrkd_sliced" : "k_syrkd_lds", type_name<T>(), wide ? 128 : 64,
+        note_kernel("mi::%s<%s, TKB=%d%s%.0d>", sliced ? "k_syrkd_sliced" : "k_syrkd_lds", type_name<T>(), xwide ? 152 : wide ? 128 : 64,
                     sliced ? ", MODE=" : "", sliced ? mode + 0 : 0);
         if (sliced) {
 #define MI_SLICED(TKB_, MODE_, THREADS_)                                                                               \
     MI_LAUNCH((k_syrkd_sliced<T, TKB_, MODE_>), dim3((unsigned)grid), dim3(THREADS_), c.stream, n, row0, row1,           \
               tiles_per_row, (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, rec, off, head, \
               dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks)
-            if (wide) {
+            if (xwide) {
+                if (mode == 2) MI_SLICED(152, 2, 1024); else if (mode == 1) MI_SLICED(152, 1, 1024); else MI_SLICED(152, 0, 1024);
+            } else if (wide) {
                 if (mode == 2) MI_SLICED(128, 2, 1024); else if (mode == 1) MI_SLICED(128, 1, 1024); else MI_SLICED(128, 0, 1024);
             } else {
                 if (mode == 2) MI_SLICED(64, 2, 512); else if (mode == 1) MI_SLICED(64, 1, 512); else MI_SLICED(64, 0, 512);

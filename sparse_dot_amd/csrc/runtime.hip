@@ -789,7 +789,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
         } else if (!strcmp(name, "gram_persistent")) {
             o.gram_persistent = value;
         } else if (!strcmp(name, "gram_tile_kb")) {
-            if (value != 64 && value != 128) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "gram_tile_kb must be 64 or 128");
+            if (value != 0 && value != 64 && value != 128 && value != 152)
+                mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "gram_tile_kb must be 0 (automatic), 64, 128 or 152");
             o.gram_tile_kb = value;
         } else if (!strcmp(name, "bsr_native")) {
             o.bsr_native = value;

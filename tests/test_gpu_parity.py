@@ -1195,7 +1195,8 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         # per LDS slot walking the tile list (0: one workgroup per tile, -1: default)
         # heads = 1: slice bounds travel with the entries of X^T (rows of X <= 255 entries); 0: per-row table
         for sliced, tile_kb, persistent, heads in ((2, 128, -1, 1), (2, 64, 4, 1), (2, 64, -1, 0), (2, 128, 1, 0), (2, 128, 0, 1),
-                                                   (2, 64, 0, 1), (0, 128, -1, 1), (0, 64, 1, 1), (1, 128, -1, 1)):
+                                                   (2, 64, 0, 1), (0, 128, -1, 1), (0, 64, 1, 1), (1, 128, -1, 1),
+                                                   (2, 152, -1, 1), (2, 152, 0, 0), (2, 0, -1, 1), (0, 152, -1, 1), (1, 0, -1, 1)):
             gpu.mi_set_option("gram_heads", heads)
             gpu.mi_set_option("gram_sliced", sliced)
             gpu.mi_set_option("gram_tile_kb", tile_kb)
@@ -1206,9 +1207,9 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
             check_rows(C, 0, sample)
             C = None
         gpu.mi_set_option("gram_sliced", 2)
-        gpu.mi_set_option("gram_tile_kb", 128)
+        gpu.mi_set_option("gram_tile_kb", 152)
         gpu.mi_set_option("gram_persistent", -1)
-        # a band of output rows that starts inside a tile
+        # a band of output rows that starts inside a tile (152 KiB tiles: boundaries that are not powers of two)
         r0, r1 = 20001, 20001 + 4099
         band = torch.full((r1 - r0, n), -7.0, device=dev, dtype=tdt)
         _check_return_value(MI.call("mi_sparse_%s_syrkd_rows" % pre, 11, h, one, zero, band.data_ptr(), 101, n, r0, r1), "rows")
@@ -1249,7 +1250,7 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
         C = None
     finally:
         gpu.mi_set_option("gram_sliced", 1)
-        gpu.mi_set_option("gram_tile_kb", 128)
+        gpu.mi_set_option("gram_tile_kb", 0)
         gpu.mi_set_option("gram_persistent", -1)
         gpu.mi_set_option("gram_heads", 1)
         for h in handles:
