@@ -486,7 +486,8 @@ def secondary_gram(torch, abi, dev, with_cpu):
             times.append(time.perf_counter() - t0)
     t = min(times)
     colsq = torch.zeros(ncols, device=dev, dtype=torch.float64)
-    colsq.index_add_(0, idx.long(), val.double() ** 2)
+    for lo in range(0, int(idx.numel()), 1 << 24):  # in pieces: next to the 256 GiB output and the library's tables ~1 GiB is free
+        colsq.index_add_(0, idx[lo:lo + (1 << 24)].long(), val[lo:lo + (1 << 24)].double() ** 2)
     diag_err = float(((torch.diagonal(C).double() - colsq).abs() / colsq.clamp(min=1e-30)).max())
     lower_zero = bool((torch.tril(C[-4096:, -4096:], -1) == 0).all()) and bool((C[-4096:, :4096] == 0).all())
     lens = (ip[1:] - ip[:-1]).double()
