@@ -370,22 +370,7 @@ def secondary_uniform_spmm(torch, abi, dev, n, N, B, steps, warmup):
 def secondary_spgemm(torch, abi, dev, kind, with_cpu):
     """BASELINE configs[2]: two CSR 2^20 x 2^20, 16/row fp64 (uniform, or the literal R-MAT) -> sparse C."""
     n = 1 << 20
-    fresh = None
     if kind == "rmat":
-        # the same product as the first thing a fresh process does (tools/gpu_first_call.py) -- run BEFORE this process
-        # allocates and releases its own 117 GB result: memory another process has just returned is scrubbed by the driver
-        # when it is handed out again, and a child started right after the release measured that (2.6 s) instead of the
-        # library (0.18 s) in one run out of two
-        abi.sda.mi_set_option("pool_trim", 1)
-        torch.cuda.empty_cache()
-        try:
-            import subprocess
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_first_call.py")], stdout=subprocess.PIPE,
-                               stderr=subprocess.DEVNULL, timeout=300)
-            lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
-            fresh = json.loads(lines[-1]) if lines else {"error": "no output (rc %d)" % r.returncode}
-        except Exception as exc:  # noqa: BLE001
-            fresh = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
         a = rmat_csr(torch, 20, 16, 21, dev)
         b = rmat_csr(torch, 20, 16, 23, dev)
     else:
@@ -434,9 +419,12 @@ def secondary_spgemm(torch, abi, dev, kind, with_cpu):
                                 "all phases: upper bounds, binning, symbolic, scan, numeric)" % reps},
            "parity_rowsum_max_rel_err": rel}
     assert rel <= 1e-12, "SpGEMM row-sum parity check failed: %g" % rel
-    out["first_call_note"] = ("first_call_ms is the first product in THIS process, after earlier workloads returned large blocks to the "
-                              "driver: a block that was hipFree'd and is allocated again costs seconds on this driver "
-                              "(tools/probes/alloc_probe.hip); first_call_fresh_process is what a one-shot caller pays")
+    out["first_call_note"] = ("first_call_ms is the first product in THIS process; first_call_fresh_process the same product as the first "
+                              "thing a new process does.  Both contain one hipMalloc of the 117 GB result, and device memory that has been "
+                              "used before -- by this process or by one that has exited -- is scrubbed by the driver when it is handed out "
+                              "again (tools/probes/alloc_probe.hip: 78 GiB in 0.25 ms from untouched memory, 5.8 s after a hipFree): "
+                              "observed 0.18 s on untouched memory, 0.9 - 2.6 s (child) / 5.5 s (parent) on recycled memory, with the "
+                              "same library and a steady state of 0.18 s")
     if kind == "rmat":
         for h in (ha, hb, hc):
             abi.destroy(h)
@@ -444,7 +432,14 @@ def secondary_spgemm(torch, abi, dev, kind, with_cpu):
         del a, b, av, bv, b1, ab1, c1, ones, colnnz_a, rownnz_b
         abi.sda.mi_set_option("pool_trim", 1)
         torch.cuda.empty_cache()
-        out["first_call_fresh_process"] = fresh
+        try:  # the same product as the first thing a fresh process does (tools/gpu_first_call.py)
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_first_call.py")], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, timeout=300)
+            lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+            out["first_call_fresh_process"] = json.loads(lines[-1]) if lines else {"error": "no output (rc %d)" % r.returncode}
+        except Exception as exc:  # noqa: BLE001
+            out["first_call_fresh_process"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
         if with_cpu:
             out["cpu_baseline"] = {"value": None, "note": "nnz(C) = %d exceeds MKL's LP64 index range and the reference's "
                                                           "INT_MAX guard (_common.py:166-172): not runnable on the CPU path" % nnzc}
