@@ -384,7 +384,10 @@ mi_sparse_status_t mi_sparse_d_syprd(int op, mi_sparse_matrix_t A, const double 
                                      double alpha, double beta, double *C, int layout_c, int64_t ldc);
 /* Replace ALL values of a handle (storage order of the arrays it was created from; host or device pointer), keeping
  * its pattern and its plans -- the analogue of updating the aliased value array in place under MKL
- * (mkl_sparse_?_update_values): what makes NNZ_COUNT once / FINALIZE_MULT many times useful. */
+ * (mkl_sparse_?_update_values): what makes NNZ_COUNT once / FINALIZE_MULT many times useful.
+ * A handle created from DEVICE arrays aliases them, but it also keeps derived copies of the values (the cached
+ * transpose, the packed records of the dense gram): values of aliased device arrays must therefore be changed through
+ * this call, not by writing the arrays in place -- an in-place write leaves those copies stale. */
 mi_sparse_status_t mi_sparse_s_set_values(mi_sparse_matrix_t A, const float *values);
 mi_sparse_status_t mi_sparse_d_set_values(mi_sparse_matrix_t A, const double *values);
 mi_sparse_status_t mi_sparse_c_set_values(mi_sparse_matrix_t A, const mi_complex8 *values);

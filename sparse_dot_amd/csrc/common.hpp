@@ -345,6 +345,10 @@ struct Csr {
     DevBuf ptr_own, col_own, val_own;  // storage when the library owns it (else aliases caller HBM)
     bool valid = false;
     bool sorted = false;  // column indices known to be ascending inside every row
+    // generation of the ENTRY ORDER inside the rows: a fresh value (next_order_gen) whenever the entries are (re)laid out --
+    // built, transposed into, re-sorted.  Anything that indexes per-entry tables by position (the staged product's B-row
+    // extents, spgemm.hip) records it and checks it again before trusting those tables.
+    uint64_t order_gen = 0;
     // dense gram (gram.hip): ABSOLUTE position of the first entry of every row at or right of each tile boundary, int32[rows * (cols / w + 2)], built on first
     // use for tile width gram_off_w (structure only: unaffected by set_values)
     DevBuf gram_off;
@@ -358,6 +362,8 @@ struct Csr {
     int64_t gram_head_w = 0;
     int64_t gram_max_row = -1;
 };
+
+uint64_t next_order_gen();  // handle.hip: process-wide, never repeats
 
 // block form kept next to the CSR expansion on handles created from BSR arrays: the SpMM block kernel (bsr.hip) reads it
 struct Bsr {

@@ -5,6 +5,7 @@
 // Internal canonical form (mi::Csr): int64 row pointer (rows + 1), int32 column index, values.
 // Reference call sites replaced: sparse_dot_mkl/_mkl_interface/_common.py:245-384 (create),
 // 387-609 (export), 671-722 (destroy / order / convert).
+#include <atomic>
 #include <climits>
 
 #include "common.hpp"
@@ -404,18 +405,26 @@ bool rows_sorted(const Csr& a)
     return !hflag;
 }
 
+uint64_t next_order_gen()
+{
+    static std::atomic<uint64_t> g{0};
+    return ++g;
+}
+
 void sort_csr(char vtype, Csr& a)
 {
+    // already sorted? (scipy's canonical matrices are, and the reference orders after every product): nothing moves, the
+    // caches that follow the storage order stay valid
+    if (rows_sorted(a)) {
+        a.sorted = true;
+        return;
+    }
     a.gram_rec.release();  // caches that follow the storage order of the entries (dense gram)
     a.gram_off.release();
     a.gram_off_w = 0;
     a.gram_head.release();
     a.gram_head_w = 0;
-    // already sorted? (scipy's canonical matrices are)
-    if (rows_sorted(a)) {
-        a.sorted = true;
-        return;
-    }
+    a.order_gen = next_order_gen();
     Context& c = ctx();
     // the arrays are about to be rewritten: if they alias caller HBM, that is what "order" means.  Values go
     // into a fresh block that replaces the old one when the library owns the storage (results of spmm / syrk /
@@ -539,6 +548,7 @@ void transpose_csr(char vtype, const Csr& in, Csr& out, bool conj)
         });
     }
     out.valid = true;
+    out.order_gen = next_order_gen();
     out.sorted = false;
     sort_csr(vtype, out);  // canonical + deterministic
 }
@@ -715,6 +725,7 @@ static void build_csr(Csr& out, int base, int64_t nrows, int64_t ncols, const I*
     if (hbad & 3) fail(MI_SPARSE_STATUS_INVALID_VALUE, "row pointer array is not monotone / does not start at base");
     if (hbad & 4) fail(MI_SPARSE_STATUS_INVALID_VALUE, "column index out of range");
     out.valid = true;
+    out.order_gen = next_order_gen();
     out.sorted = false;
 }
 
@@ -809,6 +820,7 @@ static int create_bsr_generic(mi_sparse_matrix_t* A, int base, int block_layout,
             }
             MI_HIP_CHECK(hipStreamSynchronize(c.stream));
             o.valid = true;
+            o.order_gen = next_order_gen();
             // keep the block form for the SpMM block kernel (bsr.hip): structure from `blk`, values owned
             // (staged copy of host values) or aliased (device values, like CSR handles alias device arrays)
             Bsr& bb = h->bsr;
@@ -1243,6 +1255,7 @@ mi_sparse_status_t mi_sparse_convert_csr(mi_sparse_matrix_t A, int op, mi_sparse
                                             hipMemcpyDeviceToDevice, c.stream));
             }
             d.valid = true;
+            d.order_gen = mi::next_order_gen();
             d.sorted = src.sorted;
             c.sync();
         } catch (...) {

@@ -1460,6 +1460,10 @@ struct SpgemmSymbolic {
     int upper_mode = 0;
     int64_t max_nnz = 0;   // longest row of C
     bool done = false;
+    // entry-order generations (Csr::order_gen) of the operands big.ext0 / big.extlen were computed for: the tables are indexed
+    // by the POSITION of A's entries, so a re-ordered A (mi_sparse_order between the stages) needs them again
+    uint64_t a_gen = 0, b_gen = 0;
+    int64_t a_nnz = 0, b_nnz = 0;
 };
 
 // Phase 1: row pointer of C (C.ptr, C.nnz) -- upper bounds, binning, symbolic hash / bitmap kernels, scan.
@@ -1505,6 +1509,10 @@ static void spgemm_symbolic(const Csr& A, const Csr& B, bool upper, Csr& C, Spge
         MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows,
                   (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, ub,
                   big.ext0.as<int64_t>(), big.extlen.as<int32_t>());
+    st.a_gen = A.order_gen;
+    st.b_gen = B.order_gen;
+    st.a_nnz = A.nnz;
+    st.b_nnz = B.nnz;
     const int64_t max_ub = device_max(ub, A.rows);
     mark("row upper bounds");
     run_phase<T, false>(A, B, st.upper_mode, ub, max_ub, row_nnz, nullptr, nullptr, nullptr, big);
@@ -1524,6 +1532,22 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
 {
     Context& c = ctx();
     if (!st.done) fail(MI_SPARSE_STATUS_INVALID_VALUE, "numeric SpGEMM phase requested before the symbolic one");
+    if (A.nnz != st.a_nnz || B.nnz != st.b_nnz)
+        fail(MI_SPARSE_STATUS_INVALID_VALUE, "operand structure changed since the symbolic phase (nnz %lld x %lld, was %lld x %lld)",
+             (long long)A.nnz, (long long)B.nnz, (long long)st.a_nnz, (long long)st.b_nnz);
+    if (A.order_gen != st.a_gen || B.order_gen != st.b_gen) {
+        // the entries of an operand moved since the symbolic phase (mi_sparse_order between NNZ_COUNT and FINALIZE): the pattern
+        // of C, its row lengths and the range starts are unaffected, but the per-entry extents of B's rows follow A's storage
+        // order (and, upper triangle of a sorted B, B's) -- one streamed pass rebuilds them.  A B that was unsorted at the
+        // symbolic phase keeps mode 1 (every product tested), which is valid for any order.
+        int64_t* ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
+        if (A.rows > 0)
+            MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows, (const int64_t*)A.ptr,
+                      (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, ub,
+                      st.big.ext0.as<int64_t>(), st.big.extlen.as<int32_t>());
+        st.a_gen = A.order_gen;
+        st.b_gen = B.order_gen;
+    }
     if (!C.col_own.p || C.col_own.bytes < sizeof(int32_t) * (size_t)C.nnz) C.col_own.alloc(sizeof(int32_t) * (size_t)C.nnz);
     if (!C.val_own.p || C.val_own.bytes < sizeof(T) * (size_t)C.nnz) C.val_own.alloc(sizeof(T) * (size_t)C.nnz);
     C.col = C.col_own.as<int32_t>();
@@ -1536,6 +1560,7 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
         fprintf(stderr, "[mi_sparse spgemm] numeric done\n");
     }
     C.valid = true;
+    C.order_gen = next_order_gen();
     C.sorted = false;
 }
 
@@ -1721,6 +1746,7 @@ static void symmetric_expand(const Csr& u, const Csr& ut, Csr& out)
                   (const int32_t*)u.col, (const T*)u.val, (const int64_t*)ut.ptr, (const int32_t*)ut.col, (const T*)ut.val,
                   (const int64_t*)out.ptr, out.col, static_cast<T*>(out.val));
     out.valid = true;
+    out.order_gen = next_order_gen();
     out.sorted = u.sorted && ut.sorted;
 }
 

@@ -912,7 +912,11 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk, hot_rows);
     // fix-up grid: the exact task count once it has reached the host, else its upper bound
     const int64_t fix_tasks = p.n_tasks >= 0 ? p.n_tasks : p.nchunks;
-    const int64_t fix_grid = fix_tasks < ((int64_t)1 << 20) ? fix_tasks : ((int64_t)1 << 20);  // one workgroup per task, grid-stride beyond 2^20
+    // one workgroup per task, grid-stride beyond the grid.  While the exact count is still on its way to the host the bound is
+    // the chunk count -- hundreds of thousands of workgroups that would read the count and exit on exactly the first calls:
+    // a few workgroups per CU stride over whatever the count turns out to be
+    int64_t fix_grid = fix_tasks < ((int64_t)1 << 20) ? fix_tasks : ((int64_t)1 << 20);
+    if (p.n_tasks < 0 && c.cus > 0 && fix_grid > (int64_t)8 * c.cus) fix_grid = (int64_t)8 * c.cus;
     const unsigned long long* n_tasks_dev = static_cast<const unsigned long long*>(p.n_tasks_dev.p);
     T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)p.nchunks * (size_t)N));
     const bool row_major = (layout == MI_SPARSE_LAYOUT_ROW_MAJOR);

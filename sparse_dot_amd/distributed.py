@@ -157,13 +157,14 @@ def broadcast_rows(t, src=0, group=None, mode="scatter_allgather"):
     k = t.shape[0]
     cut = [k * r // world for r in range(world + 1)]
     slab = lambda r: t[cut[r]:cut[r + 1]]  # noqa: E731
-    on_nccl = dist.get_backend(group) == "nccl"
     if rank == src:
         p1 = _p2p_batch([(slab(r), r) for r in range(world) if r != src], [], group)
     else:
         p1 = _p2p_batch([], [(slab(rank), src)], group)
-    if not on_nccl:
-        p1.wait()  # gloo: the slab must have landed before it is forwarded (NCCL orders the two batches on its stream)
+    # the slab must have landed before it is forwarded.  On NCCL / RCCL wait() is a stream dependency (no host block); it is
+    # issued unconditionally because only coalesced batches are guaranteed to share one communicator stream with the next
+    # batch -- torch builds that issue point-to-point operations on per-peer streams would otherwise read before arrival
+    p1.wait()
     if rank == src:  # the root already holds everything: it only hands out its own slab
         sends, recvs = [(slab(src), r) for r in range(world) if r != src], []
     else:

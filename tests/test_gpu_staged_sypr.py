@@ -60,6 +60,47 @@ def test_staged_product_pattern_reuse(gpu, dtype):
         _same(p.finalize(), a.astype(ref.dtype) @ a.astype(ref.dtype).T, dtype)
 
 
+@pytest.mark.parametrize("hub", [False, True])
+def test_staged_product_order_between_stages(gpu, hub):
+    """mi_sparse_order(A) (or of B) between NNZ_COUNT and FINALIZE moves the entries the symbolic phase's per-entry tables
+    were indexed by (max abs error 1.68 before the entry-order generation check).  Unsorted operands, ordered
+    after the symbolic phase: the product must still be exact."""
+    import ctypes as ct
+    from sparse_dot_amd._mi_interface import MI, SparseHandle, matrix_descr, sparse_matrix_t
+    rng = np.random.default_rng(11)
+
+    def unsorted(m, seed):
+        m = m.tocsr().copy()
+        r = np.random.default_rng(seed)
+        for i in range(m.shape[0]):  # shuffle the entries inside every row
+            lo, hi = m.indptr[i], m.indptr[i + 1]
+            perm = r.permutation(hi - lo)
+            m.indices[lo:hi] = m.indices[lo:hi][perm]
+            m.data[lo:hi] = m.data[lo:hi][perm]
+        m.has_sorted_indices = False
+        return m
+
+    a = _pos(900, 700, 0.02, np.float64, 5)
+    if hub:  # hub rows: the bitmap / range-partitioned path and its stored tables as well
+        a = sps.vstack([a[:300], _pos(2, 700, 0.7, np.float64, 6), a[300:]]).tocsr()
+    b = _pos(700, 6000 if hub else 800, 0.02, np.float64, 7)
+    want = (a @ b).tocsr()
+    for which in ("a", "b", "both"):
+        ua, ub = unsorted(a, 1), unsorted(b, 2)
+        with SparseHandle.from_scipy(ua) as ha, SparseHandle.from_scipy(ub) as hb:
+            c = sparse_matrix_t()
+            assert MI.call("mi_sparse_sp2m", 10, matrix_descr(), ha.ptr, 10, matrix_descr(), hb.ptr, 91, ct.byref(c)) == 0
+            if which in ("a", "both"):
+                assert MI.call("mi_sparse_order", ha.ptr) == 0
+            if which in ("b", "both"):
+                assert MI.call("mi_sparse_order", hb.ptr) == 0
+            assert MI.call("mi_sparse_sp2m", 10, matrix_descr(), ha.ptr, 10, matrix_descr(), hb.ptr, 92, ct.byref(c)) == 0
+            hc = SparseHandle(c, "d")
+            hc.order()
+            _same(hc.export("csr_matrix"), want, np.float64)
+            hc.destroy()
+
+
 def test_staged_product_errors(gpu):
     import ctypes as ct
     from sparse_dot_amd._mi_interface import MI, SparseHandle, matrix_descr, sparse_matrix_t
