@@ -328,6 +328,74 @@ def measure_traffic_live(timeout_s=150):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+
+def measure_traffic_child(child_args, calls, include, exclude=("k_spmv", "k_spmm"), timeout_s=240):
+    """HBM-side bytes per CALL of a secondary workload from rocprofv3 PMC counters collected NOW: two separate
+    `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE, WRITE_SIZE) over tools/bench_ops.py, which runs the very
+    workload of the secondary (same generator, seeds, library defaults) `calls` times in a child process.  Bytes = sum over
+    every library kernel whose name contains one of `include` (and none of `exclude`: the row-sum checks of the child)
+    of FETCH_SIZE KB x 2 (gfx950 correction for wide reads, MI355X_MICROARCH.md; RDREQ x 128 B for gathers by the
+    calibration of profiles/r03_fetch_size_calibration.log -- the same figure) + WRITE_SIZE KB, divided by `calls`.
+    Returns ({"traffic": bytes, "by_kernel_GB": {...}}, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+    per_kernel = defaultdict(lambda: defaultdict(float))
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "bench_ops.py")] + list(child_args)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            seen = 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"]
+                    if row["Counter_Name"] != counter or not any(k in name for k in include) or any(k in name for k in exclude):
+                        continue
+                    base = name.split("<")[0].split("(")[0].replace("void ", "").replace("mi::", "")
+                    per_kernel[base][counter] += float(row["Counter_Value"])
+                    seen += 1
+            if not seen:
+                return None, "no matching dispatches in the %s pass" % counter
+        by = {k: (v.get("FETCH_SIZE", 0.0) * 2048.0 + v.get("WRITE_SIZE", 0.0) * 1024.0) / calls for k, v in per_kernel.items()}
+        total = sum(by.values())
+        top = dict(sorted(((k, round(b / 1e9, 3)) for k, b in by.items()), key=lambda kv: -kv[1])[:6])
+        return ({"traffic": total, "by_kernel_GB": top},
+                "rocprofv3 --pmc, two passes in this run over `tools/bench_ops.py %s`: sum over the library's kernels of FETCH_SIZE KB x 2 "
+                "+ WRITE_SIZE KB, per call (%d calls)" % (" ".join(child_args), calls))
+    except Exception as exc:  # noqa: BLE001
+        return None, "%s: %s" % (type(exc).__name__, str(exc)[:200])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def attach_traffic(entry, child_args, calls, include, enabled):
+    """roofline.traffic (+ its source and the per-kernel split) for a secondary entry."""
+    if not enabled or "roofline" not in entry:
+        return
+    res, src = measure_traffic_child(child_args, calls, include)
+    rf = entry["roofline"]
+    if res is None:
+        rf["traffic"] = None
+        rf["traffic_source"] = "live collection unavailable: %s" % src
+        return
+    rf["traffic"] = res["traffic"]
+    rf["traffic_over_algorithmic"] = round(res["traffic"] / rf["algorithmic_bytes"], 2)
+    rf["traffic_by_kernel_GB"] = res["by_kernel_GB"]
+    rf["traffic_source"] = src
+
+
 def load_traffic(name):
     """HBM bytes per launch from this round's committed PMC summary (separate rocprofv3 --pmc passes; the counters
     cannot be collected from inside this process)."""

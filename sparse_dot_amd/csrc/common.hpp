@@ -196,6 +196,17 @@ __device__ __forceinline__ T lane_bcast(T v, int src)
 #endif
 }
 
+// "this value is needed HERE": an empty asm the optimiser must feed with the value in a VGPR.  Stops the sinking of loads /
+// multiplies into the conditional block that uses them -- where the wait-count pass, not knowing how many LDS / memory
+// operations earlier conditional blocks have issued, falls back to s_waitcnt 0 in every block (gram.hip, round 4).
+template <typename T>
+__device__ __forceinline__ void pin_vgpr(T& x)
+{
+#ifndef MI_HIP_EMU
+    asm volatile("" : "+v"(x));
+#endif
+}
+
 // atomic accumulate (LDS or global).  Real types map to the hardware float / double atomic add
 // (-munsafe-fp-atomics); complex does the two components independently.
 template <typename T>
@@ -209,6 +220,69 @@ __device__ __forceinline__ void atomic_accum(cx<R>* p, cx<R> x)
     atomicAdd(&p->re, x.re);
     atomicAdd(&p->im, x.im);
 }
+
+// Accumulate into an LDS cell that STARTED AT ZERO (gram tiles, SpGEMM hash values).  gfx950 executes ds_add_f32 / ds_add_f64
+// at ~3 cycles PER ACTIVE LANE -- 193 cycles for a full wave instruction, against 8.5 for the integer ds_add_u32 and 12 for a
+// plain read + add + write (tools/probes/lds_atomic_probe.hip, profiles/r04_lds_atomic_probe.log); the dense gram kernel
+// spent a third of its time there.  The FIRST product of a cell needs no addition: an integer compare-and-swap of the zero
+// bit pattern against the product's bits (ds_cmpst_rtn, integer rate) stores it exactly, and only a cell that was already
+// taken (or just lost a race) falls back to the floating-point atomic.  Same result as the atomic alone in every
+// interleaving: the swap succeeds only on a cell that holds +0.0, where 0 + x = x exactly.
+template <typename T>
+__device__ __forceinline__ void lds_accum(T* p, T x)
+{
+    atomic_accum(p, x);
+}
+#ifndef MI_HIP_EMU
+template <>
+__device__ __forceinline__ void lds_accum<float>(float* p, float x)
+{
+    const unsigned old = atomicCAS(reinterpret_cast<unsigned*>(p), 0u, __float_as_uint(x));
+    if (old != 0u) atomicAdd(p, x);
+}
+template <>
+__device__ __forceinline__ void lds_accum<double>(double* p, double x)
+{
+    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(p), 0ull, (unsigned long long)__double_as_longlong(x));
+    if (old != 0ull) atomicAdd(p, x);
+}
+#endif
+template <typename R>
+__device__ __forceinline__ void lds_accum(cx<R>* p, cx<R> x)
+{
+    lds_accum(&p->re, x.re);
+    lds_accum(&p->im, x.im);
+}
+// The same in two steps, for a batch: lds_accum_swap for every product of the batch -- it returns the bit pattern the cell
+// held, and nothing looks at it yet, so the swaps are all in flight together -- then atomic_accum for the products whose swap
+// returned a non-zero pattern (cell already taken: still to be added).
+template <typename T>
+struct lds_word {  // what lds_accum_swap returns: the cell's old bit pattern, in a register of its own width
+    using type = unsigned;
+};
+template <>
+struct lds_word<double> {
+    using type = unsigned long long;
+};
+template <typename T>
+__device__ __forceinline__ typename lds_word<T>::type lds_accum_swap(T* p, T x)
+{
+    (void)p;
+    (void)x;
+    return 1u;  // types without the swap (and the host emulator): everything goes through atomic_accum
+}
+#ifndef MI_HIP_EMU
+template <>
+__device__ __forceinline__ unsigned lds_accum_swap<float>(float* p, float x)
+{
+    return atomicCAS(reinterpret_cast<unsigned*>(p), 0u, __float_as_uint(x));
+}
+template <>
+__device__ __forceinline__ unsigned long long lds_accum_swap<double>(double* p, double x)
+{
+    return atomicCAS(reinterpret_cast<unsigned long long*>(p), 0ull, (unsigned long long)__double_as_longlong(x));
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // errors

@@ -104,13 +104,13 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const int64_t j = st.jj[u];
-                if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(st.ae[u], st.xv[u]));
+                if (j >= j_lo && j < j_hi) lds_accum(&acc[j - j_lo], vt<T>::mul(st.ae[u], st.xv[u]));
             }
 #pragma unroll
             for (int u = 0; u < R; ++u) {  // rows longer than one wave
                 for (int64_t q = st.qs[u] + WAVE + lane; q < st.qe[u]; q += WAVE) {
                     const int64_t j = xcol[q];
-                    if (j >= j_lo && j < j_hi) atomic_accum(&acc[j - j_lo], vt<T>::mul(st.ae[u], xval[q]));
+                    if (j >= j_lo && j < j_hi) lds_accum(&acc[j - j_lo], vt<T>::mul(st.ae[u], xval[q]));
                 }
             }
         };
@@ -318,89 +318,164 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         return p;
     };
     auto after = [&](const Pos& p) { return p.ok ? seek(p.vb + gridDim.x) : p; };
-    // chain of a tile, one level per pipeline stage (this wave's first 64 selected rows)
-    struct Head {
-        int64_t t0, t1;   // A: extent of column i in X^T
-        int32_t r;        // B: lane = selected row
+    // The dependent chain of a tile, one LEVEL per pipeline stage (this wave's first 64 selected rows; lane = row):
+    //   A: extent of column i in X^T (uniform)   ->   B: entry (r, X[r,i]) [+ its slice bounds, MODE 2]   ->
+    //   C: the slice of row r in this tile (MODE 0 / 1: one more gather)   ->   E: the slice's entries (walk_issue).
+    // Every level is requested exactly ONE tile before the level that consumes it, and a level's registers hold the RAW loaded
+    // data until then: nothing is computed from a load, and no loaded register is copied, in the iteration that issued it
+    // (round 3 kept decoded values of several tiles in flight and rotated them: the decode / the copies made the compiler
+    // wait for the loads it had just issued -- a full memory round trip per tile in front of the barrier).
+    using OT = typename std::conditional<MODE == 0, int64_t, int32_t>::type;
+    struct LevelA {
+        int64_t t0, t1;
+    };
+    struct LevelB {
+        T a_raw;
+        int32_t start;     // MODE 2: GramHead::start ...
+        uint16_t bounds;   // ... and bytes g, g + 1 of its boundary array (entries of the row left of this tile / the next one)
+        int32_t r;         // MODE 0 / 1
+        bool valid;
+    };
+    struct LevelC {
+        OT o0, o1;  // the slice: absolute positions in `rec` (MODE 0 / 1: raw loads; MODE 2: decoded from B's record)
         T a;
-        int32_t s;        // C: start of the row's slice in this tile (absolute position in `rec`) ...
-        int32_t len;      //    ... and its length (0 for lanes past the end / positions that hold nothing)
+        bool valid;
     };
-    auto stage_a = [&](const Pos& p, Head& h) {
-        h.t0 = tptr[p.i];
-        h.t1 = tptr[p.i + (p.ok ? 1 : 0)];  // an empty extent for positions that hold nothing (no branch around a load)
+    auto issue_a = [&](const Pos& p) {
+        LevelA A;
+        A.t0 = tptr[p.i];
+        A.t1 = tptr[p.i + (p.ok ? 1 : 0)];  // an empty extent for positions that hold nothing (no branch around a load)
+        return A;
     };
-    auto stage_b = [&](int64_t g, Head& h) {
-        const int64_t base = h.t0 + (int64_t)wave * WAVE;
-        int64_t q = base + lane < h.t1 ? base + lane : h.t1 - 1;  // always a valid entry ...
+    auto issue_b = [&](const LevelA& A, int64_t g) {
+        LevelB b;
+        const int64_t base = A.t0 + (int64_t)wave * WAVE;
+        int64_t q = base + lane < A.t1 ? base + lane : A.t1 - 1;  // always a valid entry ...
         if (q < 0) q = 0;                                          // ... (the kernel is only launched with nnz > 0)
-        h.a = vt<T>::mul(alpha, tval[q]);
-        if constexpr (MODE == 2) {  // the bounds arrive with the entry: 16 coalesced bytes, no further level
-            const GramHead hd = head[q];
-            const int o0 = hd.left((int)g), o1 = hd.left((int)g + 1);
-            h.r = 0;
-            h.s = hd.start + o0;
-            h.len = base + lane < h.t1 ? o1 - o0 : 0;
+        b.valid = base + lane < A.t1;
+        b.a_raw = tval[q];
+        b.r = 0;
+        b.start = 0;
+        b.bounds = 0;
+        if constexpr (MODE == 2) {
+            // the bounds arrive with the entry, no further level.  Of the 16-byte record only `start` and the two boundary bytes
+            // of THIS tile are read (g is known when the level is requested): three single-register loads -- the 16-byte
+            // tuple of a whole record was split by the register allocator while the load was in flight (a copy = a wait)
+            const char* rp = reinterpret_cast<const char*>(head + q);
+            b.start = *reinterpret_cast<const int32_t*>(rp);
+            uint16_t two;
+            __builtin_memcpy(&two, rp + 4 + g, 2);
+            b.bounds = two;
         } else {
-            h.r = tcol[q];
+            b.r = tcol[q];
         }
+        return b;
     };
-    auto stage_c = [&](int64_t g, Head& h) {
-        if constexpr (MODE == 2) return;
-        const int64_t base = h.t0 + (int64_t)wave * WAVE;
-        const bool valid = base + lane < h.t1;
+    auto issue_c = [&](const LevelB& b, int64_t g) {
+        LevelC c;
+        c.a = vt<T>::mul(alpha, b.a_raw);
+        c.valid = b.valid;
         // (a run-time branch on `off` around these loads made the compiler drain vmcnt to 0 at the join: a template flag)
-        int64_t o0, o1;
-        if constexpr (MODE == 1) {
-            const int32_t* orow = off + (int64_t)h.r * (G + 1) + g;
-            o0 = orow[0];
-            o1 = orow[1];
+        if constexpr (MODE == 2) {
+            c.o0 = b.start + (int32_t)(b.bounds & 255u);
+            c.o1 = b.start + (int32_t)(b.bounds >> 8);
+        } else if constexpr (MODE == 1) {
+            const int32_t* orow = off + (int64_t)b.r * (G + 1) + g;
+            c.o0 = orow[0];
+            c.o1 = orow[1];
         } else {
-            o0 = xptr[h.r];
-            o1 = xptr[h.r + 1];
+            c.o0 = xptr[b.r];
+            c.o1 = xptr[b.r + 1];
         }
-        h.s = (int32_t)o0;
-        h.len = valid ? (int32_t)(o1 - o0) : 0;
+        return c;
     };
-    // one tile's share of 64 selected rows: entries sub (and sub + SUB) of every row's slice for all NSTEP steps are loaded
-    // before the first LDS atomic (masked lanes read record 0)
-    auto walk64 = [&](const Head& h, int64_t j_lo, int64_t tile_lo) {
+    // One tile's share of 64 selected rows, in two halves: walk_issue REQUESTS entries sub (and sub + SUB) of every row's slice
+    // for all NSTEP steps (masked lanes read record 0); walk_consume turns them into LDS atomics a tile later.
+    // Round 4 (profiles/r04_gram_knockouts.log: write-out 23.5 ms + entry loads 22.3 ms + LDS atomics 23.4 ms = the 69.3 ms of
+    // the kernel -- three phases that did not overlap at all):
+    //  * products and LDS addresses are computed in straight-line code and PINNED in registers before the first conditional
+    //    atomic.  With the multiply inside the `if`, every block started with s_waitcnt lgkmcnt(0) (the lane-shuffled row
+    //    scalar is older than an unknown number of atomics of earlier blocks): sixteen atomics per wave, each waiting for
+    //    the one before; the compiler had also sunk the value half of the first entry's load into its block (a dependent
+    //    round trip per tile);
+    //  * the entries of the NEXT tile are requested before this tile's write-out (see the tile loop).
+    struct Walk {
         int32_t ln[NSTEP], sk[NSTEP];
         T av[NSTEP];
         SpEntry<T> e[HH][NSTEP];
+    };
+    auto walk_issue = [&](const LevelC& c, Walk& w) {
+        const int32_t hs = (int32_t)c.o0, hlen = c.valid ? (int32_t)(c.o1 - c.o0) : 0;  // 0 for lanes past the end / positions that hold nothing
 #pragma unroll
         for (int k = 0; k < NSTEP; ++k) {
             const int src = k * RPS + grp;
-            sk[k] = __shfl(h.s, src);
-            ln[k] = __shfl(h.len, src);
-            av[k] = __shfl(h.a, src);
-#pragma unroll
-            for (int hh = 0; hh < HH; ++hh) e[hh][k] = rec[sub + hh * SUB < ln[k] ? sk[k] + sub + hh * SUB : 0];
+            w.sk[k] = __shfl(hs, src);
+            w.ln[k] = __shfl(hlen, src);
+            w.av[k] = __shfl(c.a, src);
         }
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k)
+#pragma unroll
+            for (int hh = 0; hh < HH; ++hh) w.e[hh][k] = rec[sub + hh * SUB < w.ln[k] ? w.sk[k] + sub + hh * SUB : 0];
+    };
+    auto walk_consume = [&](const Walk& w, int64_t j_lo, int64_t tile_lo) {
+        const int32_t jl = (int32_t)j_lo, tl = (int32_t)tile_lo;  // column indices are 32-bit
+        T prod[HH][NSTEP];
+        int32_t at[HH][NSTEP];
+#pragma unroll
+        for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k) {
+                const bool ok = sub + hh * SUB < w.ln[k] && w.e[hh][k].c >= jl;
+                at[hh][k] = ok ? w.e[hh][k].c - tl : -1;
+                prod[hh][k] = vt<T>::mul(w.av[k], w.e[hh][k].v);
+                pin_vgpr(at[hh][k]);
+                pin_vgpr(prod[hh][k]);
+            }
+        // LDS float atomics run at ~3 cycles per active lane on gfx950 (common.hpp, lds_accum): the first product of a cell
+        // goes in with an integer compare-and-swap against zero -- all of a batch in flight together -- and only the
+        // products that found their cell taken (~11 % at this fill) use the floating-point atomic
+        typename lds_word<T>::type was[HH][NSTEP];
+#pragma unroll
+        for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k) {
+                was[hh][k] = 0;
+                if (at[hh][k] >= 0) was[hh][k] = lds_accum_swap(&acc[at[hh][k]], prod[hh][k]);
+            }
+#pragma unroll
+        for (int hh = 0; hh < HH; ++hh)  // the returned patterns are looked at only HERE, after every swap has been issued (left to itself
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k) pin_vgpr(was[hh][k]);  // the compiler compares inside each block: a wait per swap)
 #pragma unroll
         for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
             for (int k = 0; k < NSTEP; ++k)
-                if (sub + hh * SUB < ln[k] && e[hh][k].c >= j_lo)
-                    atomic_accum(&acc[e[hh][k].c - tile_lo], vt<T>::mul(av[k], e[hh][k].v));
+                if (was[hh][k] != 0) atomic_accum(&acc[at[hh][k]], prod[hh][k]);
 #pragma unroll
         for (int k = 0; k < NSTEP; ++k) {  // slices longer than HH * SUB entries
-            for (int q = sub + HH * SUB; q < ln[k]; q += SUB) {
-                const SpEntry<T> x = rec[sk[k] + q];
-                if (x.c >= j_lo) atomic_accum(&acc[x.c - tile_lo], vt<T>::mul(av[k], x.v));
+            for (int q = sub + HH * SUB; q < w.ln[k]; q += SUB) {
+                const SpEntry<T> x = rec[w.sk[k] + q];
+                if (x.c >= jl) lds_accum(&acc[x.c - tl], vt<T>::mul(w.av[k], x.v));
             }
         }
     };
 
     // ---- prologue: fill the pipeline (blocking chains, once per workgroup) ----
-    Pos p0 = seek(blockIdx.x), p1 = after(p0), p2 = after(p1), p3 = after(p2);
-    Head h0, h1, h2, h3;
-    stage_a(p0, h0);
-    stage_b(p0.g, h0);
-    stage_c(p0.g, h0);
-    stage_a(p1, h1);
-    stage_b(p1.g, h1);
-    stage_a(p2, h2);
+    // At the top of the iteration for tile k:  w = entries of tile k (in flight),  cv = level C of tile k + 1,
+    // bv = level B of tile k + 2,  a3 = level A of tile k + 3  -- all requested during the iteration for tile k - 1.
+    Pos p0 = seek(blockIdx.x), p1 = after(p0), p2 = after(p1), p3 = after(p2), p4 = after(p3);
+    LevelA a0 = issue_a(p0), a1 = issue_a(p1), a2 = issue_a(p2), a3 = issue_a(p3);
+    LevelC cv;
+    LevelB bv;
+    Walk w;
+    {
+        const LevelB b0 = issue_b(a0, p0.g), b1 = issue_b(a1, p1.g);
+        bv = issue_b(a2, p2.g);
+        const LevelC c0 = issue_c(b0, p0.g);
+        cv = issue_c(b1, p1.g);
+        walk_issue(c0, w);
+    }
     for (int k = tid; k < TILE; k += nthreads) acc[k] = vt<T>::zero();
     __syncthreads();
     while (p0.ok) {
@@ -408,21 +483,25 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         const int64_t tile_lo = g * TILE;
         const int64_t j_lo = i > tile_lo ? i : tile_lo;
         const int64_t j_hi = tile_lo + TILE < n ? tile_lo + TILE : n;
-        // (1) the chain of the tiles ahead, one level each: issued together, consumed one tile later
-        stage_c(p1.g, h1);
-        stage_b(p2.g, h2);
-        stage_a(p3, h3);
-        // (2) this tile's products into LDS
-        walk64(h0, j_lo, tile_lo);
-        for (int64_t base = h0.t0 + (int64_t)(wave + nwaves) * WAVE; base < h0.t1; base += (int64_t)nwaves * WAVE) {
+        // (1) this tile's products into LDS: the entries were requested a tile ago, before the previous tile's write-out
+        walk_consume(w, j_lo, tile_lo);
+        for (int64_t base = a0.t0 + (int64_t)(wave + nwaves) * WAVE; base < a0.t1; base += (int64_t)nwaves * WAVE) {
             // further rows of a long list (more than 64 * nwaves nonzeros in column i): fetched here, the chain exposed
-            Head h;
-            h.t0 = base - (int64_t)wave * WAVE;  // so that stage_b / stage_c address `base`
-            h.t1 = h0.t1;
-            stage_b(g, h);
-            stage_c(g, h);
-            walk64(h, j_lo, tile_lo);
+            LevelA ax;
+            ax.t0 = base - (int64_t)wave * WAVE;  // so that issue_b addresses `base`
+            ax.t1 = a0.t1;
+            const LevelB bx = issue_b(ax, g);
+            const LevelC cx = issue_c(bx, g);
+            Walk x;
+            walk_issue(cx, x);
+            walk_consume(x, j_lo, tile_lo);
         }
+        // (2) one level of each of the four tiles ahead, every load issued here -- BEFORE the barrier and the stores of the
+        //     write-out, so that their latency runs under the drain of those stores -- and consumed in the next iteration
+        walk_issue(cv, w);         // E of tile k + 1
+        cv = issue_c(bv, p2.g);    // C of tile k + 2
+        bv = issue_b(a3, p3.g);    // B of tile k + 3
+        const LevelA a4 = issue_a(p4);
         __syncthreads();
         // (3) the finished tile out, and back to zero
         syrkd_flush_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, tile_lo, beta, beta_zero, tid, nthreads);
@@ -430,10 +509,12 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         p0 = p1;
         p1 = p2;
         p2 = p3;
-        p3 = after(p3);
-        h0 = h1;
-        h1 = h2;
-        h2 = h3;
+        p3 = p4;
+        p4 = after(p4);
+        a0 = a1;
+        a1 = a2;
+        a2 = a3;
+        a3 = a4;
     }
 }
 
