@@ -221,55 +221,36 @@ __device__ __forceinline__ void atomic_accum(cx<R>* p, cx<R> x)
     atomicAdd(&p->im, x.im);
 }
 
-// Accumulate into an LDS cell that STARTED AT ZERO (gram tiles, SpGEMM hash values).  gfx950 executes ds_add_f32 / ds_add_f64
-// at ~3 cycles PER ACTIVE LANE -- 193 cycles for a full wave instruction, against 8.5 for the integer ds_add_u32 and 12 for a
-// plain read + add + write (tools/probes/lds_atomic_probe.hip, profiles/r04_lds_atomic_probe.log); the dense gram kernel
-// spent a third of its time there.  The FIRST product of a cell needs no addition: an integer compare-and-swap of the zero
-// bit pattern against the product's bits (ds_cmpst_rtn, integer rate) stores it exactly, and only a cell that was already
-// taken (or just lost a race) falls back to the floating-point atomic.  Same result as the atomic alone in every
-// interleaving: the swap succeeds only on a cell that holds +0.0, where 0 + x = x exactly.
+// Accumulate into an LDS cell that STARTED AT ZERO (gram tiles, SpGEMM hash values).
+// gfx950 executes ds_add_f32 at ~3 cycles PER ACTIVE LANE -- 193 cycles for a full wave instruction -- while ds_add_f64 takes
+// 21, the integer ds_add_u32 9 and a compare-and-swap with return ~13 (tools/probes/lds_atomic_probe.hip, profiles/
+// r04_lds_atomic_probe.log); the dense fp32 gram kernel spent a third of its time in that instruction.  For fp32 the
+// floating-point atomic is therefore the LAST resort:
+//   1. compare-and-swap of the zero bit pattern against the product's bits (the first product of a cell needs no addition:
+//      0 + x = x exactly);
+//   2. the cell was taken: compare-and-swap of the value just seen against (seen + x);
+//   3. lost that race too (several lanes on one cell): ds_add_f32, which serialises in hardware.
+// Every interleaving gives what a sequence of atomic additions gives.  fp64 keeps its (fast) atomic.
 template <typename T>
-__device__ __forceinline__ void lds_accum(T* p, T x)
-{
-    atomic_accum(p, x);
-}
-#ifndef MI_HIP_EMU
-template <>
-__device__ __forceinline__ void lds_accum<float>(float* p, float x)
-{
-    const unsigned old = atomicCAS(reinterpret_cast<unsigned*>(p), 0u, __float_as_uint(x));
-    if (old != 0u) atomicAdd(p, x);
-}
-template <>
-__device__ __forceinline__ void lds_accum<double>(double* p, double x)
-{
-    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(p), 0ull, (unsigned long long)__double_as_longlong(x));
-    if (old != 0ull) atomicAdd(p, x);
-}
-#endif
-template <typename R>
-__device__ __forceinline__ void lds_accum(cx<R>* p, cx<R> x)
-{
-    lds_accum(&p->re, x.re);
-    lds_accum(&p->im, x.im);
-}
-// The same in two steps, for a batch: lds_accum_swap for every product of the batch -- it returns the bit pattern the cell
-// held, and nothing looks at it yet, so the swaps are all in flight together -- then atomic_accum for the products whose swap
-// returned a non-zero pattern (cell already taken: still to be added).
-template <typename T>
-struct lds_word {  // what lds_accum_swap returns: the cell's old bit pattern, in a register of its own width
+struct lds_word {  // bit pattern of an fp32 cell; a dummy for every other type
     using type = unsigned;
 };
-template <>
-struct lds_word<double> {
-    using type = unsigned long long;
-};
+// step 1 for a batch: returns the pattern the cell held -- 0: the product is in.  Nothing has to look at the result before
+// the other swaps of the batch have been issued.  Types without the swap (and the host emulator) report "taken".
 template <typename T>
-__device__ __forceinline__ typename lds_word<T>::type lds_accum_swap(T* p, T x)
+__device__ __forceinline__ unsigned lds_accum_swap(T* p, T x)
 {
     (void)p;
     (void)x;
-    return 1u;  // types without the swap (and the host emulator): everything goes through atomic_accum
+    return 1u;
+}
+// step 2: returns the pattern the cell held at the second swap -- equal to `seen`: the product is in
+template <typename T>
+__device__ __forceinline__ unsigned lds_accum_retry(T* p, T x, unsigned seen)
+{
+    (void)p;
+    (void)x;
+    return ~seen;
 }
 #ifndef MI_HIP_EMU
 template <>
@@ -278,11 +259,24 @@ __device__ __forceinline__ unsigned lds_accum_swap<float>(float* p, float x)
     return atomicCAS(reinterpret_cast<unsigned*>(p), 0u, __float_as_uint(x));
 }
 template <>
-__device__ __forceinline__ unsigned long long lds_accum_swap<double>(double* p, double x)
+__device__ __forceinline__ unsigned lds_accum_retry<float>(float* p, float x, unsigned seen)
 {
-    return atomicCAS(reinterpret_cast<unsigned long long*>(p), 0ull, (unsigned long long)__double_as_longlong(x));
+    return atomicCAS(reinterpret_cast<unsigned*>(p), seen, __float_as_uint(__uint_as_float(seen) + x));
 }
 #endif
+// one product at a time
+template <typename T>
+__device__ __forceinline__ void lds_accum(T* p, T x)
+{
+    const unsigned seen = lds_accum_swap(p, x);
+    if (seen != 0u && lds_accum_retry(p, x, seen) != seen) atomic_accum(p, x);
+}
+template <typename R>
+__device__ __forceinline__ void lds_accum(cx<R>* p, cx<R> x)
+{
+    lds_accum(&p->re, x.re);
+    lds_accum(&p->im, x.im);
+}
 
 // ------------------------------------------------------------------------------------------------
 // errors

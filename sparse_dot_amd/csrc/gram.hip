@@ -432,26 +432,39 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
                 pin_vgpr(at[hh][k]);
                 pin_vgpr(prod[hh][k]);
             }
-        // LDS float atomics run at ~3 cycles per active lane on gfx950 (common.hpp, lds_accum): the first product of a cell
-        // goes in with an integer compare-and-swap against zero -- all of a batch in flight together -- and only the
-        // products that found their cell taken (~11 % at this fill) use the floating-point atomic
-        typename lds_word<T>::type was[HH][NSTEP];
+        // ds_add_f32 runs at ~3 cycles per active lane on gfx950 (common.hpp, lds_accum): the first product of a cell goes in
+        // with an integer compare-and-swap against zero -- all of a batch in flight together --, a product that found its cell
+        // taken (~11 % at this fill) with a second swap on the value it saw, and only what loses that race too with the
+        // floating-point atomic.  (fp64: the swaps are no-ops that report "taken"; ds_add_f64 is fast.)
+        unsigned was[HH][NSTEP];
 #pragma unroll
         for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
             for (int k = 0; k < NSTEP; ++k) {
-                was[hh][k] = 0;
+                was[hh][k] = 0u;
                 if (at[hh][k] >= 0) was[hh][k] = lds_accum_swap(&acc[at[hh][k]], prod[hh][k]);
             }
 #pragma unroll
         for (int hh = 0; hh < HH; ++hh)  // the returned patterns are looked at only HERE, after every swap has been issued (left to itself
 #pragma unroll
             for (int k = 0; k < NSTEP; ++k) pin_vgpr(was[hh][k]);  // the compiler compares inside each block: a wait per swap)
+        unsigned got[HH][NSTEP];  // what the second swap saw (== was: the product is in)
+#pragma unroll
+        for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k) {
+                got[hh][k] = was[hh][k];
+                if (was[hh][k] != 0u) got[hh][k] = lds_accum_retry(&acc[at[hh][k]], prod[hh][k], was[hh][k]);
+            }
+#pragma unroll
+        for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k) pin_vgpr(got[hh][k]);
 #pragma unroll
         for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
             for (int k = 0; k < NSTEP; ++k)
-                if (was[hh][k] != 0) atomic_accum(&acc[at[hh][k]], prod[hh][k]);
+                if (got[hh][k] != was[hh][k]) atomic_accum(&acc[at[hh][k]], prod[hh][k]);
 #pragma unroll
         for (int k = 0; k < NSTEP; ++k) {  // slices longer than HH * SUB entries
             for (int q = sub + HH * SUB; q < w.ln[k]; q += SUB) {
