@@ -143,6 +143,26 @@ __device__ __forceinline__ int flat_find(const int* inc, int f)
     return l;
 }
 
+// U positions at once, in LOCKSTEP: the U probes of a step are issued together and waited for together -- log2(N) LDS round
+// trips for the whole batch.  Left to the compiler, U calls of flat_find run one after the other (every probe of a search
+// depends on the one before and is followed by s_waitcnt lgkmcnt(0)): U * log2(N) dependent round trips per batch, about
+// half of a k_spgemm_part batch's latency (round 4, from the kernel's machine code).
+template <int N, int U>
+__device__ __forceinline__ void flat_find_lockstep(const int* inc, const int (&f)[U], int (&l)[U])
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) l[u] = 0;
+#pragma unroll
+    for (int step = N / 2; step > 0; step >>= 1) {
+        int probe[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) probe[u] = inc[l[u] + step - 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (probe[u] <= f[u]) l[u] += step;
+    }
+}
+
 // Walking the flat product list: a WAVE takes 64 * U consecutive products (lane + 64 u), so the products of one lane
 // are 64 apart and mostly stay inside one slice (the B rows that matter are long): the slice of the first is found by
 // bisection, the following ones by stepping forward -- about one LDS read per product instead of log2(N) + 2.
@@ -995,12 +1015,14 @@ __global__ void __launch_bounds__(PART_THREADS)
                 T v[PART_UNROLL];
                 int64_t q[PART_UNROLL];
                 T av[PART_UNROLL];
+                int fs[PART_UNROLL], ls[PART_UNROLL];
+#pragma unroll
+                for (int u = 0; u < PART_UNROLL; ++u) fs[u] = f0 + u * NT < total ? f0 + u * NT : f0;
+                flat_find_lockstep<NT, PART_UNROLL>(inc, fs, ls);
 #pragma unroll
                 for (int u = 0; u < PART_UNROLL; ++u) {
-                    const int f = f0 + u * NT < total ? f0 + u * NT : f0;
-                    const int l = flat_find<NT>(inc, f);
-                    q[u] = qlo[l] + (f - (l ? inc[l - 1] : 0));
-                    av[u] = a_s[l];
+                    q[u] = qlo[ls[u]] + (fs[u] - (ls[u] ? inc[ls[u] - 1] : 0));
+                    av[u] = a_s[ls[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < PART_UNROLL; ++u) {
