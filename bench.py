@@ -380,11 +380,11 @@ def measure_traffic_child(child_args, calls, include, exclude=("k_spmv", "k_spmm
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def attach_traffic(entry, child_args, calls, include, enabled):
+def attach_traffic(entry, child_args, calls, include, enabled, exclude=("k_spmv", "k_spmm")):
     """roofline.traffic (+ its source and the per-kernel split) for a secondary entry."""
     if not enabled or "roofline" not in entry:
         return
-    res, src = measure_traffic_child(child_args, calls, include)
+    res, src = measure_traffic_child(child_args, calls, include, exclude=exclude)
     rf = entry["roofline"]
     if res is None:
         rf["traffic"] = None
@@ -584,6 +584,23 @@ def secondary_gram(torch, abi, dev, with_cpu):
         sip, sidx, sval, _ = uniform_csr(torch, 1 << 18, 64, 3, dev, ncols=16384)
         a = sps.csr_matrix((sval.cpu().numpy(), sidx.cpu().numpy(), sip.cpu().numpy()), shape=(1 << 18, 16384))
         out["cpu_baseline"] = cpu_baseline_gram(a, nrep=1)
+        # the like-for-like partner of that CPU number: the SAME sample (2^18 x 16384, 64/row, dense 1 GiB output) on the GPU
+        hs = abi.create("s", sip, sidx, sval, 1 << 18, 16384)
+        Cs = torch.zeros((16384, 16384), device=dev, dtype=torch.float32)
+        ts = []
+        for rep in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            abi.check(abi.MI.call("mi_sparse_s_syrkd", 11, hs, 1.0, 0.0, Cs.data_ptr(), 101, 16384), "syrkd")
+            torch.cuda.synchronize()
+            if rep:
+                ts.append(time.perf_counter() - t0)
+        slens = (sip[1:] - sip[:-1]).double()
+        sflops = float((slens * (slens + 1)).sum())
+        out["gpu_on_cpu_sample_shape"] = {"workload": "A^T A, uniform CSR 2^18 x 16384, 64/row fp32, dense 1 GiB output (the cpu_baseline sample)",
+                                          "ms": round(min(ts) * 1e3, 3), "value": round(sflops / min(ts) / 1e9, 2), "unit": "GFLOP/s"}
+        abi.destroy(hs)
+        del Cs
     return out
 
 
@@ -592,7 +609,7 @@ def secondary_config5(torch, dist, dev, abi, rank, world, allreduce_max, steps=3
     row-partitioned over the 8 ranks (every rank generates the same matrix and keeps its nnz-balanced block), B broadcast
     from rank 0, C all-gathered -- timed end to end like the headline step, plus the kernels alone."""
     from sparse_dot_amd import distributed as D
-    scale, N = 24, 256
+    scale, N = int(os.environ.get("BENCH_CFG5_SCALE", "24")), 256
     indptr, indices, vals, n = rmat_csr(torch, scale, 32, 7, dev)
     nnz = int(indices.numel())
     ip64 = indptr.to(torch.int64)
@@ -654,7 +671,8 @@ def secondary_config5(torch, dist, dev, abi, rank, world, allreduce_max, steps=3
         worst = max(worst, float(((C[r].double() - want).abs() / want.abs().clamp(min=1e-30)).max()))
     assert worst < 1e-5, "configs[4] fails the fp32 parity bar: %g" % worst
     abi.destroy(h)
-    return {"workload": "BASELINE configs[4]: R-MAT CSR %dx%d (%d nnz) x dense %dx%d fp32, %d nnz-balanced row blocks" % (n, n, nnz, n, N, world),
+    return {"workload": "%sR-MAT CSR %dx%d (%d nnz) x dense %dx%d fp32, %d nnz-balanced row blocks"
+                        % ("BASELINE configs[4]: " if scale == 24 else "DRY RUN at scale %d of BASELINE configs[4]: " % scale, n, n, nnz, n, N, world),
             "value": round(2.0 * nnz * N / t_e2e / 1e9, 2), "unit": "GFLOP/s", "end_to_end_ms": round(t_e2e * 1e3, 3),
             "compute_only_ms": round(t_cmp * 1e3, 3), "compute_only_value": round(2.0 * nnz * N / t_cmp / 1e9, 2),
             "bcast_scatter_allgather_ms": round(t_b * 1e3, 3), "gather_p2p_ms": round(t_g * 1e3, 3),
@@ -1110,7 +1128,8 @@ def main():
     res["free"]()
     del res, C
     handles.clear()
-    if dist and world == 8 and backend == "nccl" and not args.no_variants and not args.no_secondary and args.workload == "rmat":
+    cfg5_dry = os.environ.get("BENCH_CFG5_SCALE")  # dry run of the 8-rank control flow on a small matrix (gloo, ranks sharing a GPU)
+    if dist and world == 8 and (backend == "nccl" or cfg5_dry) and not args.no_variants and not args.no_secondary and args.workload == "rmat":
         import threading
 
         def _bail5():
@@ -1170,6 +1189,14 @@ def main():
             torch.cuda.synchronize()
             sda.mi_set_option("pool_trim", 1)
             torch.cuda.empty_cache()
+            if isinstance(secondary[key], dict) and "error" not in secondary[key]:
+                # counter traffic of THIS secondary, collected now in a child under rocprofv3 (two --pmc passes)
+                child = {"spgemm_uniform": (["spgemm", "--no-order", "--reps", "2"], 3),
+                         "spgemm_rmat_literal": (["spgemm", "--kind", "rmat", "--scale", "20", "--per-row", "16", "--no-order", "--reps", "1"], 2),
+                         "gram_dense": (["gram", "--dense", "--cols", "262144", "--rows-log2", "22", "--reps", "1"], 2)}[key]
+                inc = ("k_syrkd",) if key == "gram_dense" else ("mi::",)
+                exc = ("k_spmv", "k_spmm", "k_check_", "k_widen_ptr", "k_rows_unsorted")
+                attach_traffic(secondary[key], child[0], child[1], inc, not args.no_pmc, exclude=exc)
         line["secondary"] = secondary
     elif rank == 0:
         line["cpu_baseline"] = None
