@@ -329,7 +329,7 @@ def measure_traffic_live(timeout_s=150):
 
 
 
-def measure_traffic_child(child_args, calls, include, exclude=("k_spmv", "k_spmm"), timeout_s=240):
+def measure_traffic_child(child_args, calls, include, exclude=("k_spmv", "k_spmm"), timeout_s=240, need_free_bytes=0):
     """HBM-side bytes per CALL of a secondary workload from rocprofv3 PMC counters collected NOW: two separate
     `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE, WRITE_SIZE) over tools/bench_ops.py, which runs the very
     workload of the secondary (same generator, seeds, library defaults) `calls` times in a child process.  Bytes = sum over
@@ -348,15 +348,25 @@ def measure_traffic_child(child_args, calls, include, exclude=("k_spmv", "k_spmm
         return None, "rocprofv3 not on PATH"
     tmp = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
     per_kernel = defaultdict(lambda: defaultdict(float))
+
+    def wait_for_memory():  # what this process (and the previous child) released comes back to the driver asynchronously
+        if not need_free_bytes:
+            return
+        import torch
+        for _ in range(80):
+            if torch.cuda.mem_get_info()[0] >= need_free_bytes:
+                return
+            time.sleep(0.5)
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
+            wait_for_memory()
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.join(ROOT, "tools", "bench_ops.py")] + list(child_args)
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, timeout=timeout_s)
             if r.returncode != 0:
-                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stdout.decode(errors="replace")[-300:].replace("\n", " | "))
             seen = 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -380,11 +390,11 @@ def measure_traffic_child(child_args, calls, include, exclude=("k_spmv", "k_spmm
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def attach_traffic(entry, child_args, calls, include, enabled, exclude=("k_spmv", "k_spmm")):
+def attach_traffic(entry, child_args, calls, include, enabled, exclude=("k_spmv", "k_spmm"), need_free_bytes=0):
     """roofline.traffic (+ its source and the per-kernel split) for a secondary entry."""
     if not enabled or "roofline" not in entry:
         return
-    res, src = measure_traffic_child(child_args, calls, include, exclude=exclude)
+    res, src = measure_traffic_child(child_args, calls, include, exclude=exclude, need_free_bytes=need_free_bytes)
     rf = entry["roofline"]
     if res is None:
         rf["traffic"] = None
@@ -978,6 +988,7 @@ def main():
 
     t_step = allreduce_max(res["t_end_to_end"])
     t_cmp = allreduce_max(res["t_compute"])
+    t_res = allreduce_max(res["t_resident_B"]) if "t_resident_B" in res else None  # a collective: every rank takes part
     ms_per_step = t_step * 1e3
     gflops = 2.0 * nnz * N / t_step / 1e9
 
@@ -1055,7 +1066,6 @@ def main():
                                            "tallest block + all_gather_into_tensor" % (n * N * 4 / 1e6))
             line["compute_only_value"] = round(2.0 * nnz * N / t_cmp / 1e9, 2)
             line["block_rows_rank0"] = blk_rows
-            t_res = allreduce_max(res["t_resident_B"])
             line["resident_B_ms"] = round(t_res * 1e3, 4)
             line["resident_B_value"] = round(2.0 * nnz * N / t_res / 1e9, 2)
             line["scaling_basis"] = "end_to_end"
@@ -1196,7 +1206,8 @@ def main():
                          "gram_dense": (["gram", "--dense", "--cols", "262144", "--rows-log2", "22", "--reps", "1"], 2)}[key]
                 inc = ("k_syrkd",) if key == "gram_dense" else ("mi::",)
                 exc = ("k_spmv", "k_spmm", "k_check_", "k_widen_ptr", "k_rows_unsorted")
-                attach_traffic(secondary[key], child[0], child[1], inc, not args.no_pmc, exclude=exc)
+                need = {"spgemm_uniform": 16 << 30, "spgemm_rmat_literal": 150 << 30, "gram_dense": 272 << 30}[key]
+                attach_traffic(secondary[key], child[0], child[1], inc, not args.no_pmc, exclude=exc, need_free_bytes=need)
         line["secondary"] = secondary
     elif rank == 0:
         line["cpu_baseline"] = None

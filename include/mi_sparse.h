@@ -488,6 +488,10 @@ const char *mi_sparse_last_error(void);
  *   pageable host arrays)
  *   pool_enable (0: hipFree released device blocks at once), pool_max_mb (cap on cached bytes,
  *   -1 = half of the device memory), pool_trim (any value: return the cache to the driver now)
+ *   deterministic (1: SpGEMM, sparse gram and dense gram return the same BITS on every run -- SpMM / SpMV always do.
+ *                  The default kernels add the products of an entry with LDS atomics in arrival order; this mode orders the
+ *                  result's columns and re-forms every value in a fixed order (one wave per row; dense gram: one wave per
+ *                  tile).  A validation mode: several times slower, minutes on hub rows of > 1e8 products)
  *   profile_events, trace_phases                                               (diagnostics) */
 mi_sparse_status_t mi_sparse_set_option(const char *name, int64_t value);
 /* Diagnostic counters of the calling thread.  With option "profile_events" = 1 the SpMM executor

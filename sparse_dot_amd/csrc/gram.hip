@@ -684,11 +684,15 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
             }
         }
         const int mode = !sliced ? -1 : head ? 2 : off ? 1 : 0;
+        // option "deterministic": ONE wave per workgroup.  A tile is owned by one workgroup; with a single wave its products
+        // reach the LDS in program order (and the lanes of one instruction in the hardware's fixed lane order), so the
+        // floating-point sums are formed in the same order on every run -- at the price of 1/16 of the waves.
+        const bool det = options().deterministic != 0;
         note_kernel("mi::%s<%s, TKB=%d%s%.0d>", sliced ? "k_syrkd_sliced" : "k_syrkd_lds", type_name<T>(), xwide ? 152 : wide ? 128 : 64,
                     sliced ? ", MODE=" : "", sliced ? mode + 0 : 0);
         if (sliced) {
 #define MI_SLICED(TKB_, MODE_, THREADS_)                                                                               \
-    MI_LAUNCH((k_syrkd_sliced<T, TKB_, MODE_>), dim3((unsigned)grid), dim3(THREADS_), c.stream, n, row0, row1,           \
+    MI_LAUNCH((k_syrkd_sliced<T, TKB_, MODE_>), dim3((unsigned)grid), dim3(det ? WAVE : THREADS_), c.stream, n, row0, row1, \
               tiles_per_row, (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, rec, off, head, \
               dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks)
             if (xwide) {
@@ -700,10 +704,10 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
             }
 #undef MI_SLICED
         } else if (wide) {
-            MI_LAUNCH((k_syrkd_lds<T, 128>), dim3((unsigned)grid), dim3(1024), c.stream, n, row0, row1, tiles_per_row,
+            MI_LAUNCH((k_syrkd_lds<T, 128>), dim3((unsigned)grid), dim3(det ? WAVE : 1024), c.stream, n, row0, row1, tiles_per_row,
                       MI_SYRKD_ARGS, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
         } else {
-            MI_LAUNCH((k_syrkd_lds<T, 64>), dim3((unsigned)grid), dim3(512), c.stream, n, row0, row1, tiles_per_row,
+            MI_LAUNCH((k_syrkd_lds<T, 64>), dim3((unsigned)grid), dim3(det ? WAVE : 512), c.stream, n, row0, row1, tiles_per_row,
                       MI_SYRKD_ARGS, dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks);
         }
 #undef MI_SYRKD_ARGS

@@ -1096,6 +1096,34 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// Option "deterministic": the values of C recomputed in a FIXED order.  One wave owns a row of C (its columns already sorted):
+// it takes the nonzeros of A's row one after the other, the lanes span the entries of the selected row of B, every product finds
+// its place in the row by a search and is added with a global atomic -- atomics of one wave to one address are performed in the
+// order they were issued (one queue to one L2 channel), so every entry is the same sequence of additions on every run
+// (k_spmmd sums the same way).  Slow on hub rows (one wave walks all of the row's products); a validation mode.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_spgemm_values_det(int64_t row0, int64_t rows, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
+                        const T* __restrict__ aval, const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol,
+                        const T* __restrict__ bval, int upper, const int64_t* __restrict__ cptr,
+                        const int32_t* __restrict__ ccol, T* __restrict__ cval)
+{
+    const int64_t row = row0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (row >= rows) return;
+    const int64_t c0 = cptr[row], c1 = cptr[row + 1];
+    for (int64_t p = aptr[row]; p < aptr[row + 1]; ++p) {
+        const int32_t kk = acol[p];
+        const T a = aval[p];
+        for (int64_t q = bptr[kk] + lane; q < bptr[kk + 1]; q += WAVE) {
+            const int32_t j = bcol[q];
+            if (upper && j < row) continue;
+            const int64_t pos = lower_bound_col(ccol, c0, c1, j);
+            atomic_accum(cval + pos, vt<T>::mul(a, bval[q]));
+        }
+    }
+}
+
 template <typename T>
 __global__ void k_fill_dense(T* C, int64_t r, int64_t cdim, int64_t c_rs, int64_t c_cs, T v)
 {
@@ -1584,6 +1612,19 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     C.valid = true;
     C.order_gen = next_order_gen();
     C.sorted = false;
+    if (options().deterministic && C.nnz > 0) {
+        // the hash kernels above add the products of an entry in whatever order their waves arrive: keep their PATTERN, put
+        // the columns of every row in order (a unique arrangement) and form the values again in a fixed order
+        sort_csr(type_char<T>::value, C);
+        MI_HIP_CHECK(hipMemsetAsync(C.val, 0, sizeof(T) * (size_t)C.nnz, c.stream));
+        constexpr int RPB = 256 / WAVE;  // rows per workgroup
+        launch_batched(ceil_div(A.rows, (int64_t)RPB), 256, [&](int64_t off, int64_t nb) {
+            const int64_t r0 = off * RPB;
+            MI_LAUNCH((k_spgemm_values_det<T>), dim3((unsigned)nb), dim3(256), c.stream, r0, A.rows, (const int64_t*)A.ptr,
+                      (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val,
+                      st.upper_mode != 0 ? 1 : 0, (const int64_t*)C.ptr, (const int32_t*)C.col, static_cast<T*>(C.val));
+        });
+    }
 }
 
 // C := A * B (or its upper triangle).  C's storage is allocated here.

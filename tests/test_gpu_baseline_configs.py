@@ -99,12 +99,21 @@ def test_config3_literal_rmat_spgemm(gpu):
         cptr = _d2h(p_ptr.value, n + 1, np.int64)
         assert cptr[0] == 0 and cptr[-1] == nnz.value and np.all(np.diff(cptr) >= 0)
         clen = np.diff(cptr)
-        longest = np.argsort(clen)[-5:]
-        rng = np.random.default_rng(0)
-        sample = np.unique(np.concatenate([longest, rng.integers(0, n, 70)]))
-        assert len(sample) >= 64
         a_ptr, a_idx, a_val = a[0].cpu().numpy().astype(np.int64), a[1].cpu().numpy(), av.cpu().numpy()
         b_ptr, b_idx, b_val = b[0].cpu().numpy().astype(np.int64), b[1].cpu().numpy(), bv.cpu().numpy()
+        # the five longest rows of C whose host Gustavson stays below 2e8 products each (the very longest rows have > 1e9:
+        # tens of GB of numpy temporaries and minutes on a busy host), always at least one of the 40 longest
+        b_len = np.diff(b_ptr)
+        longest = []
+        for r in np.argsort(clen)[::-1][:400].tolist():
+            if int(b_len[a_idx[a_ptr[r]:a_ptr[r + 1]]].sum()) <= 200_000_000:
+                longest.append(r)
+            if len(longest) == 5:
+                break
+        assert longest and clen[longest[0]] > 100_000
+        rng = np.random.default_rng(0)
+        sample = np.unique(np.concatenate([np.array(longest, dtype=np.int64), rng.integers(0, n, 70)]))
+        assert len(sample) >= 64
         for r in sample.tolist():
             ks = a_idx[a_ptr[r]:a_ptr[r + 1]]
             avs = a_val[a_ptr[r]:a_ptr[r + 1]]

@@ -1257,3 +1257,44 @@ def test_gram_dense_multi_tile_every_walk(gpu, dtype):
             MI.call("mi_sparse_destroy", h)
         gpu.mi_set_stream(0)
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_deterministic_option_bitwise_reproducible(gpu, dtype):
+    """mi_sparse_set_option("deterministic", 1) (sanitizer row): SpGEMM, sparse gram and dense gram give the
+    SAME BITS run after run (hub rows / many products per entry, where the default path's LDS atomics add in arrival order),
+    and agree with the default path within the north_star's tolerance."""
+    import scipy.sparse as sps
+    tol = 1e-5 if dtype == np.float32 else 1e-12
+    rng = np.random.default_rng(5)
+
+    def pos(m, n, density, seed):
+        x = sps.random(m, n, density=density, format="csr", dtype=np.float64, random_state=seed)
+        x.data[:] = np.random.default_rng(seed + 1).uniform(0.5, 1.5, x.nnz)
+        return x.astype(dtype)
+    a = sps.vstack([pos(1200, 900, 0.02, 1), pos(3, 900, 0.7, 2)]).tocsr()   # hub rows: the big-row kernels too
+    b = pos(900, 5000, 0.02, 3)
+    x = pos(20000, 300, 0.05, 4)  # dense gram: ~50 products per entry
+    gpu.mi_set_option("deterministic", 0)
+    ref_prod = gpu.dot_product_mkl(a, b, reorder_output=True)
+    ref_gram = gpu.gram_matrix_mkl(x, dense=True)
+    ref_sgram = gpu.gram_matrix_mkl(x, reorder_output=True)
+    gpu.mi_set_option("deterministic", 1)
+    try:
+        runs = []
+        for _ in range(3):
+            p = gpu.dot_product_mkl(a, b, reorder_output=True)
+            g = gpu.gram_matrix_mkl(x, dense=True)
+            s = gpu.gram_matrix_mkl(x, reorder_output=True)
+            runs.append((p, g, s))
+        for p, g, s in runs[1:]:
+            assert np.array_equal(p.indices, runs[0][0].indices) and np.array_equal(p.data, runs[0][0].data)
+            assert np.array_equal(g, runs[0][1])
+            assert np.array_equal(s.indices, runs[0][2].indices) and np.array_equal(s.data, runs[0][2].data)
+        p, g, s = runs[0]
+        assert np.array_equal(p.indptr, ref_prod.indptr) and np.array_equal(p.indices, ref_prod.indices)
+        assert np.allclose(p.data, ref_prod.data, rtol=tol, atol=0)
+        assert np.allclose(np.triu(g), np.triu(ref_gram), rtol=tol, atol=0)
+        assert np.array_equal(s.indices, ref_sgram.indices) and np.allclose(s.data, ref_sgram.data, rtol=tol, atol=0)
+    finally:
+        gpu.mi_set_option("deterministic", 0)
