@@ -484,6 +484,7 @@ const char *mi_sparse_last_error(void);
  *   gram_sliced (1: slice-table walk when the slices are short, 2: whenever the rows are sorted, 0: never),
  *   gram_heads (1: slice bounds travel with the entries of X^T when rows have <= 255 entries; 0: per-row table),
  *   gram_tile_kb (0: 152 KiB tiles where they save a tile per output row, else 128; 64 / 128 / 152 force), gram_persistent (-1 auto, 0: one workgroup per tile, k: k workgroups per LDS slot),
+ *   gram_queue (1: the sliced walk's (row, tile) pairs are pulled in order from one counter per XCD; 0: fixed stride per workgroup),
  *   bsr_native (0: BSR handles multiply through their CSR expansion), staged_copies (0: plain hipMemcpy for
  *   pageable host arrays)
  *   pool_enable (0: hipFree released device blocks at once), pool_max_mb (cap on cached bytes,

@@ -575,6 +575,7 @@ struct Options {
     int64_t staged_copies = 1;     // large pageable host <-> device copies through the parallel pinned stager (0: plain hipMemcpy)
     int64_t profile_events = 0;    // bracket the SpMM main kernel with hipEvents (diagnostics)
     int64_t spmm_plan_sync = 0;    // 1: run the hot / cold analysis synchronously inside the first product (tests, A/B tools)
+    int64_t gram_queue = 1;        // sliced dense gram: (row, tile) pairs pulled in order from one counter per XCD (0: fixed stride per workgroup)
     int64_t deterministic = 0;     // 1: run-to-run bitwise reproducible SpGEMM / sparse + dense gram (SpMM / SpMV always are): fixed summation order, slower
 };
 struct Counters {

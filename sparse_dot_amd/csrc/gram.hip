@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     k_syrkd_sliced(int64_t n, int64_t row0, int64_t row_end, int64_t G, const int64_t* __restrict__ tptr,
                    const int32_t* __restrict__ tcol, const T* __restrict__ tval, const int64_t* __restrict__ xptr,
                    const SpEntry<T>* __restrict__ rec, const int32_t* __restrict__ off, const GramHead* __restrict__ head,
-                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual)
+                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha, T beta, int beta_zero, int64_t n_virtual,
+                   unsigned long long* __restrict__ queue)
 {
     constexpr int TILE = syrkd_tile<T, TKB>();
     constexpr int SUB = 8;            // lanes per selected row
@@ -318,6 +319,36 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         return p;
     };
     auto after = [&](const Pos& p) { return p.ok ? seek(p.vb + gridDim.x) : p; };
+    // `queue` != nullptr (round 4): the (row, tile) pairs are PULLED, in order, from one counter per XCD instead of being walked
+    // with a fixed stride.  With the stride every workgroup had its own sequence and the workgroups drifted apart over
+    // thousands of tiles, so the tiles of one output row -- which read neighbouring slices of the same rows of X, sharing
+    // the lines in between -- ran tens of microseconds apart, long after the XCD's L2 had dropped those lines.  Pulled from
+    // a counter, the pairs of an XCD start in list order: the tiles of a row within a tile's duration of each other.
+    // The counter enumerates VALID pairs only (tiles at or right of the diagonal), block of TILE rows by block.
+    __shared__ unsigned long long s_pull[5];
+    const int xq = (int)(blockIdx.x & 7u);
+    auto pos_of = [&](unsigned long long d) {  // d-th valid pair of the rows  row0 + xq + 8 m
+        Pos p;
+        p.vb = 0;
+        p.ok = false;
+        p.i = row0;
+        p.g = 0;
+        const int64_t first = row0 + xq;
+        for (int64_t b = row0 / TILE; b < G; ++b) {
+            const int64_t lo = b * TILE > first ? b * TILE : first, hi = (b + 1) * TILE < row_end ? (b + 1) * TILE : row_end;
+            if (hi <= lo) continue;
+            const int64_t m_lo = (lo - first + 7) >> 3, m_hi = (hi - first + 7) >> 3;  // rows first + 8 m in [lo, hi)
+            const unsigned long long w = (unsigned long long)(G - b), cnt = (unsigned long long)(m_hi - m_lo) * w;
+            if (d < cnt) {
+                p.i = first + 8 * (m_lo + (int64_t)(d / w));
+                p.g = b + (int64_t)(d % w);
+                p.ok = true;
+                break;
+            }
+            d -= cnt;
+        }
+        return p;
+    };
     // The dependent chain of a tile, one LEVEL per pipeline stage (this wave's first 64 selected rows; lane = row):
     //   A: extent of column i in X^T (uniform)   ->   B: entry (r, X[r,i]) [+ its slice bounds, MODE 2]   ->
     //   C: the slice of row r in this tile (MODE 0 / 1: one more gather)   ->   E: the slice's entries (walk_issue).
@@ -477,7 +508,24 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
     // ---- prologue: fill the pipeline (blocking chains, once per workgroup) ----
     // At the top of the iteration for tile k:  w = entries of tile k (in flight),  cv = level C of tile k + 1,
     // bv = level B of tile k + 2,  a3 = level A of tile k + 3  -- all requested during the iteration for tile k - 1.
-    Pos p0 = seek(blockIdx.x), p1 = after(p0), p2 = after(p1), p3 = after(p2), p4 = after(p3);
+    Pos p0, p1, p2, p3, p4;
+    if (queue) {
+        if (tid == 0)
+            for (int k = 0; k < 5; ++k) s_pull[k] = atomicAdd(&queue[xq], 1ull);
+        __syncthreads();
+        p0 = pos_of(s_pull[0]);
+        p1 = pos_of(s_pull[1]);
+        p2 = pos_of(s_pull[2]);
+        p3 = pos_of(s_pull[3]);
+        p4 = pos_of(s_pull[4]);
+        __syncthreads();
+    } else {
+        p0 = seek(blockIdx.x);
+        p1 = after(p0);
+        p2 = after(p1);
+        p3 = after(p2);
+        p4 = after(p3);
+    }
     LevelA a0 = issue_a(p0), a1 = issue_a(p1), a2 = issue_a(p2), a3 = issue_a(p3);
     LevelC cv;
     LevelB bv;
@@ -515,15 +563,18 @@ __global__ void __launch_bounds__(TKB == 64 ? 512 : 1024)
         cv = issue_c(bv, p2.g);    // C of tile k + 2
         bv = issue_b(a3, p3.g);    // B of tile k + 3
         const LevelA a4 = issue_a(p4);
+        unsigned long long pulled = 0;  // the pair five tiles ahead: requested here, looked at after the write-out
+        if (queue && tid == 0) pulled = atomicAdd(&queue[xq], 1ull);
         __syncthreads();
         // (3) the finished tile out, and back to zero
         syrkd_flush_tile(acc, C + (i - row0) * c_rs, c_cs, j_lo, j_hi, tile_lo, beta, beta_zero, tid, nthreads);
+        if (queue && tid == 0) s_pull[0] = pulled;
         __syncthreads();
         p0 = p1;
         p1 = p2;
         p2 = p3;
         p3 = p4;
-        p4 = after(p4);
+        p4 = queue ? pos_of(s_pull[0]) : after(p4);
         a0 = a1;
         a1 = a2;
         a2 = a3;
@@ -691,10 +742,16 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         note_kernel("mi::%s<%s, TKB=%d%s%.0d>", sliced ? "k_syrkd_sliced" : "k_syrkd_lds", type_name<T>(), xwide ? 152 : wide ? 128 : 64,
                     sliced ? ", MODE=" : "", sliced ? mode + 0 : 0);
         if (sliced) {
+            // one counter per XCD (workgroup b pulls from counter b % 8); persistent grids only
+            unsigned long long* queue = nullptr;
+            if (options().gram_queue && grid < nblocks && grid % 8 == 0) {
+                queue = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * 8));
+                MI_HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long) * 8, c.stream));
+            }
 #define MI_SLICED(TKB_, MODE_, THREADS_)                                                                               \
     MI_LAUNCH((k_syrkd_sliced<T, TKB_, MODE_>), dim3((unsigned)grid), dim3(det ? WAVE : THREADS_), c.stream, n, row0, row1, \
               tiles_per_row, (const int64_t*)t.ptr, (const int32_t*)t.col, (const T*)t.val, (const int64_t*)x.ptr, rec, off, head, \
-              dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks)
+              dC, c_rs, c_cs, alpha, beta, beta_zero, nblocks, queue)
             if (xwide) {
                 if (mode == 2) MI_SLICED(152, 2, 1024); else if (mode == 1) MI_SLICED(152, 1, 1024); else MI_SLICED(152, 0, 1024);
             } else if (wide) {

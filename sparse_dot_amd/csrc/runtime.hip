@@ -827,6 +827,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.trace_phases = value;
         } else if (!strcmp(name, "profile_events")) {
             o.profile_events = value;
+        } else if (!strcmp(name, "gram_queue")) {
+            o.gram_queue = value;
         } else if (!strcmp(name, "deterministic")) {
             o.deterministic = value ? 1 : 0;
         } else {
