@@ -2,7 +2,7 @@
 row of B while that pass runs), then the rest with beta = 1 -- each pass with its own slice count / tagging, against the
 single pass the library ships.  Uses the unmodified library through the C ABI; splits A with torch on the device."""
 import ctypes as ct, os, sys, json
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 import torch, bench
 import sparse_dot_amd as sda
