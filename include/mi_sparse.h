@@ -481,6 +481,8 @@ const char *mi_sparse_last_error(void);
  *                                                                               (SpMM kernel variants)
  *   spgemm_lds_parts, spgemm_slice_table, spgemm_slice_table_max, spgemm_part_log2s_bias,
  *   spgemm_force_global, spgemm_global_mode                                     (SpGEMM big-row paths)
+ *   spgemm_onepass (1: a product whose rows all have <= 512 products runs as ONE kernel -- no symbolic pass, the rows of the
+ *                   result are placed by a decoupled look-back; 0: always symbolic + numeric)
  *   gram_sliced (1: slice-table walk when the slices are short, 2: whenever the rows are sorted, 0: never),
  *   gram_heads (1: slice bounds travel with the entries of X^T when rows have <= 255 entries; 0: per-row table),
  *   gram_tile_kb (0: 152 KiB tiles where they save a tile per output row, else 128; 64 / 128 / 152 force), gram_persistent (-1 auto, 0: one workgroup per tile, k: k workgroups per LDS slot),

@@ -196,6 +196,45 @@ __device__ __forceinline__ T lane_bcast(T v, int src)
 #endif
 }
 
+// Position of this lane among the lanes of the wave whose `flag` is set, and their number (all 64 lanes call it together).
+__device__ __forceinline__ int wave_rank(bool flag, int& total)
+{
+#ifdef MI_HIP_EMU
+    int v = flag ? 1 : 0;
+    const int lane = (int)(threadIdx.x & 63);
+    for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_up(v, d);
+        if (lane >= d) v += n;
+    }
+    total = __shfl(v, 63);
+    return v - (flag ? 1 : 0);
+#else
+    const unsigned long long m = __ballot(flag);
+    total = __popcll(m);
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+#endif
+}
+
+// A 64-bit word other WORKGROUPS publish and poll (decoupled look-back of the one-pass SpGEMM): relaxed, agent scope -- the
+// word carries its own status bits, nothing else is ordered by it.
+__device__ __forceinline__ unsigned long long agent_load(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_store(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS written by some lanes of a wave and read by others of the SAME wave: the lanes run in lockstep, an LDS fence is all
+// the hardware needs (the host emulation synchronises its threads here)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // "this value is needed HERE": an empty asm the optimiser must feed with the value in a VGPR.  Stops the sinking of loads /
 // multiplies into the conditional block that uses them -- where the wait-count pass, not knowing how many LDS / memory
 // operations earlier conditional blocks have issued, falls back to s_waitcnt 0 in every block (gram.hip, round 4).
@@ -428,7 +467,19 @@ struct Csr {
     // boundary (GramHead, gram.hip), built for tile width gram_head_w; as the CSR of X -- its longest row (-1: not known yet)
     DevBuf gram_head;
     int64_t gram_head_w = 0;
-    int64_t gram_max_row = -1;
+    mutable int64_t gram_max_row = -1;
+    // SpGEMM with this matrix as the RIGHT operand (spgemm.hip): a padded copy of the entries as (column, value) records in
+    // which every row starts on a 128-byte line (SpEntry<T>), and per row {first record, first entry, entries} (SpRow) --
+    // a 16-entry fp64 row is two lines there, 3.5 on average in the two CSR arrays.  Built on first use; follows the VALUES
+    // and the entry order, so mi_sparse_?_set_values and mi_sparse_order drop it.
+    mutable DevBuf sp_rec, sp_row;
+};
+
+struct alignas(32) SpRow {
+    int64_t pstart;  // first record of the row in sp_rec
+    int64_t ustart;  // first entry of the row in col / val (= ptr[row])
+    int32_t len, pad0;
+    int64_t pad1;
 };
 
 uint64_t next_order_gen();  // handle.hip: process-wide, never repeats
@@ -564,6 +615,9 @@ struct Options {
     int64_t spgemm_slice_table = 1;  // big rows, numeric: precompute the B-row slices of every (row, range) (k_part_slices)
     int64_t spgemm_slice_table_max = (int64_t)3 << 30;  // ... unless the table would exceed this many int32 entries
     int64_t spgemm_global_mode = 0;  // 0: one workgroup per row, L2-local atomics; 1: cooperative, agent-scope atomics
+    int64_t spgemm_group = 1;        // short rows of B (<= 32 entries): one 16-lane group per selected row of B instead of the flat product list (a third of the instructions)
+    int64_t spgemm_packed = 1;       // numeric LDS kernels read B through a padded copy of (column, value) records, rows on 128-byte lines (built per handle on first use); 0: the two CSR arrays
+    int64_t spgemm_onepass = 1;      // products whose rows all fit the small LDS tables: ONE kernel (no symbolic pass), rows placed by a decoupled look-back; 0: always two phases
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory
     int64_t trace_phases = 0;      // print host wall-clock per SpGEMM phase to stderr (diagnostics; synchronises)

@@ -44,8 +44,8 @@ __device__ __forceinline__ int64_t lower_bound_col(const int32_t* __restrict__ c
 // three times (here, symbolic, numeric): with 16-entry rows of B that was one line in 2.5 (symbolic) / 4.5 (numeric).
 __global__ void __launch_bounds__(256)
     k_row_ub(int64_t rows, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
-             const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub,
-             int64_t* __restrict__ ext0, int32_t* __restrict__ extlen)
+             const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, const SpRow* __restrict__ brow, int upper,
+             int64_t* __restrict__ ub, int64_t* __restrict__ ext0, int32_t* __restrict__ extlen, int64_t* __restrict__ ext0p)
 {
     // 8 lanes per row
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,18 +55,95 @@ __global__ void __launch_bounds__(256)
     if (row < rows) {
         for (int64_t p = aptr[row] + sub; p < aptr[row + 1]; p += 8) {
             const int32_t k = acol[p];
-            int64_t b0 = bptr[k];
-            const int64_t b1 = bptr[k + 1];
+            int64_t b0, b1, shift = 0;
+            if (brow) {  // one 32-byte record instead of the two row-pointer entries; `shift`: entry position -> record position
+                const SpRow r = brow[k];
+                b0 = r.ustart;
+                b1 = b0 + r.len;
+                shift = r.pstart - r.ustart;
+            } else {
+                b0 = bptr[k];
+                b1 = bptr[k + 1];
+            }
             if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, (int32_t)row);
             s += b1 - b0;
             ext0[p] = b0;
             extlen[p] = (int32_t)(b1 - b0);
+            if (brow) ext0p[p] = b0 + shift;
         }
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 4);
     if (row < rows && sub == 0) ub[row] = s;
+}
+
+// ---- padded (column, value) records of the right operand (Csr::sp_rec / sp_row) -------------------------------------------
+template <typename T>
+constexpr int sp_unit() { return 128 / (int)sizeof(SpEntry<T>); }  // records per 128-byte line
+
+template <int UNIT>
+__global__ void k_sp_padded_len(int64_t rows, const int64_t* __restrict__ ptr, int64_t* __restrict__ plen)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) plen[i] = (ptr[i + 1] - ptr[i] + UNIT - 1) / UNIT * UNIT;
+}
+__global__ void k_sp_rows(int64_t rows, const int64_t* __restrict__ ptr, const int64_t* __restrict__ pstart,
+                          SpRow* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    SpRow r;
+    r.pstart = pstart[i];
+    r.ustart = ptr[i];
+    r.len = (int32_t)(ptr[i + 1] - ptr[i]);
+    r.pad0 = 0;
+    r.pad1 = 0;
+    out[i] = r;
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_sp_pack(int64_t nnz, int64_t rows, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
+              const T* __restrict__ val, const int64_t* __restrict__ pstart, SpEntry<T>* __restrict__ rec)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = rows;  // row of entry e: largest i with ptr[i] <= e (neighbouring threads share the probes)
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (ptr[mid] <= e) lo = mid; else hi = mid;
+        }
+        SpEntry<T> r;
+        r.c = col[e];
+        r.v = val[e];
+        rec[pstart[lo] + (e - ptr[lo])] = r;
+    }
+}
+
+// records + row table of B, built on first use (nullptr when B is too large for 32-bit row lengths to matter: never)
+template <typename T>
+static void ensure_packed(const Csr& B)
+{
+    if (B.sp_rec.p && B.sp_row.p) return;
+    Context& c = ctx();
+    constexpr int UNIT = sp_unit<T>();
+    int64_t* plen = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(B.rows + 1)));
+    int64_t* pstart = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(B.rows + 1)));
+    int64_t total = 0;
+    if (B.rows > 0) {
+        MI_LAUNCH(k_sp_padded_len<UNIT>, dim3((unsigned)ceil_div(B.rows, 256)), dim3(256), c.stream, B.rows,
+                  (const int64_t*)B.ptr, plen);
+        total = exclusive_scan_i64(plen, pstart, B.rows);
+    }
+    B.sp_row.alloc(sizeof(SpRow) * (size_t)(B.rows + 1));
+    B.sp_rec.alloc(sizeof(SpEntry<T>) * (size_t)(total + UNIT));
+    if (B.rows > 0)
+        MI_LAUNCH(k_sp_rows, dim3((unsigned)ceil_div(B.rows, 256)), dim3(256), c.stream, B.rows, (const int64_t*)B.ptr,
+                  (const int64_t*)pstart, B.sp_row.as<SpRow>());
+    if (B.nnz > 0) {
+        const int64_t blocks = ceil_div(B.nnz, 256) < (1 << 20) ? ceil_div(B.nnz, 256) : (1 << 20);
+        MI_LAUNCH((k_sp_pack<T>), dim3((unsigned)blocks), dim3(256), c.stream, B.nnz, B.rows, (const int64_t*)B.ptr,
+                  (const int32_t*)B.col, (const T*)B.val, (const int64_t*)pstart, B.sp_rec.as<SpEntry<T>>());
+    }
 }
 
 // ---- binning -------------------------------------------------------------------------------------
@@ -205,11 +282,11 @@ struct FlatCursor {
 #define MI_LDS_UNROLL 4
 #endif
 constexpr int LDS_UNROLL = MI_LDS_UNROLL;
-template <typename T, int LOG2S, int THREADS, bool NUMERIC>
+template <typename T, int LOG2S, int THREADS, bool NUMERIC, bool PACKED>
 __global__ void __launch_bounds__(THREADS)
     k_spgemm_lds(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
                  const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
-                 const int32_t* __restrict__ bcol, const T* __restrict__ bval, int gw, int upper,
+                 const int32_t* __restrict__ bcol, const T* __restrict__ bval, const SpEntry<T>* __restrict__ brec, int gw, int upper,
                  int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
                  T* __restrict__ cval)
 {
@@ -272,10 +349,19 @@ __global__ void __launch_bounds__(THREADS)
                     avs[u] = av;
                 }
             }
+            if constexpr (NUMERIC && PACKED) {  // ext0 counts RECORDS of the padded copy: column and value in one load
 #pragma unroll
-            for (int u = 0; u < LDS_UNROLL; ++u) {
-                j[u] = bcol[q[u]];
-                if (NUMERIC) v[u] = bval[q[u]];
+                for (int u = 0; u < LDS_UNROLL; ++u) {
+                    const SpEntry<T> e = brec[q[u]];
+                    j[u] = e.c;
+                    v[u] = e.v;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < LDS_UNROLL; ++u) {
+                    j[u] = bcol[q[u]];
+                    if (NUMERIC) v[u] = bval[q[u]];
+                }
             }
 #pragma unroll
             for (int u = 0; u < LDS_UNROLL; ++u) {
@@ -312,6 +398,342 @@ __global__ void __launch_bounds__(THREADS)
                 cval[out0 + pos] = vals[k];
             }
         }
+    }
+}
+
+// ---- LDS hash kernel for SHORT rows of B: one wave per row of C, one 16-lane group per selected row of B ----------------------
+// Counters of the flat-list kernel on the uniform configs[2] (round 4, profiles/r04_pmc_spgemm_uniform_lds.jsonl): 1 100
+// instructions per row (540 VALU, 410 SALU, 125 LDS) for 256 products, s_waitcnt 8 % of the wave cycles, and the time did not
+// move when the fetched bytes fell by a third (padded records): the kernel is bound by the INSTRUCTIONS of the flat walk (scan
+// of the row lengths, position -> row search, stepping cursor, 64-bit positions), which pay off when rows of B are long or
+// uneven.  When every row of B has at most 32 entries none of it is needed: lane group g of the wave takes row 4 i + g of the
+// selected rows, lane l of the group its entry l (and l + 16) -- no scan, no search; four rows per group in flight.
+template <typename T, int LOG2S, bool NUMERIC, bool PACKED>
+__global__ void __launch_bounds__(64)
+    k_spgemm_grp(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
+                 const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
+                 const int32_t* __restrict__ bcol, const T* __restrict__ bval, const SpEntry<T>* __restrict__ brec, int upper,
+                 int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
+                 T* __restrict__ cval)
+{
+    constexpr int S = 1 << LOG2S, GW = 16, NG = 64 / GW, U = 4;
+    __shared__ __attribute__((aligned(16))) int32_t keys[S];
+    __shared__ __attribute__((aligned(16))) T vals[NUMERIC ? S : 1];
+    __shared__ int64_t qlo[64];
+    __shared__ int qlen[64];
+    __shared__ T a_s[NUMERIC ? 64 : 1];
+    const int lane = threadIdx.x, g = lane / GW, l16 = lane % GW;
+    const int32_t row = row_list[blockIdx.x];
+    {
+        u32x4 e4 = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, z4 = {0u, 0u, 0u, 0u};
+        if constexpr (S >= 256) {
+            for (int k = lane; k < S / 4; k += 64) reinterpret_cast<u32x4*>(keys)[k] = e4;
+            if (NUMERIC)
+                for (int k = lane; k < (int)(S * sizeof(T) / 16); k += 64) reinterpret_cast<u32x4*>(vals)[k] = z4;
+        } else {
+            for (int k = lane; k < S; k += 64) {
+                keys[k] = HASH_EMPTY;
+                if (NUMERIC) vals[k] = vt<T>::zero();
+            }
+        }
+    }
+    int local = 0;
+    const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+    int64_t out0 = 0;
+    if (NUMERIC) out0 = cptr[row];
+    for (int64_t base = a0; base < a1; base += 64) {
+        wave_lds_sync();  // the previous chunk's readers are done (first chunk: the table is cleared)
+        int len = 0;
+        if (base + lane < a1) {
+            qlo[lane] = ext0[base + lane];
+            len = extlen[base + lane];
+            if (NUMERIC) a_s[lane] = aval[base + lane];
+        }
+        qlen[lane] = len;
+        const int n = (int)(a1 - base < 64 ? a1 - base : 64);
+        int lmax = len;  // longest of the chunk's rows of B (the same in every lane)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_xor(lmax, d);
+            lmax = o > lmax ? o : lmax;
+        }
+        wave_lds_sync();
+        for (int s0 = 0; s0 < n; s0 += NG * U) {
+            for (int off = 0; off < lmax; off += GW) {
+                int32_t j[U];
+                T v[U], av[U];
+                int64_t q[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int sl = s0 + u * NG + g;  // < 64; slices at or beyond n have length 0
+                    ok[u] = off + l16 < qlen[sl];
+                    q[u] = ok[u] ? qlo[sl] + off + l16 : 0;
+                    if (NUMERIC) av[u] = a_s[sl];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {  // unconditional, issued together
+                    if constexpr (NUMERIC && PACKED) {
+                        const SpEntry<T> e = brec[q[u]];
+                        j[u] = e.c;
+                        v[u] = e.v;
+                    } else {
+                        j[u] = bcol[q[u]];
+                        if (NUMERIC) v[u] = bval[q[u]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!ok[u]) j[u] = -1;
+                    if (NUMERIC) v[u] = vt<T>::mul(av[u], v[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (j[u] < 0 || (upper && j[u] < row)) continue;
+                    uint32_t h = hash_col(j[u], LOG2S);
+                    for (;;) {
+                        const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, j[u]);
+                        if (old == HASH_EMPTY || old == j[u]) {
+                            if (NUMERIC) atomic_accum(&vals[h], v[u]);
+                            else if (old == HASH_EMPTY) ++local;
+                            break;
+                        }
+                        h = (h + 1) & (S - 1);
+                    }
+                }
+            }
+        }
+    }
+    if (!NUMERIC) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) local += __shfl_xor(local, d);
+        if (lane == 0) row_nnz[row] = local;
+    } else {
+        wave_lds_sync();
+        int written = 0;
+        for (int k0 = 0; k0 < S; k0 += 64) {
+            const int32_t key = keys[k0 + lane];
+            int cnt;
+            const int pos = wave_rank(key != HASH_EMPTY, cnt);
+            if (key != HASH_EMPTY) {
+                ccol[out0 + written + pos] = key;
+                cval[out0 + written + pos] = vals[k0 + lane];
+            }
+            written += cnt;
+        }
+    }
+}
+
+// ---- one-pass kernel: no symbolic phase ----------------------------------------------------------------------------------
+// When EVERY row of the product has few products (ub <= S / 2, S <= 1024) the symbolic pass is the same walk over B as the
+// numeric one -- done twice only to learn where each row of C starts.  Here a wave forms its row ONCE (columns and values in
+// its LDS table, as k_spgemm_lds) and the rows are placed by a DECOUPLED LOOK-BACK over the workgroups: a workgroup draws a
+// ticket (its WAVES consecutive rows), publishes the number of entries of its rows as soon as they are known, adds up the
+// published counts of the tickets before it until it meets one whose running total is already known, publishes its own
+// running total and writes its rows at that position.  Tickets are drawn when a workgroup STARTS, so every ticket a
+// workgroup waits for belongs to a workgroup that is running or done: no deadlock, whatever the dispatch order.  C's column
+// and value arrays are allocated for the upper bound (sum of ub) before the kernel; nnz(C) is the last running total.
+// Column order inside a row: table order (unspecified, as in the two-phase kernels).
+constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
+
+__device__ __forceinline__ int wave_min_int(int v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_xor(v, d);
+        v = n < v ? n : v;
+    }
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+template <typename T, int LOG2S, int WAVES, bool PACKED>
+__global__ void __launch_bounds__(WAVES * 64)
+    k_spgemm_onepass(int64_t rows, const int64_t* __restrict__ aptr, const int64_t* __restrict__ ub,
+                     const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
+                     const int32_t* __restrict__ bcol, const T* __restrict__ bval, const SpEntry<T>* __restrict__ brec, int upper,
+                     unsigned long long* __restrict__ ticket_counter, unsigned long long* __restrict__ flags,
+                     int64_t* __restrict__ cptr, int32_t* __restrict__ ccol, T* __restrict__ cval)
+{
+    constexpr int S = 1 << LOG2S;
+    __shared__ int32_t keys_all[WAVES][S];
+    __shared__ T vals_all[WAVES][S];
+    __shared__ int64_t qlo_all[WAVES][64];
+    __shared__ T a_all[WAVES][64];
+    __shared__ int inc_all[WAVES][64];
+    __shared__ int row_n[WAVES];
+    __shared__ long long block_excl, ticket_s;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int32_t* keys = keys_all[wave];
+    T* vals = vals_all[wave];
+    int64_t* qlo = qlo_all[wave];
+    T* a_s = a_all[wave];
+    int* inc = inc_all[wave];
+#ifdef MI_ONEPASS_BLOCKIDX  // experiment: dispatch order instead of a ticket
+    const int64_t blk = blockIdx.x;
+#else
+    if (tid == 0) ticket_s = (long long)atomicAdd(ticket_counter, 1ull);
+    __syncthreads();
+    const int64_t blk = ticket_s;
+#endif
+    const int64_t row = blk * WAVES + wave;
+    int nnz_row = 0, log2e = 6;
+    if (row < rows) {  // whole wave
+        // table sized for THIS row: the smallest power of two >= 2 ub (>= 64), so that a short row among long ones clears
+        // and compacts what it needs
+        const int64_t my_ub = ub[row];
+        while (((int64_t)1 << log2e) < 2 * my_ub && log2e < LOG2S) ++log2e;
+        const int se = 1 << log2e;
+        for (int k = lane; k < se; k += 64) {
+            keys[k] = HASH_EMPTY;
+            vals[k] = vt<T>::zero();
+        }
+        int local = 0;
+        const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+        for (int64_t base = a0; base < a1; base += 64) {
+            int len = 0;
+            wave_lds_sync();  // the previous chunk's readers are done with qlo / a_s / inc (first chunk: the table is cleared)
+            if (base + lane < a1) {
+                qlo[lane] = ext0[base + lane];
+                len = extlen[base + lane];
+                a_s[lane] = aval[base + lane];
+            }
+            int v = len;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int n = __shfl_up(v, d);
+                if (lane >= d) v += n;
+            }
+            inc[lane] = v;
+            const int total = __shfl(v, 63);
+            wave_lds_sync();
+            for (int g0 = 0; g0 < total; g0 += 64 * LDS_UNROLL) {
+                const int f0 = g0 + lane;
+                FlatCursor<64> cur;
+                int64_t qb = 0;
+                T av = vt<T>::zero();
+                if (f0 < total) {
+                    cur.seek(inc, f0);
+                    qb = qlo[cur.l];
+                    av = a_s[cur.l];
+                }
+                int64_t q[LDS_UNROLL];
+                T avs[LDS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < LDS_UNROLL; ++u) {
+                    const int f = f0 + u * 64;
+                    q[u] = 0;
+                    avs[u] = av;
+                    if (f < total) {
+                        if (u && cur.advance(inc, f)) {
+                            qb = qlo[cur.l];
+                            av = a_s[cur.l];
+                        }
+                        q[u] = qb + (f - cur.lo);
+                        avs[u] = av;
+                    }
+                }
+                int32_t j[LDS_UNROLL];
+                T pv[LDS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < LDS_UNROLL; ++u) {  // unconditional, issued together
+                    if constexpr (PACKED) {
+                        const SpEntry<T> e = brec[q[u]];
+                        j[u] = e.c;
+                        pv[u] = e.v;
+                    } else {
+                        j[u] = bcol[q[u]];
+                        pv[u] = bval[q[u]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < LDS_UNROLL; ++u) {
+                    if (f0 + u * 64 >= total) j[u] = -1;
+                    pv[u] = vt<T>::mul(avs[u], pv[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < LDS_UNROLL; ++u) {
+                    if (j[u] < 0 || (upper && j[u] < row)) continue;
+                    uint32_t h = hash_col(j[u], log2e);
+                    for (;;) {
+                        const int32_t old = atomicCAS(&keys[h], HASH_EMPTY, j[u]);
+                        if (old == HASH_EMPTY || old == j[u]) {
+                            atomic_accum(&vals[h], pv[u]);
+                            if (old == HASH_EMPTY) ++local;
+                            break;
+                        }
+                        h = (h + 1) & (se - 1);
+                    }
+                }
+            }
+        }
+        nnz_row = (int)wave_sum_i64(local);
+    }
+    if (lane == 0) row_n[wave] = nnz_row;
+    __syncthreads();
+#ifdef MI_ONEPASS_KO  // timing only: no look-back, rows at their upper-bound positions (valid for <= 256 products per row)
+    if (tid == 0) block_excl = blk * WAVES * 256;
+    if (false) {
+#else
+    if (wave == 0) {
+#endif
+        long long agg = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) agg += row_n[w];
+        long long excl = 0;
+        if (blk == 0) {
+            if (lane == 0) {
+                agent_store(&flags[0], LB_PREFIX | (unsigned long long)agg);
+                cptr[0] = 0;
+            }
+        } else {
+            if (lane == 0) agent_store(&flags[blk], LB_AGG | (unsigned long long)agg);
+            int64_t look = blk - 1;
+            for (;;) {  // 64 earlier tickets per step, nearest first
+                const int64_t idx = look - lane;
+                const unsigned long long v = idx >= 0 ? agent_load(&flags[idx]) : LB_PREFIX;  // before ticket 0: total 0
+                const int status = (int)(v >> 62);
+                const int first_pfx = wave_min_int(status == 2 ? lane : 64);
+                const int first_inv = wave_min_int(status == 0 ? lane : 64);
+                const int limit = first_pfx < 64 ? first_pfx : 63;
+                if (first_inv <= limit) {  // a count this step needs is not published yet
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += wave_sum_i64(lane <= limit ? (long long)(v & LB_VALUE) : 0ll);
+                if (first_pfx < 64) break;
+                look -= 64;
+            }
+            if (lane == 0) agent_store(&flags[blk], LB_PREFIX | (unsigned long long)(excl + agg));
+        }
+        if (lane == 0) block_excl = excl;
+    }
+    __syncthreads();
+    if (row < rows) {
+        int64_t out0 = block_excl;
+#ifdef MI_ONEPASS_KO
+        out0 += wave * 256;
+#else
+        for (int w = 0; w < wave; ++w) out0 += row_n[w];
+#endif
+        const int se = 1 << log2e;
+        int written = 0;
+        for (int k0 = 0; k0 < se; k0 += 64) {
+            const int32_t key = keys[k0 + lane];
+            int cnt;
+            const int pos = wave_rank(key != HASH_EMPTY, cnt);
+            if (key != HASH_EMPTY) {
+                ccol[out0 + written + pos] = key;
+                cval[out0 + written + pos] = vals[k0 + lane];
+            }
+            written += cnt;
+        }
+        if (lane == 0) cptr[row + 1] = out0 + nnz_row;
     }
 }
 
@@ -1190,6 +1612,47 @@ __global__ void k_max_i64(const int64_t* in, int64_t n, int64_t* out)
     if (threadIdx.x == 0) atomicMax((long long*)out, (long long)red[0]);
 }
 
+__global__ void k_sum_max_i64(const int64_t* in, int64_t n, int64_t* out)  // out[0] += sum, out[1] = max
+{
+    __shared__ int64_t red_s[256], red_m[256];
+    int64_t s = 0, m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = in[i];
+        s += v;
+        if (v > m) m = v;
+    }
+    red_s[threadIdx.x] = s;
+    red_m[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red_s[threadIdx.x] += red_s[threadIdx.x + off];
+            if (red_m[threadIdx.x + off] > red_m[threadIdx.x]) red_m[threadIdx.x] = red_m[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long*)&out[0], (unsigned long long)red_s[0]);
+        atomicMax((long long*)&out[1], (long long)red_m[0]);
+    }
+}
+
+static void device_sum_max(const int64_t* in, int64_t n, int64_t& sum, int64_t& mx)
+{
+    Context& c = ctx();
+    int64_t* d = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * 2));
+    MI_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(int64_t) * 2, c.stream));
+    if (n > 0) {
+        const int64_t blocks = ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024;
+        MI_LAUNCH(k_sum_max_i64, dim3((unsigned)blocks), dim3(256), c.stream, in, n, d);
+    }
+    int64_t h[2] = {0, 0};
+    MI_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+    sum = h[0];
+    mx = h[1];
+}
+
 static int64_t device_max(const int64_t* in, int64_t n)
 {
     Context& c = ctx();
@@ -1238,6 +1701,9 @@ struct BigRows {
     DevBuf boff_by_row;        // int64[A.rows]: offset of a big row's range starts in `bounds`
     DevBuf bounds;             // int32: range starts, P_max = ceil(min(ub, cols) / cap) slots per big row
     DevBuf ext0, extlen;       // per nonzero of A: first counted entry of B's row (int64) and their number (int32) -- k_row_ub
+    DevBuf ext0p;              // the same first entry as a position in B's padded records (Csr::sp_rec) when `packed`
+    bool packed = false;
+    bool grp = false;          // every row of B has <= 32 entries: the LDS bins up to 512 products run k_spgemm_grp
 };
 
 template <typename T, bool NUMERIC>
@@ -1258,18 +1724,42 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
 #define MI_SPGEMM_ARGS(list)                                                                                       \
     (const int32_t*)list, (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,   \
         (const int32_t*)B.col, (const T*)B.val
+    const bool packed = NUMERIC && big.packed;  // numeric LDS kernels: one 16-byte record per product from the padded copy of B
 #define MI_SPGEMM_LDS_ARGS(list)                                                                                   \
-    (const int32_t*)list, (const int64_t*)A.ptr, (const int64_t*)big.ext0.as<int64_t>(),                           \
-        (const int32_t*)big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val
+    (const int32_t*)list, (const int64_t*)A.ptr, (const int64_t*)(packed ? big.ext0p.as<int64_t>() : big.ext0.as<int64_t>()), \
+        (const int32_t*)big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val,        \
+        (const SpEntry<T>*)B.sp_rec.as<SpEntry<T>>()
     if (!force_global) {
 #define MI_SPGEMM_BIN(k, LOG2S, THREADS, GW)                                                                       \
     if (b.n[k]) {                                                                                                  \
         launch_batched(b.n[k], THREADS, [&](int64_t off, int64_t nb) {                                             \
-            MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC>), dim3((unsigned)nb), dim3(THREADS), c.stream,       \
-                      MI_SPGEMM_LDS_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);               \
+            if (packed)                                                                                            \
+                MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC, NUMERIC>), dim3((unsigned)nb), dim3(THREADS), c.stream, \
+                          MI_SPGEMM_LDS_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);           \
+            else                                                                                                   \
+                MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC, false>), dim3((unsigned)nb), dim3(THREADS), c.stream, \
+                          MI_SPGEMM_LDS_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);           \
         });                                                                                                        \
         b.n[k] = 0;                                                                                                \
     }
+#define MI_SPGEMM_GRP(k, LOG2S)                                                                                     \
+    if (big.grp && b.n[k]) {                                                                                       \
+        launch_batched(b.n[k], 64, [&](int64_t off, int64_t nb) {                                                  \
+            if (packed)                                                                                            \
+                MI_LAUNCH((k_spgemm_grp<T, LOG2S, NUMERIC, NUMERIC>), dim3((unsigned)nb), dim3(64), c.stream,        \
+                          MI_SPGEMM_LDS_ARGS(b.list[k] + off), (int)upper, row_nnz, cptr, ccol, cval);               \
+            else                                                                                                   \
+                MI_LAUNCH((k_spgemm_grp<T, LOG2S, NUMERIC, false>), dim3((unsigned)nb), dim3(64), c.stream,          \
+                          MI_SPGEMM_LDS_ARGS(b.list[k] + off), (int)upper, row_nnz, cptr, ccol, cval);               \
+        });                                                                                                        \
+        b.n[k] = 0;                                                                                                \
+    }
+        MI_SPGEMM_GRP(0, 6)
+        MI_SPGEMM_GRP(1, 7)
+        MI_SPGEMM_GRP(2, 8)
+        MI_SPGEMM_GRP(3, 9)
+        MI_SPGEMM_GRP(4, 10)
+#undef MI_SPGEMM_GRP
         MI_SPGEMM_BIN(0, 6, 64, gw64)
         MI_SPGEMM_BIN(1, 7, 64, gw64)
         MI_SPGEMM_BIN(2, 8, 64, gw64)
@@ -1516,20 +2006,26 @@ struct SpgemmSymbolic {
     int64_t a_nnz = 0, b_nnz = 0;
 };
 
-// Phase 1: row pointer of C (C.ptr, C.nnz) -- upper bounds, binning, symbolic hash / bitmap kernels, scan.
+// Phase 0: upper bound of every row of C and, per nonzero of A, the extent of B's row that counts (k_row_ub).
+struct SpgemmBounds {
+    int64_t* ub = nullptr;  // scratch, A.rows + 1
+    int64_t max_ub = 0, sum_ub = 0;
+};
+
+static void trace_mark(const char* what, std::chrono::steady_clock::time_point& t_last)
+{
+    if (!options().trace_phases) return;
+    MI_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mi_sparse spgemm] %-18s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+}
+
 template <typename T>
-static void spgemm_symbolic(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st)
+static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st)
 {
     Context& c = ctx();
-    const bool trace = options().trace_phases != 0;
     auto t_last = std::chrono::steady_clock::now();
-    auto mark = [&](const char* what) {
-        if (!trace) return;
-        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[mi_sparse spgemm] %-18s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-        t_last = now;
-    };
     if (A.cols != B.rows)
         fail(MI_SPARSE_STATUS_INVALID_VALUE, "dimension mismatch: (%lld x %lld) * (%lld x %lld)", (long long)A.rows,
              (long long)A.cols, (long long)B.rows, (long long)B.cols);
@@ -1549,31 +2045,158 @@ static void spgemm_symbolic(const Csr& A, const Csr& B, bool upper, Csr& C, Spge
     C.cols = B.cols;
     C.ptr_own.alloc(sizeof(int64_t) * (size_t)(C.rows + 1));
     C.ptr = C.ptr_own.as<int64_t>();
-    int64_t* ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
-    st.row_nnz.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
-    int64_t* row_nnz = st.row_nnz.as<int64_t>();
-    MI_HIP_CHECK(hipMemsetAsync(row_nnz, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
+    SpgemmBounds bd;
+    bd.ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
     big.ext0.alloc(sizeof(int64_t) * (size_t)(A.nnz + 1));
     big.extlen.alloc(sizeof(int32_t) * (size_t)(A.nnz + 1));
+    big.packed = options().spgemm_packed != 0 && B.nnz > 0 && !options().spgemm_force_global;
+    if (options().spgemm_group && B.rows > 0 && B.nnz >= 6 * B.rows) {  // short, even rows of B: 16 lanes per row, no flat list
+        if (B.gram_max_row < 0) B.gram_max_row = device_max_row_len(B);
+        big.grp = B.gram_max_row <= 32;
+    }
+    if (big.packed) {
+        ensure_packed<T>(B);
+        big.ext0p.alloc(sizeof(int64_t) * (size_t)(A.nnz + 1));
+    }
     if (A.rows > 0)
         MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows,
-                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, ub,
-                  big.ext0.as<int64_t>(), big.extlen.as<int32_t>());
+                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col,
+                  (const SpRow*)(big.packed ? B.sp_row.as<SpRow>() : nullptr), st.upper_mode, bd.ub,
+                  big.ext0.as<int64_t>(), big.extlen.as<int32_t>(), big.ext0p.as<int64_t>());
     st.a_gen = A.order_gen;
     st.b_gen = B.order_gen;
     st.a_nnz = A.nnz;
     st.b_nnz = B.nnz;
-    const int64_t max_ub = device_max(ub, A.rows);
-    mark("row upper bounds");
-    run_phase<T, false>(A, B, st.upper_mode, ub, max_ub, row_nnz, nullptr, nullptr, nullptr, big);
-    mark("symbolic");
+    device_sum_max(bd.ub, A.rows, bd.sum_ub, bd.max_ub);
+    trace_mark("row upper bounds", t_last);
+    return bd;
+}
+
+// Phase 1: row pointer of C (C.ptr, C.nnz) -- binning, symbolic hash / bitmap kernels, scan.
+template <typename T>
+static void spgemm_symbolic(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, const SpgemmBounds& bd)
+{
+    Context& c = ctx();
+    auto t_last = std::chrono::steady_clock::now();
+    st.row_nnz.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
+    int64_t* row_nnz = st.row_nnz.as<int64_t>();
+    MI_HIP_CHECK(hipMemsetAsync(row_nnz, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
+    run_phase<T, false>(A, B, st.upper_mode, bd.ub, bd.max_ub, row_nnz, nullptr, nullptr, nullptr, st.big);
+    trace_mark("symbolic", t_last);
     C.nnz = exclusive_scan_i64(row_nnz, C.ptr, C.rows);
     st.max_nnz = C.nnz > 0 ? device_max(row_nnz, A.rows) : 0;
     C.col = nullptr;
     C.val = nullptr;
     C.valid = false;
     st.done = true;
-    mark("scan");
+    trace_mark("scan", t_last);
+}
+
+// option "deterministic": the hash kernels add the products of an entry in whatever order their waves arrive: keep their
+// PATTERN, put the columns of every row in order (a unique arrangement) and form the values again in a fixed order
+template <typename T>
+static void spgemm_values_deterministic(const Csr& A, const Csr& B, Csr& C, int upper_mode)
+{
+    Context& c = ctx();
+    sort_csr(type_char<T>::value, C);
+    MI_HIP_CHECK(hipMemsetAsync(C.val, 0, sizeof(T) * (size_t)C.nnz, c.stream));
+    constexpr int RPB = 256 / WAVE;  // rows per workgroup
+    launch_batched(ceil_div(A.rows, (int64_t)RPB), 256, [&](int64_t off, int64_t nb) {
+        const int64_t r0 = off * RPB;
+        MI_LAUNCH((k_spgemm_values_det<T>), dim3((unsigned)nb), dim3(256), c.stream, r0, A.rows, (const int64_t*)A.ptr,
+                  (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val,
+                  upper_mode != 0 ? 1 : 0, (const int64_t*)C.ptr, (const int32_t*)C.col, static_cast<T*>(C.val));
+    });
+}
+
+// rows (= waves) per workgroup of the one-pass kernel: every workgroup draws a ticket with ONE atomic on ONE address, which the
+// memory side performs at ~80 M / s -- with four rows per ticket the counter, not the product, set the pace (round 4:
+// 1 / 2 / 4 rows per workgroup = 12.7 / 6.6 / 3.4 ms on the uniform configs[2], exactly 12 ns per ticket)
+#ifndef MI_ONEPASS_WAVES
+#define MI_ONEPASS_WAVES 8
+#endif
+constexpr int onepass_waves(int log2s, size_t vbytes)
+{
+    int w = MI_ONEPASS_WAVES;
+    while (w > 1 && (size_t)w * ((size_t)1 << log2s) * (sizeof(int32_t) + vbytes) > (size_t)96 * 1024) w >>= 1;
+    return w;
+}
+
+// One pass (k_spgemm_onepass): taken when every row has at most 512 products and the upper bound of nnz(C) is affordable.
+// Returns false (nothing done) otherwise.
+template <typename T>
+static bool spgemm_onepass(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, const SpgemmBounds& bd)
+{
+    Context& c = ctx();
+    if (!options().spgemm_onepass || options().spgemm_force_global) return false;
+    // every workgroup draws its ticket from ONE counter (~12 ns each at the memory side) and rows retire in order: measured
+    // faster than two phases up to ~10^5 rows (fewer launches and host round trips: 2^14 x 2^14, 16 / row: 0.30 -> 0.17 ms)
+    // and slower beyond (2^20 rows: 4.0 -> 4.6 ms); option value 2 forces it
+    if (options().spgemm_onepass == 1 && A.rows > 65536) return false;
+    if (A.rows < 1 || bd.max_ub > 512 || bd.sum_ub < 1) return false;
+    const size_t per = sizeof(int32_t) + sizeof(T);
+    size_t free_b = 0, total_b = 0;
+    MI_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    if ((size_t)bd.sum_ub * per > total_b / 4) return false;  // the arrays are sized for the bound, not for nnz(C)
+    auto t_last = std::chrono::steady_clock::now();
+    int log2s = 10;
+    if (bd.max_ub <= 32) log2s = 6;
+    else if (bd.max_ub <= 128) log2s = 8;
+    else if (bd.max_ub <= 256) log2s = 9;
+    const int waves = onepass_waves(log2s, sizeof(T));
+    const int64_t nblocks = ceil_div(A.rows, (int64_t)waves);
+    unsigned long long* flags = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * (size_t)(nblocks + 1)));
+    MI_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(unsigned long long) * (size_t)(nblocks + 1), c.stream));
+    unsigned long long* ticket = flags + nblocks;
+    C.col_own.alloc(sizeof(int32_t) * (size_t)bd.sum_ub);
+    C.val_own.alloc(sizeof(T) * (size_t)bd.sum_ub);
+    C.col = C.col_own.as<int32_t>();
+    C.val = C.val_own.p;
+    auto launch = [&](auto log2s_tag) {
+        constexpr int L = decltype(log2s_tag)::value;
+        constexpr int WAVES = onepass_waves(L, sizeof(T));
+        launch_batched(nblocks, WAVES * 64, [&](int64_t, int64_t nb) {  // tickets, not block indices, pick the rows
+            if (st.big.packed)
+                MI_LAUNCH((k_spgemm_onepass<T, L, WAVES, true>), dim3((unsigned)nb), dim3(WAVES * 64), c.stream, A.rows,
+                          (const int64_t*)A.ptr, (const int64_t*)bd.ub, (const int64_t*)st.big.ext0p.as<int64_t>(),
+                          (const int32_t*)st.big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val,
+                          (const SpEntry<T>*)B.sp_rec.as<SpEntry<T>>(), st.upper_mode, ticket, flags, C.ptr, C.col,
+                          static_cast<T*>(C.val));
+            else
+                MI_LAUNCH((k_spgemm_onepass<T, L, WAVES, false>), dim3((unsigned)nb), dim3(WAVES * 64), c.stream, A.rows,
+                          (const int64_t*)A.ptr, (const int64_t*)bd.ub, (const int64_t*)st.big.ext0.as<int64_t>(),
+                          (const int32_t*)st.big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val,
+                          (const SpEntry<T>*)nullptr, st.upper_mode, ticket, flags, C.ptr, C.col, static_cast<T*>(C.val));
+        });
+        note_kernel("k_spgemm_onepass<%s,%d,%d>", type_name<T>(), L, WAVES);
+    };
+    if (log2s == 6) launch(std::integral_constant<int, 6>{});
+    else if (log2s == 8) launch(std::integral_constant<int, 8>{});
+    else if (log2s == 9) launch(std::integral_constant<int, 9>{});
+    else launch(std::integral_constant<int, 10>{});
+    MI_HIP_CHECK(hipGetLastError());
+    MI_HIP_CHECK(hipMemcpyAsync(&C.nnz, C.ptr + A.rows, sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+    trace_mark("one pass", t_last);
+    if (C.nnz * 2 < bd.sum_ub) {  // the bound was loose: give the surplus back
+        DevBuf col, val;
+        col.alloc(sizeof(int32_t) * (size_t)C.nnz);
+        val.alloc(sizeof(T) * (size_t)C.nnz);
+        if (C.nnz > 0) {
+            MI_HIP_CHECK(hipMemcpyAsync(col.p, C.col, sizeof(int32_t) * (size_t)C.nnz, hipMemcpyDeviceToDevice, c.stream));
+            MI_HIP_CHECK(hipMemcpyAsync(val.p, C.val, sizeof(T) * (size_t)C.nnz, hipMemcpyDeviceToDevice, c.stream));
+        }
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+        C.col_own = std::move(col);
+        C.val_own = std::move(val);
+        C.col = C.col_own.as<int32_t>();
+        C.val = C.val_own.p;
+    }
+    C.valid = true;
+    C.order_gen = next_order_gen();
+    C.sorted = false;
+    if (options().deterministic && C.nnz > 0) spgemm_values_deterministic<T>(A, B, C, st.upper_mode);
+    return true;
 }
 
 // Phase 2: column indices and values of C (storage allocated on the first run; repeatable).
@@ -1591,13 +2214,16 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
         // order (and, upper triangle of a sorted B, B's) -- one streamed pass rebuilds them.  A B that was unsorted at the
         // symbolic phase keeps mode 1 (every product tested), which is valid for any order.
         int64_t* ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
+        if (st.big.packed) ensure_packed<T>(B);
         if (A.rows > 0)
             MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows, (const int64_t*)A.ptr,
-                      (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, ub,
-                      st.big.ext0.as<int64_t>(), st.big.extlen.as<int32_t>());
+                      (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col,
+                      (const SpRow*)(st.big.packed ? B.sp_row.as<SpRow>() : nullptr), st.upper_mode, ub,
+                      st.big.ext0.as<int64_t>(), st.big.extlen.as<int32_t>(), st.big.ext0p.as<int64_t>());
         st.a_gen = A.order_gen;
         st.b_gen = B.order_gen;
     }
+    if (st.big.packed) ensure_packed<T>(B);  // the records follow B's values: rebuilt after mi_sparse_?_set_values (same layout)
     if (!C.col_own.p || C.col_own.bytes < sizeof(int32_t) * (size_t)C.nnz) C.col_own.alloc(sizeof(int32_t) * (size_t)C.nnz);
     if (!C.val_own.p || C.val_own.bytes < sizeof(T) * (size_t)C.nnz) C.val_own.alloc(sizeof(T) * (size_t)C.nnz);
     C.col = C.col_own.as<int32_t>();
@@ -1612,19 +2238,7 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     C.valid = true;
     C.order_gen = next_order_gen();
     C.sorted = false;
-    if (options().deterministic && C.nnz > 0) {
-        // the hash kernels above add the products of an entry in whatever order their waves arrive: keep their PATTERN, put
-        // the columns of every row in order (a unique arrangement) and form the values again in a fixed order
-        sort_csr(type_char<T>::value, C);
-        MI_HIP_CHECK(hipMemsetAsync(C.val, 0, sizeof(T) * (size_t)C.nnz, c.stream));
-        constexpr int RPB = 256 / WAVE;  // rows per workgroup
-        launch_batched(ceil_div(A.rows, (int64_t)RPB), 256, [&](int64_t off, int64_t nb) {
-            const int64_t r0 = off * RPB;
-            MI_LAUNCH((k_spgemm_values_det<T>), dim3((unsigned)nb), dim3(256), c.stream, r0, A.rows, (const int64_t*)A.ptr,
-                      (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val,
-                      st.upper_mode != 0 ? 1 : 0, (const int64_t*)C.ptr, (const int32_t*)C.col, static_cast<T*>(C.val));
-        });
-    }
+    if (options().deterministic && C.nnz > 0) spgemm_values_deterministic<T>(A, B, C, st.upper_mode);
 }
 
 // C := A * B (or its upper triangle).  C's storage is allocated here.
@@ -1632,7 +2246,9 @@ template <typename T>
 static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
 {
     SpgemmSymbolic st;
-    spgemm_symbolic<T>(A, B, upper, C, st);
+    const SpgemmBounds bd = spgemm_bounds<T>(A, B, upper, C, st);
+    if (spgemm_onepass<T>(A, B, C, st, bd)) return;
+    spgemm_symbolic<T>(A, B, C, st, bd);
     spgemm_numeric<T>(A, B, C, st);
 }
 
@@ -1701,7 +2317,10 @@ static void sp2m_run(int op_a, mi_sparse_matrix* ha, int op_b, mi_sparse_matrix*
     try {
         by_type(ha->vtype, [&](auto tag) {
             using T = decltype(tag);
-            if (starts) spgemm_symbolic<T>(a, b, upper, r->csr, st->sym);
+            if (starts) {  // staged: always two phases -- the pattern is kept for FINALIZE / later numeric re-runs
+                const SpgemmBounds bd = spgemm_bounds<T>(a, b, upper, r->csr, st->sym);
+                spgemm_symbolic<T>(a, b, r->csr, st->sym, bd);
+            }
             if (finishes) spgemm_numeric<T>(a, b, r->csr, st->sym);
         });
         ctx().sync();
@@ -1911,6 +2530,8 @@ static int set_values_generic(mi_sparse_matrix_t A, const T* values)
         }
         // the derived representation and the packed records of the dense gram (nothing else: plans depend on the pattern only) are stale
         primary.gram_rec.release();
+        primary.sp_rec.release();
+        primary.sp_row.release();
         Csr& other = created_csc ? h->csr : h->csrT;
         other = Csr();
         c.sync();

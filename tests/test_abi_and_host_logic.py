@@ -232,7 +232,8 @@ def test_options_are_validated_without_a_device(sda):
     """mi_sparse_set_option is host-side state: every documented knob is accepted, unknown names and out-of-range values
     are INVALID_VALUE (surfaced as ValueError), and nothing here needs a GPU."""
     defaults = {"spmm_slices": 0, "gram_sliced": 1, "gram_heads": 1, "gram_tile_kb": 0, "gram_persistent": -1, 
-                "bsr_native": 1, "staged_copies": 1, "spgemm_lds_parts": 1, "spgemm_slice_table": 1, "deterministic": 0, "gram_queue": 1}
+                "bsr_native": 1, "staged_copies": 1, "spgemm_lds_parts": 1, "spgemm_slice_table": 1, "deterministic": 0, "gram_queue": 1,
+                "spgemm_onepass": 1}
     for name, value in defaults.items():
         sda.mi_set_option(name, value)
     for name, bad in (("no_such_option", 1), ("gram_tile_kb", 96), ("spmm_slices", 3), ("spmm_slices", -1)):

@@ -285,6 +285,12 @@ inline void __builtin_amdgcn_wave_barrier() { hip_emu::st().waves[hip_emu::t_tid
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename T>
+inline T __hip_atomic_load(const T* p, int, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+template <typename T>
+inline void __hip_atomic_store(T* p, T v, int, int) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
 template <typename T>
 inline bool __hip_atomic_compare_exchange_strong(T* p, T* expected, T desired, int, int, int)
 {
