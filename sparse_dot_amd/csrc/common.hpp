@@ -616,7 +616,7 @@ struct Options {
     int64_t spgemm_slice_table_max = (int64_t)3 << 30;  // ... unless the table would exceed this many int32 entries
     int64_t spgemm_global_mode = 0;  // 0: one workgroup per row, L2-local atomics; 1: cooperative, agent-scope atomics
     int64_t spgemm_group = 1;        // short rows of B (<= 32 entries): one 16-lane group per selected row of B instead of the flat product list (a third of the instructions)
-    int64_t spgemm_packed = 1;       // numeric LDS kernels read B through a padded copy of (column, value) records, rows on 128-byte lines (built per handle on first use); 0: the two CSR arrays
+    int64_t spgemm_packed = 0;       // 1: numeric LDS kernels read B through a padded copy of (column, value) records, rows on 128-byte lines (built per handle on first use): fetch -34 %, time unchanged (round 4) -- off
     int64_t spgemm_onepass = 1;      // products whose rows all fit the small LDS tables: ONE kernel (no symbolic pass), rows placed by a decoupled look-back; 0: always two phases
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory

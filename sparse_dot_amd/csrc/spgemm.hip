@@ -161,11 +161,13 @@ __host__ __device__ inline int bin_of(int64_t c)
     return b;
 }
 
-// counts per bin (rows with c == 0 are skipped; NBINS <= blockDim); when `lists` != nullptr also scatters the row ids.
+// scatters the row ids into the lists of their size classes (rows with c == 0 are skipped; NBINS <= blockDim).
 // One global atomic per (workgroup, bin): positions inside the workgroup come from LDS counters.
+struct BinLists {
+    int32_t* l[NBINS];
+};
 __global__ void __launch_bounds__(256)
-    k_bin_rows(int64_t rows, const int64_t* __restrict__ cnt, int64_t* __restrict__ bin_counts,
-               int32_t* const* __restrict__ lists)
+    k_bin_rows(int64_t rows, const int64_t* __restrict__ cnt, int64_t* __restrict__ bin_counts, BinLists lists)
 {
     __shared__ int local_n[NBINS];
     __shared__ int64_t base[NBINS];
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256)
         base[threadIdx.x] = (int64_t)atomicAdd((unsigned long long*)&bin_counts[threadIdx.x],
                                                (unsigned long long)local_n[threadIdx.x]);
     __syncthreads();
-    if (b >= 0 && lists) lists[b][base[b] + pos] = (int32_t)i;
+    if (b >= 0) lists.l[b][base[b] + pos] = (int32_t)i;
 }
 
 // Inclusive prefix sums of one int per thread over a workgroup of NT threads, left in inc[0..NT): a
@@ -510,6 +512,60 @@ __global__ void __launch_bounds__(64)
         if (lane == 0) row_nnz[row] = local;
     } else {
         wave_lds_sync();
+#if defined(MI_GRP_KO_STORE)   // timing only: no output
+        if (keys[lane] == 12345678) ccol[out0] = 1;
+#elif defined(MI_GRP_STAGED)
+        // the row's entries compacted IN PLACE (an entry moves to a slot at or before its own; all reads of a step precede its
+        // writes), then written with 16 bytes per lane: whole 128-byte lines per store instruction instead of 4- / 8-byte
+        // pieces (the memory side saw 50 write requests of 64 bytes per row -- as many requests as the reads)
+        int n_out = 0;
+        for (int k0 = 0; k0 < S; k0 += 64) {
+            const int32_t key = keys[k0 + lane];
+            const T val = vals[k0 + lane];
+            int cnt;
+            const int pos = wave_rank(key != HASH_EMPTY, cnt);
+            wave_lds_sync();
+            if (key != HASH_EMPTY) {
+                keys[n_out + pos] = key;
+                vals[n_out + pos] = val;
+            }
+            n_out += cnt;
+        }
+        wave_lds_sync();
+        {   // columns: 4 per lane and store
+            int32_t* dst = ccol + out0;
+            int head = (int)((4 - (out0 & 3)) & 3);  // entries before the first 16-byte boundary
+            if (head > n_out) head = n_out;
+            if (lane < head) dst[lane] = keys[lane];
+            const int nvec = (n_out - head) / 4;
+            for (int i = lane; i < nvec; i += 64) {
+                u32x4 w;
+                w[0] = (unsigned)keys[head + 4 * i];
+                w[1] = (unsigned)keys[head + 4 * i + 1];
+                w[2] = (unsigned)keys[head + 4 * i + 2];
+                w[3] = (unsigned)keys[head + 4 * i + 3];
+                *reinterpret_cast<u32x4*>(dst + head + 4 * i) = w;
+            }
+            const int done = head + 4 * nvec;
+            if (lane < n_out - done) dst[done + lane] = keys[done + lane];
+        }
+        if constexpr (sizeof(T) == 8) {  // values: 2 per lane and store
+            T* dst = cval + out0;
+            const int head = (int)(out0 & 1) < n_out ? (int)(out0 & 1) : n_out;
+            if (lane < head) dst[lane] = vals[lane];
+            const int nvec = (n_out - head) / 2;
+            for (int i = lane; i < nvec; i += 64) {
+                vec<T, 2> w;
+                w.v[0] = vals[head + 2 * i];
+                w.v[1] = vals[head + 2 * i + 1];
+                *reinterpret_cast<vec<T, 2>*>(dst + head + 2 * i) = w;
+            }
+            const int done = head + 2 * nvec;
+            if (lane < n_out - done) dst[done + lane] = vals[done + lane];
+        } else {
+            for (int i = lane; i < n_out; i += 64) cval[out0 + i] = vals[i];
+        }
+#else
         int written = 0;
         for (int k0 = 0; k0 < S; k0 += 64) {
             const int32_t key = keys[k0 + lane];
@@ -521,6 +577,7 @@ __global__ void __launch_bounds__(64)
             }
             written += cnt;
         }
+#endif
     }
 }
 
@@ -1566,26 +1623,78 @@ struct Bins {
     int32_t* list[NBINS] = {};
 };
 
-static Bins make_bins(const int64_t* cnt, int64_t rows)
+// sum, maximum and the size-class histogram (bin_of) of `n` row counts in ONE pass and ONE copy back: out[0] += sum,
+// out[1] = max, out[2 + k] += rows of class k (rows with count 0 are in no class, as in k_bin_rows)
+__global__ void __launch_bounds__(256) k_row_stats(const int64_t* in, int64_t n, int64_t* out)
+{
+    __shared__ int64_t red_s[256], red_m[256];
+    __shared__ int hist[NBINS];
+    if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t s = 0, m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = in[i];
+        s += v;
+        if (v > m) m = v;
+        if (v > 0) atomicAdd(&hist[bin_of(v)], 1);
+    }
+    red_s[threadIdx.x] = s;
+    red_m[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red_s[threadIdx.x] += red_s[threadIdx.x + off];
+            if (red_m[threadIdx.x + off] > red_m[threadIdx.x]) red_m[threadIdx.x] = red_m[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long*)&out[0], (unsigned long long)red_s[0]);
+        atomicMax((long long*)&out[1], (long long)red_m[0]);
+    }
+    if (threadIdx.x < NBINS && hist[threadIdx.x] > 0)
+        atomicAdd((unsigned long long*)&out[2 + threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+struct RowStats {
+    int64_t sum = 0, max = 0;
+    int64_t bins[NBINS] = {};
+};
+
+static RowStats device_row_stats(const int64_t* in, int64_t n)
+{
+    Context& c = ctx();
+    int64_t* d = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (2 + NBINS)));
+    MI_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(int64_t) * (2 + NBINS), c.stream));
+    if (n > 0) {
+        const int64_t blocks = ceil_div(n, 1024) < 2048 ? ceil_div(n, 1024) : 2048;
+        MI_LAUNCH(k_row_stats, dim3((unsigned)blocks), dim3(256), c.stream, in, n, d);
+    }
+    int64_t h[2 + NBINS] = {};
+    MI_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+    RowStats r;
+    r.sum = h[0];
+    r.max = h[1];
+    for (int k = 0; k < NBINS; ++k) r.bins[k] = h[2 + k];
+    return r;
+}
+
+// row lists per size class; the class sizes come from device_row_stats (no counting pass, no round trip of its own)
+static Bins make_bins(const int64_t* cnt, int64_t rows, const RowStats& rs)
 {
     Context& c = ctx();
     Bins b;
     int64_t* dcounts = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * NBINS));
-    MI_HIP_CHECK(hipMemsetAsync(dcounts, 0, sizeof(int64_t) * NBINS, c.stream));
     const dim3 grid((unsigned)ceil_div(rows > 0 ? rows : 1, 256));
-    MI_LAUNCH(k_bin_rows, grid, dim3(256), c.stream, rows, cnt, dcounts, (int32_t* const*)nullptr);
-    MI_HIP_CHECK(hipMemcpyAsync(b.n, dcounts, sizeof(int64_t) * NBINS, hipMemcpyDeviceToHost, c.stream));
-    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-    int32_t* hl[NBINS];
+    BinLists hl;
     for (int k = 0; k < NBINS; ++k) {
+        b.n[k] = rs.bins[k];
         b.list[k] = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(b.n[k] + 1)));
-        hl[k] = b.list[k];
+        hl.l[k] = b.list[k];
     }
-    int32_t** dl = static_cast<int32_t**>(c.scratch_alloc(sizeof(int32_t*) * NBINS));
-    MI_HIP_CHECK(hipMemcpyAsync(dl, hl, sizeof(hl), hipMemcpyHostToDevice, c.stream));
     MI_HIP_CHECK(hipMemsetAsync(dcounts, 0, sizeof(int64_t) * NBINS, c.stream));
-    MI_LAUNCH(k_bin_rows, grid, dim3(256), c.stream, rows, cnt, dcounts, (int32_t* const*)dl);
-    MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // hl is on the host stack
+    MI_LAUNCH(k_bin_rows, grid, dim3(256), c.stream, rows, cnt, dcounts, hl);  // the pointers travel as a kernel argument
     return b;
 }
 
@@ -1610,47 +1719,6 @@ __global__ void k_max_i64(const int64_t* in, int64_t n, int64_t* out)
         __syncthreads();
     }
     if (threadIdx.x == 0) atomicMax((long long*)out, (long long)red[0]);
-}
-
-__global__ void k_sum_max_i64(const int64_t* in, int64_t n, int64_t* out)  // out[0] += sum, out[1] = max
-{
-    __shared__ int64_t red_s[256], red_m[256];
-    int64_t s = 0, m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t v = in[i];
-        s += v;
-        if (v > m) m = v;
-    }
-    red_s[threadIdx.x] = s;
-    red_m[threadIdx.x] = m;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            red_s[threadIdx.x] += red_s[threadIdx.x + off];
-            if (red_m[threadIdx.x + off] > red_m[threadIdx.x]) red_m[threadIdx.x] = red_m[threadIdx.x + off];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        atomicAdd((unsigned long long*)&out[0], (unsigned long long)red_s[0]);
-        atomicMax((long long*)&out[1], (long long)red_m[0]);
-    }
-}
-
-static void device_sum_max(const int64_t* in, int64_t n, int64_t& sum, int64_t& mx)
-{
-    Context& c = ctx();
-    int64_t* d = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * 2));
-    MI_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(int64_t) * 2, c.stream));
-    if (n > 0) {
-        const int64_t blocks = ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024;
-        MI_LAUNCH(k_sum_max_i64, dim3((unsigned)blocks), dim3(256), c.stream, in, n, d);
-    }
-    int64_t h[2] = {0, 0};
-    MI_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c.stream));
-    MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-    sum = h[0];
-    mx = h[1];
 }
 
 static int64_t device_max(const int64_t* in, int64_t n)
@@ -1706,14 +1774,22 @@ struct BigRows {
     bool grp = false;          // every row of B has <= 32 entries: the LDS bins up to 512 products run k_spgemm_grp
 };
 
+// `lists`: in -- row lists to use instead of binning `cnt` (the symbolic phase's, when every row sits in an LDS class: a table
+// sized for the upper bound of a row holds its exact length too); out (symbolic phase) -- the lists it built
 template <typename T, bool NUMERIC>
-static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt, int64_t max_cnt, int64_t* row_nnz,
-                      const int64_t* cptr, int32_t* ccol, T* cval, BigRows& big)
+static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt, const RowStats& rs, int64_t* row_nnz,
+                      const int64_t* cptr, int32_t* ccol, T* cval, BigRows& big, Bins* lists = nullptr)
 {
     Context& c = ctx();
     const int gw = pick_gw(B);
     const int gw64 = gw > 64 ? 64 : gw;
-    Bins b = make_bins(cnt, A.rows);
+    const int64_t max_cnt = rs.max;
+    Bins b;
+    if (NUMERIC && lists) b = *lists;
+    else {
+        b = make_bins(cnt, A.rows, rs);
+        if (lists) *lists = b;
+    }
     const bool force_global = options().spgemm_force_global != 0;
     // big rows (beyond the numeric LDS tables): LDS bitmap in the symbolic phase, range-partitioned LDS hash in
     // the numeric one -- when B is narrow enough for a bitmap (and, numeric, its rows are sorted)
@@ -2010,6 +2086,9 @@ struct SpgemmSymbolic {
 struct SpgemmBounds {
     int64_t* ub = nullptr;  // scratch, A.rows + 1
     int64_t max_ub = 0, sum_ub = 0;
+    RowStats stats;         // of ub: sum, maximum, rows per size class
+    Bins lists;             // row lists of the symbolic phase (scratch memory: valid inside the API call that built them)
+    bool lists_valid = false;
 };
 
 static void trace_mark(const char* what, std::chrono::steady_clock::time_point& t_last)
@@ -2067,24 +2146,26 @@ static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C
     st.b_gen = B.order_gen;
     st.a_nnz = A.nnz;
     st.b_nnz = B.nnz;
-    device_sum_max(bd.ub, A.rows, bd.sum_ub, bd.max_ub);
+    bd.stats = device_row_stats(bd.ub, A.rows);
+    bd.sum_ub = bd.stats.sum;
+    bd.max_ub = bd.stats.max;
     trace_mark("row upper bounds", t_last);
     return bd;
 }
 
 // Phase 1: row pointer of C (C.ptr, C.nnz) -- binning, symbolic hash / bitmap kernels, scan.
 template <typename T>
-static void spgemm_symbolic(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, const SpgemmBounds& bd)
+static void spgemm_symbolic(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, SpgemmBounds& bd)
 {
     Context& c = ctx();
     auto t_last = std::chrono::steady_clock::now();
     st.row_nnz.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
     int64_t* row_nnz = st.row_nnz.as<int64_t>();
     MI_HIP_CHECK(hipMemsetAsync(row_nnz, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
-    run_phase<T, false>(A, B, st.upper_mode, bd.ub, bd.max_ub, row_nnz, nullptr, nullptr, nullptr, st.big);
+    run_phase<T, false>(A, B, st.upper_mode, bd.ub, bd.stats, row_nnz, nullptr, nullptr, nullptr, st.big, &bd.lists);
+    bd.lists_valid = bd.max_ub <= 2048;  // every row in an LDS class of every value type (classes 0-6)
     trace_mark("symbolic", t_last);
     C.nnz = exclusive_scan_i64(row_nnz, C.ptr, C.rows);
-    st.max_nnz = C.nnz > 0 ? device_max(row_nnz, A.rows) : 0;
     C.col = nullptr;
     C.val = nullptr;
     C.valid = false;
@@ -2201,7 +2282,7 @@ static bool spgemm_onepass(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
 
 // Phase 2: column indices and values of C (storage allocated on the first run; repeatable).
 template <typename T>
-static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st)
+static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, SpgemmBounds* bd = nullptr)
 {
     Context& c = ctx();
     if (!st.done) fail(MI_SPARSE_STATUS_INVALID_VALUE, "numeric SpGEMM phase requested before the symbolic one");
@@ -2228,9 +2309,16 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     if (!C.val_own.p || C.val_own.bytes < sizeof(T) * (size_t)C.nnz) C.val_own.alloc(sizeof(T) * (size_t)C.nnz);
     C.col = C.col_own.as<int32_t>();
     C.val = C.val_own.p;
-    if (C.nnz > 0)
-        run_phase<T, true>(A, B, st.upper_mode, st.row_nnz.as<int64_t>(), st.max_nnz, nullptr, C.ptr, C.col,
-                           static_cast<T*>(C.val), st.big);
+    if (C.nnz > 0) {
+        if (bd && bd->lists_valid) {  // same API call as the symbolic phase, small rows only: its row lists serve again
+            run_phase<T, true>(A, B, st.upper_mode, st.row_nnz.as<int64_t>(), bd->stats, nullptr, C.ptr, C.col,
+                               static_cast<T*>(C.val), st.big, &bd->lists);
+        } else {
+            const RowStats rs = device_row_stats(st.row_nnz.as<int64_t>(), A.rows);
+            run_phase<T, true>(A, B, st.upper_mode, st.row_nnz.as<int64_t>(), rs, nullptr, C.ptr, C.col,
+                               static_cast<T*>(C.val), st.big);
+        }
+    }
     if (options().trace_phases) {
         MI_HIP_CHECK(hipStreamSynchronize(c.stream));
         fprintf(stderr, "[mi_sparse spgemm] numeric done\n");
@@ -2246,10 +2334,10 @@ template <typename T>
 static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
 {
     SpgemmSymbolic st;
-    const SpgemmBounds bd = spgemm_bounds<T>(A, B, upper, C, st);
+    SpgemmBounds bd = spgemm_bounds<T>(A, B, upper, C, st);
     if (spgemm_onepass<T>(A, B, C, st, bd)) return;
     spgemm_symbolic<T>(A, B, C, st, bd);
-    spgemm_numeric<T>(A, B, C, st);
+    spgemm_numeric<T>(A, B, C, st, &bd);
 }
 
 void spgemm(char vtype, const Csr& A, const Csr& B, bool upper, Csr& C)
@@ -2318,7 +2406,7 @@ static void sp2m_run(int op_a, mi_sparse_matrix* ha, int op_b, mi_sparse_matrix*
         by_type(ha->vtype, [&](auto tag) {
             using T = decltype(tag);
             if (starts) {  // staged: always two phases -- the pattern is kept for FINALIZE / later numeric re-runs
-                const SpgemmBounds bd = spgemm_bounds<T>(a, b, upper, r->csr, st->sym);
+                SpgemmBounds bd = spgemm_bounds<T>(a, b, upper, r->csr, st->sym);
                 spgemm_symbolic<T>(a, b, r->csr, st->sym, bd);
             }
             if (finishes) spgemm_numeric<T>(a, b, r->csr, st->sym);
