@@ -215,32 +215,6 @@ __device__ __forceinline__ int wave_rank(bool flag, int& total)
 #endif
 }
 
-// Exclusive prefix sum over the lanes of a wave of a SMALL count (0 <= v < 8), and the wave's total: three ballots, no LDS and
-// no shuffles (all 64 lanes call it together).
-__device__ __forceinline__ int wave_prefix_small(int v, int& total)
-{
-#ifdef MI_HIP_EMU
-    int x = v;
-    const int lane = (int)(threadIdx.x & 63);
-    for (int d = 1; d < 64; d <<= 1) {
-        const int n = __shfl_up(x, d);
-        if (lane >= d) x += n;
-    }
-    total = __shfl(x, 63);
-    return x - v;
-#else
-    int pre = 0;
-    total = 0;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        const unsigned long long m = __ballot((v >> b) & 1);
-        pre += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << b;
-        total += __popcll(m) << b;
-    }
-    return pre;
-#endif
-}
-
 // A 64-bit word other WORKGROUPS publish and poll (decoupled look-back of the one-pass SpGEMM): relaxed, agent scope -- the
 // word carries its own status bits, nothing else is ordered by it.
 __device__ __forceinline__ unsigned long long agent_load(const unsigned long long* p)

@@ -1053,7 +1053,7 @@ __global__ void __launch_bounds__(256)
 //    no cursor, no global atomic, every product read once.
 // ------------------------------------------------------------------------------------------------
 #ifndef MI_PART_UNROLL
-#define MI_PART_UNROLL 4
+#define MI_PART_UNROLL 2
 #endif
 #ifndef MI_BITMAP_UNROLL
 #define MI_BITMAP_UNROLL 8
@@ -1483,40 +1483,26 @@ __global__ void __launch_bounds__(PART_THREADS)
             block_scan_inclusive<NT>(len, pre, wave_tot, tid);
             const int* inc = pre;
             const int total = inc[NT - 1];
-            // 3. the slices as one flat list of products.  A lane takes PART_UNROLL CONSECUTIVE products: one search for the
-            // first, the others found by stepping (they are in the same slice two times out of three).  Round 4 counters: the
-            // kernel is VALU-bound (the SIMDs issue ~65 % of its cycles, 125 lane-instructions per product) and, with one
-            // product per lane and step, the 9-step search was 110 of the 250 instructions of a two-product step.  (The
-            // stepping cursor lost in round 2 when a lane's products were 512 apart -- five slices per step.)
-            for (int g0 = 0; g0 < total; g0 += NT * PART_UNROLL) {
+            // 3. the slices as one flat list of products
+            // (binary search per product, not the stepping cursor of the other kernels: the slices of ONE range are
+            // short -- ~12 products -- and stepping over five of them per product costs more than the search)
+            for (int f0 = tid; f0 < total; f0 += NT * PART_UNROLL) {
+                // The loads of B are UNCONDITIONAL (positions past the end re-read the lane's first product and are
+                // masked afterwards) and every use comes after the last load: with `if (f < total) { load; multiply }`
+                // per product the compiler waited for product u before issuing the loads of product u + 1.
                 int32_t j[PART_UNROLL];
                 T v[PART_UNROLL];
                 int64_t q[PART_UNROLL];
                 T av[PART_UNROLL];
-                const int f0 = g0 + tid * PART_UNROLL;
-                FlatCursor<NT> cur;
-                int64_t qb = 0;
-                T ab = vt<T>::zero();
-                if (f0 < total) {
-                    cur.seek(inc, f0);
-                    qb = qlo[cur.l];
-                    ab = a_s[cur.l];
-                }
+                int fs[PART_UNROLL], ls[PART_UNROLL];
+#pragma unroll
+                for (int u = 0; u < PART_UNROLL; ++u) fs[u] = f0 + u * NT < total ? f0 + u * NT : f0;
+                flat_find_lockstep<NT, PART_UNROLL>(inc, fs, ls);
 #pragma unroll
                 for (int u = 0; u < PART_UNROLL; ++u) {
-                    const int f = f0 + u;
-                    q[u] = 0;
-                    av[u] = ab;
-                    if (f < total) {
-                        if (u && cur.advance(inc, f)) {
-                            qb = qlo[cur.l];
-                            ab = a_s[cur.l];
-                        }
-                        q[u] = qb + (f - cur.lo);
-                        av[u] = ab;
-                    }
+                    q[u] = qlo[ls[u]] + (fs[u] - (ls[u] ? inc[ls[u] - 1] : 0));
+                    av[u] = a_s[ls[u]];
                 }
-                // loads of B unconditional (positions past the end read entry 0 and are masked) and issued together
 #pragma unroll
                 for (int u = 0; u < PART_UNROLL; ++u) {
                     j[u] = bcol[q[u]];
@@ -1524,7 +1510,7 @@ __global__ void __launch_bounds__(PART_THREADS)
                 }
 #pragma unroll
                 for (int u = 0; u < PART_UNROLL; ++u) {
-                    if (f0 + u >= total) j[u] = -1;
+                    if (f0 + u * NT >= total) j[u] = -1;
                     v[u] = vt<T>::mul(av[u], v[u]);
                 }
                 // first probe of every product issued back to back (the compare-and-swap returns a value: its latency
