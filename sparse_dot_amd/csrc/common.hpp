@@ -468,18 +468,6 @@ struct Csr {
     DevBuf gram_head;
     int64_t gram_head_w = 0;
     mutable int64_t gram_max_row = -1;
-    // SpGEMM with this matrix as the RIGHT operand (spgemm.hip): a padded copy of the entries as (column, value) records in
-    // which every row starts on a 128-byte line (SpEntry<T>), and per row {first record, first entry, entries} (SpRow) --
-    // a 16-entry fp64 row is two lines there, 3.5 on average in the two CSR arrays.  Built on first use; follows the VALUES
-    // and the entry order, so mi_sparse_?_set_values and mi_sparse_order drop it.
-    mutable DevBuf sp_rec, sp_row;
-};
-
-struct alignas(32) SpRow {
-    int64_t pstart;  // first record of the row in sp_rec
-    int64_t ustart;  // first entry of the row in col / val (= ptr[row])
-    int32_t len, pad0;
-    int64_t pad1;
 };
 
 uint64_t next_order_gen();  // handle.hip: process-wide, never repeats
@@ -616,7 +604,6 @@ struct Options {
     int64_t spgemm_slice_table_max = (int64_t)3 << 30;  // ... unless the table would exceed this many int32 entries
     int64_t spgemm_global_mode = 0;  // 0: one workgroup per row, L2-local atomics; 1: cooperative, agent-scope atomics
     int64_t spgemm_group = 1;        // short rows of B (<= 32 entries): one 16-lane group per selected row of B instead of the flat product list (a third of the instructions)
-    int64_t spgemm_packed = 0;       // 1: numeric LDS kernels read B through a padded copy of (column, value) records, rows on 128-byte lines (built per handle on first use): fetch -34 %, time unchanged (round 4) -- off
     int64_t spgemm_onepass = 1;      // products whose rows all fit the small LDS tables: ONE kernel (no symbolic pass), rows placed by a decoupled look-back; 0: always two phases
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory

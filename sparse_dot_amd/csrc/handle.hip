@@ -419,9 +419,7 @@ void sort_csr(char vtype, Csr& a)
         a.sorted = true;
         return;
     }
-    a.gram_rec.release();  // caches that follow the storage order of the entries (dense gram, SpGEMM right operand)
-    a.sp_rec.release();
-    a.sp_row.release();
+    a.gram_rec.release();  // caches that follow the storage order of the entries (dense gram)
     a.gram_off.release();
     a.gram_off_w = 0;
     a.gram_head.release();

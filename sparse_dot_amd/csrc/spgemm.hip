@@ -44,8 +44,8 @@ __device__ __forceinline__ int64_t lower_bound_col(const int32_t* __restrict__ c
 // three times (here, symbolic, numeric): with 16-entry rows of B that was one line in 2.5 (symbolic) / 4.5 (numeric).
 __global__ void __launch_bounds__(256)
     k_row_ub(int64_t rows, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
-             const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, const SpRow* __restrict__ brow, int upper,
-             int64_t* __restrict__ ub, int64_t* __restrict__ ext0, int32_t* __restrict__ extlen, int64_t* __restrict__ ext0p)
+             const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub,
+             int64_t* __restrict__ ext0, int32_t* __restrict__ extlen)
 {
     // 8 lanes per row
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,95 +55,18 @@ __global__ void __launch_bounds__(256)
     if (row < rows) {
         for (int64_t p = aptr[row] + sub; p < aptr[row + 1]; p += 8) {
             const int32_t k = acol[p];
-            int64_t b0, b1, shift = 0;
-            if (brow) {  // one 32-byte record instead of the two row-pointer entries; `shift`: entry position -> record position
-                const SpRow r = brow[k];
-                b0 = r.ustart;
-                b1 = b0 + r.len;
-                shift = r.pstart - r.ustart;
-            } else {
-                b0 = bptr[k];
-                b1 = bptr[k + 1];
-            }
+            int64_t b0 = bptr[k];
+            const int64_t b1 = bptr[k + 1];
             if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, (int32_t)row);
             s += b1 - b0;
             ext0[p] = b0;
             extlen[p] = (int32_t)(b1 - b0);
-            if (brow) ext0p[p] = b0 + shift;
         }
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 4);
     if (row < rows && sub == 0) ub[row] = s;
-}
-
-// ---- padded (column, value) records of the right operand (Csr::sp_rec / sp_row) -------------------------------------------
-template <typename T>
-constexpr int sp_unit() { return 128 / (int)sizeof(SpEntry<T>); }  // records per 128-byte line
-
-template <int UNIT>
-__global__ void k_sp_padded_len(int64_t rows, const int64_t* __restrict__ ptr, int64_t* __restrict__ plen)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows) plen[i] = (ptr[i + 1] - ptr[i] + UNIT - 1) / UNIT * UNIT;
-}
-__global__ void k_sp_rows(int64_t rows, const int64_t* __restrict__ ptr, const int64_t* __restrict__ pstart,
-                          SpRow* __restrict__ out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    SpRow r;
-    r.pstart = pstart[i];
-    r.ustart = ptr[i];
-    r.len = (int32_t)(ptr[i + 1] - ptr[i]);
-    r.pad0 = 0;
-    r.pad1 = 0;
-    out[i] = r;
-}
-template <typename T>
-__global__ void __launch_bounds__(256)
-    k_sp_pack(int64_t nnz, int64_t rows, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
-              const T* __restrict__ val, const int64_t* __restrict__ pstart, SpEntry<T>* __restrict__ rec)
-{
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
-        int64_t lo = 0, hi = rows;  // row of entry e: largest i with ptr[i] <= e (neighbouring threads share the probes)
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (ptr[mid] <= e) lo = mid; else hi = mid;
-        }
-        SpEntry<T> r;
-        r.c = col[e];
-        r.v = val[e];
-        rec[pstart[lo] + (e - ptr[lo])] = r;
-    }
-}
-
-// records + row table of B, built on first use (nullptr when B is too large for 32-bit row lengths to matter: never)
-template <typename T>
-static void ensure_packed(const Csr& B)
-{
-    if (B.sp_rec.p && B.sp_row.p) return;
-    Context& c = ctx();
-    constexpr int UNIT = sp_unit<T>();
-    int64_t* plen = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(B.rows + 1)));
-    int64_t* pstart = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(B.rows + 1)));
-    int64_t total = 0;
-    if (B.rows > 0) {
-        MI_LAUNCH(k_sp_padded_len<UNIT>, dim3((unsigned)ceil_div(B.rows, 256)), dim3(256), c.stream, B.rows,
-                  (const int64_t*)B.ptr, plen);
-        total = exclusive_scan_i64(plen, pstart, B.rows);
-    }
-    B.sp_row.alloc(sizeof(SpRow) * (size_t)(B.rows + 1));
-    B.sp_rec.alloc(sizeof(SpEntry<T>) * (size_t)(total + UNIT));
-    if (B.rows > 0)
-        MI_LAUNCH(k_sp_rows, dim3((unsigned)ceil_div(B.rows, 256)), dim3(256), c.stream, B.rows, (const int64_t*)B.ptr,
-                  (const int64_t*)pstart, B.sp_row.as<SpRow>());
-    if (B.nnz > 0) {
-        const int64_t blocks = ceil_div(B.nnz, 256) < (1 << 20) ? ceil_div(B.nnz, 256) : (1 << 20);
-        MI_LAUNCH((k_sp_pack<T>), dim3((unsigned)blocks), dim3(256), c.stream, B.nnz, B.rows, (const int64_t*)B.ptr,
-                  (const int32_t*)B.col, (const T*)B.val, (const int64_t*)pstart, B.sp_rec.as<SpEntry<T>>());
-    }
 }
 
 // ---- binning -------------------------------------------------------------------------------------
@@ -284,11 +207,11 @@ struct FlatCursor {
 #define MI_LDS_UNROLL 4
 #endif
 constexpr int LDS_UNROLL = MI_LDS_UNROLL;
-template <typename T, int LOG2S, int THREADS, bool NUMERIC, bool PACKED>
+template <typename T, int LOG2S, int THREADS, bool NUMERIC>
 __global__ void __launch_bounds__(THREADS)
     k_spgemm_lds(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
                  const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
-                 const int32_t* __restrict__ bcol, const T* __restrict__ bval, const SpEntry<T>* __restrict__ brec, int gw, int upper,
+                 const int32_t* __restrict__ bcol, const T* __restrict__ bval, int gw, int upper,
                  int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
                  T* __restrict__ cval)
 {
@@ -351,19 +274,10 @@ __global__ void __launch_bounds__(THREADS)
                     avs[u] = av;
                 }
             }
-            if constexpr (NUMERIC && PACKED) {  // ext0 counts RECORDS of the padded copy: column and value in one load
 #pragma unroll
-                for (int u = 0; u < LDS_UNROLL; ++u) {
-                    const SpEntry<T> e = brec[q[u]];
-                    j[u] = e.c;
-                    v[u] = e.v;
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < LDS_UNROLL; ++u) {
-                    j[u] = bcol[q[u]];
-                    if (NUMERIC) v[u] = bval[q[u]];
-                }
+            for (int u = 0; u < LDS_UNROLL; ++u) {
+                j[u] = bcol[q[u]];
+                if (NUMERIC) v[u] = bval[q[u]];
             }
 #pragma unroll
             for (int u = 0; u < LDS_UNROLL; ++u) {
@@ -410,11 +324,11 @@ __global__ void __launch_bounds__(THREADS)
 // of the row lengths, position -> row search, stepping cursor, 64-bit positions), which pay off when rows of B are long or
 // uneven.  When every row of B has at most 32 entries none of it is needed: lane group g of the wave takes row 4 i + g of the
 // selected rows, lane l of the group its entry l (and l + 16) -- no scan, no search; four rows per group in flight.
-template <typename T, int LOG2S, bool NUMERIC, bool PACKED>
+template <typename T, int LOG2S, bool NUMERIC>
 __global__ void __launch_bounds__(64)
     k_spgemm_grp(const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
                  const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
-                 const int32_t* __restrict__ bcol, const T* __restrict__ bval, const SpEntry<T>* __restrict__ brec, int upper,
+                 const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
                  int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
                  T* __restrict__ cval)
 {
@@ -475,14 +389,8 @@ __global__ void __launch_bounds__(64)
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {  // unconditional, issued together
-                    if constexpr (NUMERIC && PACKED) {
-                        const SpEntry<T> e = brec[q[u]];
-                        j[u] = e.c;
-                        v[u] = e.v;
-                    } else {
-                        j[u] = bcol[q[u]];
-                        if (NUMERIC) v[u] = bval[q[u]];
-                    }
+                    j[u] = bcol[q[u]];
+                    if (NUMERIC) v[u] = bval[q[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -609,11 +517,11 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
     return v;
 }
 
-template <typename T, int LOG2S, int WAVES, bool PACKED>
+template <typename T, int LOG2S, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
     k_spgemm_onepass(int64_t rows, const int64_t* __restrict__ aptr, const int64_t* __restrict__ ub,
                      const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
-                     const int32_t* __restrict__ bcol, const T* __restrict__ bval, const SpEntry<T>* __restrict__ brec, int upper,
+                     const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
                      unsigned long long* __restrict__ ticket_counter, unsigned long long* __restrict__ flags,
                      int64_t* __restrict__ cptr, int32_t* __restrict__ ccol, T* __restrict__ cval)
 {
@@ -699,14 +607,8 @@ __global__ void __launch_bounds__(WAVES * 64)
                 T pv[LDS_UNROLL];
 #pragma unroll
                 for (int u = 0; u < LDS_UNROLL; ++u) {  // unconditional, issued together
-                    if constexpr (PACKED) {
-                        const SpEntry<T> e = brec[q[u]];
-                        j[u] = e.c;
-                        pv[u] = e.v;
-                    } else {
-                        j[u] = bcol[q[u]];
-                        pv[u] = bval[q[u]];
-                    }
+                    j[u] = bcol[q[u]];
+                    pv[u] = bval[q[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < LDS_UNROLL; ++u) {
@@ -1769,8 +1671,6 @@ struct BigRows {
     DevBuf boff_by_row;        // int64[A.rows]: offset of a big row's range starts in `bounds`
     DevBuf bounds;             // int32: range starts, P_max = ceil(min(ub, cols) / cap) slots per big row
     DevBuf ext0, extlen;       // per nonzero of A: first counted entry of B's row (int64) and their number (int32) -- k_row_ub
-    DevBuf ext0p;              // the same first entry as a position in B's padded records (Csr::sp_rec) when `packed`
-    bool packed = false;
     bool grp = false;          // every row of B has <= 32 entries: the LDS bins up to 512 products run k_spgemm_grp
 };
 
@@ -1800,33 +1700,23 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
 #define MI_SPGEMM_ARGS(list)                                                                                       \
     (const int32_t*)list, (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,   \
         (const int32_t*)B.col, (const T*)B.val
-    const bool packed = NUMERIC && big.packed;  // numeric LDS kernels: one 16-byte record per product from the padded copy of B
 #define MI_SPGEMM_LDS_ARGS(list)                                                                                   \
-    (const int32_t*)list, (const int64_t*)A.ptr, (const int64_t*)(packed ? big.ext0p.as<int64_t>() : big.ext0.as<int64_t>()), \
-        (const int32_t*)big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val,        \
-        (const SpEntry<T>*)B.sp_rec.as<SpEntry<T>>()
+    (const int32_t*)list, (const int64_t*)A.ptr, (const int64_t*)big.ext0.as<int64_t>(),                           \
+        (const int32_t*)big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val
     if (!force_global) {
 #define MI_SPGEMM_BIN(k, LOG2S, THREADS, GW)                                                                       \
     if (b.n[k]) {                                                                                                  \
         launch_batched(b.n[k], THREADS, [&](int64_t off, int64_t nb) {                                             \
-            if (packed)                                                                                            \
-                MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC, NUMERIC>), dim3((unsigned)nb), dim3(THREADS), c.stream, \
-                          MI_SPGEMM_LDS_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);           \
-            else                                                                                                   \
-                MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC, false>), dim3((unsigned)nb), dim3(THREADS), c.stream, \
-                          MI_SPGEMM_LDS_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);           \
+            MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC>), dim3((unsigned)nb), dim3(THREADS), c.stream,       \
+                      MI_SPGEMM_LDS_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);               \
         });                                                                                                        \
         b.n[k] = 0;                                                                                                \
     }
 #define MI_SPGEMM_GRP(k, LOG2S)                                                                                     \
     if (big.grp && b.n[k]) {                                                                                       \
         launch_batched(b.n[k], 64, [&](int64_t off, int64_t nb) {                                                  \
-            if (packed)                                                                                            \
-                MI_LAUNCH((k_spgemm_grp<T, LOG2S, NUMERIC, NUMERIC>), dim3((unsigned)nb), dim3(64), c.stream,        \
-                          MI_SPGEMM_LDS_ARGS(b.list[k] + off), (int)upper, row_nnz, cptr, ccol, cval);               \
-            else                                                                                                   \
-                MI_LAUNCH((k_spgemm_grp<T, LOG2S, NUMERIC, false>), dim3((unsigned)nb), dim3(64), c.stream,          \
-                          MI_SPGEMM_LDS_ARGS(b.list[k] + off), (int)upper, row_nnz, cptr, ccol, cval);               \
+            MI_LAUNCH((k_spgemm_grp<T, LOG2S, NUMERIC>), dim3((unsigned)nb), dim3(64), c.stream,                     \
+                      MI_SPGEMM_LDS_ARGS(b.list[k] + off), (int)upper, row_nnz, cptr, ccol, cval);                   \
         });                                                                                                        \
         b.n[k] = 0;                                                                                                \
     }
@@ -2128,20 +2018,14 @@ static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C
     bd.ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
     big.ext0.alloc(sizeof(int64_t) * (size_t)(A.nnz + 1));
     big.extlen.alloc(sizeof(int32_t) * (size_t)(A.nnz + 1));
-    big.packed = options().spgemm_packed != 0 && B.nnz > 0 && !options().spgemm_force_global;
     if (options().spgemm_group && B.rows > 0 && B.nnz >= 6 * B.rows) {  // short, even rows of B: 16 lanes per row, no flat list
         if (B.gram_max_row < 0) B.gram_max_row = device_max_row_len(B);
         big.grp = B.gram_max_row <= 32;
     }
-    if (big.packed) {
-        ensure_packed<T>(B);
-        big.ext0p.alloc(sizeof(int64_t) * (size_t)(A.nnz + 1));
-    }
     if (A.rows > 0)
         MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows,
-                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col,
-                  (const SpRow*)(big.packed ? B.sp_row.as<SpRow>() : nullptr), st.upper_mode, bd.ub,
-                  big.ext0.as<int64_t>(), big.extlen.as<int32_t>(), big.ext0p.as<int64_t>());
+                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, bd.ub,
+                  big.ext0.as<int64_t>(), big.extlen.as<int32_t>());
     st.a_gen = A.order_gen;
     st.b_gen = B.order_gen;
     st.a_nnz = A.nnz;
@@ -2237,17 +2121,10 @@ static bool spgemm_onepass(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
         constexpr int L = decltype(log2s_tag)::value;
         constexpr int WAVES = onepass_waves(L, sizeof(T));
         launch_batched(nblocks, WAVES * 64, [&](int64_t, int64_t nb) {  // tickets, not block indices, pick the rows
-            if (st.big.packed)
-                MI_LAUNCH((k_spgemm_onepass<T, L, WAVES, true>), dim3((unsigned)nb), dim3(WAVES * 64), c.stream, A.rows,
-                          (const int64_t*)A.ptr, (const int64_t*)bd.ub, (const int64_t*)st.big.ext0p.as<int64_t>(),
-                          (const int32_t*)st.big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val,
-                          (const SpEntry<T>*)B.sp_rec.as<SpEntry<T>>(), st.upper_mode, ticket, flags, C.ptr, C.col,
-                          static_cast<T*>(C.val));
-            else
-                MI_LAUNCH((k_spgemm_onepass<T, L, WAVES, false>), dim3((unsigned)nb), dim3(WAVES * 64), c.stream, A.rows,
-                          (const int64_t*)A.ptr, (const int64_t*)bd.ub, (const int64_t*)st.big.ext0.as<int64_t>(),
-                          (const int32_t*)st.big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val,
-                          (const SpEntry<T>*)nullptr, st.upper_mode, ticket, flags, C.ptr, C.col, static_cast<T*>(C.val));
+            MI_LAUNCH((k_spgemm_onepass<T, L, WAVES>), dim3((unsigned)nb), dim3(WAVES * 64), c.stream, A.rows,
+                      (const int64_t*)A.ptr, (const int64_t*)bd.ub, (const int64_t*)st.big.ext0.as<int64_t>(),
+                      (const int32_t*)st.big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val,
+                      st.upper_mode, ticket, flags, C.ptr, C.col, static_cast<T*>(C.val));
         });
         note_kernel("k_spgemm_onepass<%s,%d,%d>", type_name<T>(), L, WAVES);
     };
@@ -2295,16 +2172,13 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
         // order (and, upper triangle of a sorted B, B's) -- one streamed pass rebuilds them.  A B that was unsorted at the
         // symbolic phase keeps mode 1 (every product tested), which is valid for any order.
         int64_t* ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
-        if (st.big.packed) ensure_packed<T>(B);
         if (A.rows > 0)
             MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows, (const int64_t*)A.ptr,
-                      (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col,
-                      (const SpRow*)(st.big.packed ? B.sp_row.as<SpRow>() : nullptr), st.upper_mode, ub,
-                      st.big.ext0.as<int64_t>(), st.big.extlen.as<int32_t>(), st.big.ext0p.as<int64_t>());
+                      (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, ub,
+                      st.big.ext0.as<int64_t>(), st.big.extlen.as<int32_t>());
         st.a_gen = A.order_gen;
         st.b_gen = B.order_gen;
     }
-    if (st.big.packed) ensure_packed<T>(B);  // the records follow B's values: rebuilt after mi_sparse_?_set_values (same layout)
     if (!C.col_own.p || C.col_own.bytes < sizeof(int32_t) * (size_t)C.nnz) C.col_own.alloc(sizeof(int32_t) * (size_t)C.nnz);
     if (!C.val_own.p || C.val_own.bytes < sizeof(T) * (size_t)C.nnz) C.val_own.alloc(sizeof(T) * (size_t)C.nnz);
     C.col = C.col_own.as<int32_t>();
@@ -2618,8 +2492,6 @@ static int set_values_generic(mi_sparse_matrix_t A, const T* values)
         }
         // the derived representation and the packed records of the dense gram (nothing else: plans depend on the pattern only) are stale
         primary.gram_rec.release();
-        primary.sp_rec.release();
-        primary.sp_row.release();
         Csr& other = created_csc ? h->csr : h->csrT;
         other = Csr();
         c.sync();
