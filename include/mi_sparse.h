@@ -480,7 +480,8 @@ const char *mi_sparse_last_error(void);
  *   spmm_slices (XCD-affine column slices: 0 = by row width, 1 / 2 / 4 / 8), spmm_plan_sync
  *                                                                               (SpMM kernel variants)
  *   spgemm_lds_parts, spgemm_slice_table, spgemm_slice_table_max, spgemm_part_log2s_bias,
- *   spgemm_force_global, spgemm_global_mode                                     (SpGEMM big-row paths)
+ *   spgemm_force_global, spgemm_global_mode, spgemm_rank (1: big rows accumulate by rank on the stored row bitmaps and come
+ *                   out sorted, 0 (default): range-partitioned LDS hash)                              (SpGEMM big-row paths)
  *   spgemm_onepass (1: a product whose rows all have <= 512 products runs as ONE kernel -- no symbolic pass, the rows of the
  *                   result are placed by a decoupled look-back; 0: always symbolic + numeric)
  *   gram_sliced (1: slice-table walk when the slices are short, 2: whenever the rows are sorted, 0: never),

@@ -816,6 +816,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.spgemm_global_mode = value;
         } else if (!strcmp(name, "spgemm_group")) {
             o.spgemm_group = value;
+        } else if (!strcmp(name, "spgemm_rank")) {
+            o.spgemm_rank = value;
         } else if (!strcmp(name, "spgemm_onepass")) {
             o.spgemm_onepass = value;
         } else if (!strcmp(name, "pool_enable")) {

@@ -986,13 +986,28 @@ static inline size_t bitmap_lds_bytes(int64_t ncols)
     return sizeof(unsigned) * (size_t)(BITMAP_IDX(words) + 1);
 }
 
-template <bool BOUNDS>
+// What k_spgemm_bitmap leaves behind besides the row length.  BM_COUNT: nothing.  BM_BOUNDS: the columns where every range of
+// `cap` distinct columns starts (numeric phase: k_part_slices + k_spgemm_part).  BM_STORE (round 4): the bitmap itself, in global
+// memory, and the number of set bits of every block of RANK_G columns (numeric phase: k_spgemm_rank).
+enum { BM_COUNT = 0, BM_BOUNDS = 1, BM_STORE = 2 };
+constexpr int RANK_G = 4096;           // columns per block: a (row, block) never holds more entries than the accumulators of k_spgemm_rank
+constexpr int RANK_GW = RANK_G / 32;   // bitmap words per block
+struct BitmapStore {
+    unsigned* bm;        // nbig slots of wpr words: slot idx = position of the row in the big-row list of the symbolic phase
+    int64_t wpr;         // words per slot: nblk * RANK_GW (>= the bitmap's words; the rest zero)
+    uint16_t* blkcnt;    // nbig x nblk: set bits per block of RANK_G columns
+    int32_t* slot_of;    // per row of A: its slot
+    int nblk;
+};
+
+template <int MODE>
 __global__ void __launch_bounds__(1024)
     k_spgemm_bitmap(int64_t nbig, const int32_t* __restrict__ row_list, int64_t ncols,
                     const int64_t* __restrict__ aptr, const int64_t* __restrict__ ext0,
                     const int32_t* __restrict__ extlen, const int32_t* __restrict__ bcol, int gw, int upper,
                     int64_t* __restrict__ row_nnz, const int64_t* __restrict__ boff, int64_t cap,
-                    int32_t* __restrict__ bounds, int64_t* __restrict__ boff_by_row, unsigned long long* work_counter)
+                    int32_t* __restrict__ bounds, int64_t* __restrict__ boff_by_row, unsigned long long* work_counter,
+                    BitmapStore store)
 {
     MI_DYN_SMEM(smem);
     unsigned* bits = reinterpret_cast<unsigned*>(smem);
@@ -1066,12 +1081,36 @@ __global__ void __launch_bounds__(1024)
             }
             __syncthreads();
         }
-        if constexpr (!BOUNDS) {
+        if constexpr (MODE == BM_COUNT) {
             int local = 0;
             for (int64_t k = tid; k < padded; k += threads) local += __popc(bits[k]);  // pad words are zero
             if (local) atomicAdd(&counter, local);
             __syncthreads();
             if (tid == 0) row_nnz[row] = counter;
+        } else if constexpr (MODE == BM_STORE) {
+            // the bitmap goes out as it is (coalesced; 128 KiB for 2^20 columns) and so do the set bits per block of RANK_G columns:
+            // the numeric phase cuts the row into runs of blocks, re-reads their bits and turns a column into its RANK in the run
+            // -- the position of the entry in the (sorted) row of C -- with one LDS read and a popcount
+            unsigned* dst = store.bm + idx * store.wpr;
+            for (int64_t k = tid; k < store.wpr; k += threads) dst[k] = k < words ? bits[BITMAP_IDX(k)] : 0u;
+            int wave_sum = 0;
+            for (int b = tid >> 6; b < store.nblk; b += 16) {
+                int c = 0;
+                for (int i = tid & 63; i < RANK_GW; i += 64) {
+                    const int64_t k = (int64_t)b * RANK_GW + i;
+                    if (k < words) c += __popc(bits[BITMAP_IDX(k)]);
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+                if ((tid & 63) == 0) store.blkcnt[idx * store.nblk + b] = (uint16_t)c;  // <= RANK_G = 4096
+                wave_sum += c;
+            }
+            if ((tid & 63) == 0 && wave_sum) atomicAdd(&counter, wave_sum);
+            __syncthreads();
+            if (tid == 0) {
+                row_nnz[row] = counter;
+                store.slot_of[row] = (int32_t)idx;
+            }
         } else {
             // rank of every set bit -> the column where each range of `cap` distinct columns starts
             const int cap_log2 = 63 - __builtin_clzll((unsigned long long)cap);
@@ -1458,6 +1497,512 @@ __global__ void __launch_bounds__(PART_THREADS)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Big rows, numeric phase, round 4: accumulate BY RANK (k_spgemm_rank).
+//    The symbolic phase kept every big row's column bitmap (BM_STORE) and its set bits per block of RANK_G = 4096 columns.  A row
+//    is cut into ITEMS = runs of consecutive blocks holding at most CAP entries of C and at most RANK_SPANB blocks.  One workgroup
+//    per item:
+//      * reads the item's piece of the bitmap (<= 16 KiB, coalesced), turns it into (word, set bits before it) records in LDS and
+//        writes the item's column indices straight from the bits -- in increasing order, the whole row of C comes out SORTED;
+//      * finds the slice of every selected row of B that falls into the item's columns by TABLE LOOKUP: items start and end at
+//        block boundaries, and where block b starts inside every row of B (blkptr, k_blkptr) depends on B only -- no search per
+//        (row of C, row of B, range) as k_part_slices does (2.4e9 bisections, 28 ms on the literal configs[2]);
+//      * walks the slices as one flat product list and adds every product into acc[rank of its column] with ONE LDS atomic: the
+//        rank is records[(j - c0) >> 5].before + popcount(word & bits below j) -- no hash probe, no key compare, no collision,
+//        and the accumulators are all used (a hash table is half empty): CAP = 4096 entries of C per item instead of 1024,
+//        a quarter of the items;
+//      * writes acc[0 .. count) out in order (no compaction, no cursor atomics).
+// ------------------------------------------------------------------------------------------------
+#ifndef MI_RANK_THREADS
+#define MI_RANK_THREADS 512
+#endif
+#ifndef MI_RANK_UNROLL
+#define MI_RANK_UNROLL 2
+#endif
+#ifndef MI_RANK_SPANB
+#define MI_RANK_SPANB 32
+#endif
+constexpr int RANK_THREADS = MI_RANK_THREADS;
+constexpr int RANK_UNROLL = MI_RANK_UNROLL;
+constexpr int RANK_SPANB = MI_RANK_SPANB;            // blocks per item at most (32: 131 072 columns, 4096 bitmap words)
+constexpr int RANK_SPANW = RANK_SPANB * RANK_GW;
+#ifndef MI_RANK_XCD_RUN
+#define MI_RANK_XCD_RUN 4
+#endif
+constexpr int RANK_XCD_RUN = MI_RANK_XCD_RUN;  // consecutive groups per XCD
+template <typename T>
+constexpr int rank_cap() { return RANK_G; }  // accumulators per item (a block of RANK_G columns must fit): 32 KiB of fp64; complex double stays on k_spgemm_part
+
+#ifndef MI_RANK_LONG
+#define MI_RANK_LONG 64
+#endif
+#ifndef MI_RANK_SEG_UNROLL
+#define MI_RANK_SEG_UNROLL 8
+#endif
+constexpr int RANK_LONG = MI_RANK_LONG;              // slices of at least this many entries are walked wave-wise, 64 entries at a time
+constexpr int RANK_SEG_UNROLL = MI_RANK_SEG_UNROLL;  // segments in flight per wave
+
+__device__ __forceinline__ int wave_uniform(int v)  // v is the same in every lane: keep it in a scalar register
+{
+#ifdef MI_HIP_EMU
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_uniform_val(T v)  // the same for a value of any size that is a multiple of 4 bytes
+{
+#ifdef MI_HIP_EMU
+    return v;
+#else
+    static_assert(sizeof(T) % 4 == 0, "wave_uniform_val: whole 32-bit words");
+    int w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); ++k) w[k] = __builtin_amdgcn_readfirstlane(w[k]);
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+#endif
+}
+
+// inclusive prefix sums of three ints per thread at once (one pair of barriers; see block_scan_inclusive)
+template <int NT>
+__device__ __forceinline__ void block_scan3(int& a, int& b, int& c, int (*wt)[NT / 64], int tid)
+{
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int na = __shfl_up(a, d), nb = __shfl_up(b, d), nc = __shfl_up(c, d);
+        if (lane >= d) {
+            a += na;
+            b += nb;
+            c += nc;
+        }
+    }
+    if (lane == 63) {
+        wt[0][w] = a;
+        wt[1][w] = b;
+        wt[2][w] = c;
+    }
+    __syncthreads();
+    int xa = 0, xb = 0, xc = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k)
+        if (k < w) {
+            xa += wt[0][k];
+            xb += wt[1][k];
+            xc += wt[2][k];
+        }
+    a += xa;
+    b += xb;
+    c += xc;
+}
+
+struct alignas(8) RankRec {
+    unsigned bits, before;  // a word of the item's bitmap and the number of set bits in the words before it: one 8-byte LDS read per product
+};
+struct alignas(32) RankItem {
+    int64_t out0;         // where the item's entries start in ccol / cval
+    int32_t row, slot;    // row of A / C; the row's slot in the stored bitmaps
+    int32_t b0, nb;       // blocks [b0, b0 + nb)
+    int32_t count, pad;   // entries of C in the item
+};
+
+// blkptr[k * (nblk + 1) + b] = first position of row k of B (sorted) whose column is >= b * RANK_G; [nblk]: the end of the row.
+// One wave per row; every entry that opens one or more blocks writes their starts.
+__global__ void __launch_bounds__(256)
+    k_blkptr(int64_t rows, const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int nblk,
+             int32_t* __restrict__ blkptr)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (row >= rows) return;
+    const int64_t b0 = bptr[row], b1 = bptr[row + 1];
+    int32_t* out = blkptr + row * (int64_t)(nblk + 1);
+    if (b0 == b1) {
+        for (int b = lane; b <= nblk; b += WAVE) out[b] = (int32_t)b0;
+        return;
+    }
+    for (int64_t q = b0 + lane; q < b1; q += WAVE) {
+        const int blk = bcol[q] / RANK_G;
+        const int prev = q > b0 ? bcol[q - 1] / RANK_G : -1;
+        for (int b = prev + 1; b <= blk; ++b) out[b] = (int32_t)q;
+        if (q == b1 - 1)
+            for (int b = blk + 1; b <= nblk; ++b) out[b] = (int32_t)b1;
+    }
+}
+
+// Items of every big row: consecutive blocks are merged while they hold <= cap entries and span <= RANK_SPANB blocks; blocks
+// without entries before the first / after the last entry of an item cost nothing and empty runs are no item at all.
+// items == nullptr: count only (n_items[t]); else fill at items + item_off[t].
+__global__ void __launch_bounds__(256)
+    k_rank_items(int64_t nb, const int32_t* __restrict__ row_list, const int32_t* __restrict__ slot_of,
+                 const uint16_t* __restrict__ blkcnt, int nblk, int cap, const int64_t* __restrict__ cptr,
+                 const int64_t* __restrict__ item_off, int64_t* __restrict__ n_items, RankItem* __restrict__ items)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb) return;
+    const int32_t row = row_list[t];
+    const int32_t slot = slot_of[row];
+    const uint16_t* cnt = blkcnt + (int64_t)slot * nblk;
+    RankItem* out = items ? items + item_off[t] : nullptr;
+    int64_t n = 0, done = 0;  // items so far, entries of C before the open item
+    int cur_b0 = -1, cur = 0;
+    auto emit = [&](int b_end) {
+        if (out) {
+            RankItem it;
+            it.out0 = cptr[row] + done;
+            it.row = row;
+            it.slot = slot;
+            it.b0 = cur_b0;
+            it.nb = b_end - cur_b0;
+            it.count = cur;
+            it.pad = 0;
+            out[n] = it;
+        }
+        ++n;
+        done += cur;
+        cur_b0 = -1;
+        cur = 0;
+    };
+    for (int b = 0; b < nblk; ++b) {
+        const int c = cnt[b];
+        if (cur_b0 >= 0 && (cur + c > cap || b - cur_b0 >= RANK_SPANB)) emit(b);
+        if (c == 0) continue;  // an empty block never opens an item (inside one it is skipped over for free)
+        if (cur_b0 < 0) cur_b0 = b;
+        cur += c;
+    }
+    if (cur_b0 >= 0) emit(nblk);
+    if (!out) n_items[t] = n;
+}
+
+// One workgroup per GROUP = up to RANK_RUN consecutive items of one row, one after the other: the row's nonzeros of A (column,
+// value, extent) are loaded ONCE and stay in registers (rows of up to NT nonzeros), and while item j is walked the loads item
+// j + 1 starts with -- its piece of the bitmap and the two block starts per selected row of B -- are already in flight.  With one
+// item per workgroup (first version) every item began with the chain  item -> row -> A's columns -> block starts -> entries of B,
+// four dependent round trips with only two workgroups per CU (72 KiB of LDS each) to hide them behind: 22 us per item.
+#ifndef MI_RANK_RUN
+#define MI_RANK_RUN 16
+#endif
+constexpr int RANK_RUN = MI_RANK_RUN;
+struct alignas(32) RankGroup {
+    int64_t a0;        // the row's nonzeros in A
+    int64_t item0;     // first item
+    int32_t na, row;
+    int32_t n, pad;    // items in the group
+};
+
+// groups of every big row (after k_rank_items has counted / filled the items)
+__global__ void __launch_bounds__(256)
+    k_rank_groups(int64_t nb, const int32_t* __restrict__ row_list, const int64_t* __restrict__ aptr,
+                  const int64_t* __restrict__ item_off, const int64_t* __restrict__ group_off, int64_t* __restrict__ n_groups,
+                  RankGroup* __restrict__ groups)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb) return;
+    const int64_t n = item_off[t + 1] - item_off[t];
+    const int64_t ng = (n + RANK_RUN - 1) / RANK_RUN;
+    if (!groups) {
+        n_groups[t] = ng;
+        return;
+    }
+    const int32_t row = row_list[t];
+    for (int64_t g = 0; g < ng; ++g) {
+        RankGroup r;
+        r.a0 = aptr[row];
+        r.na = (int32_t)(aptr[row + 1] - aptr[row]);
+        r.row = row;
+        r.item0 = item_off[t] + g * RANK_RUN;
+        r.n = (int32_t)(n - g * RANK_RUN < RANK_RUN ? n - g * RANK_RUN : RANK_RUN);
+        r.pad = 0;
+        groups[group_off[t] + g] = r;
+    }
+}
+
+template <typename T, int NT, int U>
+__global__ void __launch_bounds__(NT, (sizeof(T) <= 8 ? 2 : 1) * NT / 256)  // two workgroups per CU (LDS): waves per SIMD
+    k_spgemm_rank(int64_t group_base, int64_t n_groups, const RankGroup* __restrict__ groups, const RankItem* __restrict__ items,
+                  const unsigned* __restrict__ bm, int64_t wpr, const int32_t* __restrict__ acol, const T* __restrict__ aval,
+                  const int64_t* __restrict__ ext0, const int32_t* __restrict__ blkptr, int nblk1,
+                  const int32_t* __restrict__ bcol, const T* __restrict__ bval, int32_t* __restrict__ ccol,
+                  T* __restrict__ cval)
+{
+    constexpr int CAP = rank_cap<T>();
+    constexpr int WPT = RANK_SPANW / NT;  // bitmap words per thread
+    constexpr int OPT = CAP / NT;         // entries of C per thread
+    constexpr int NW = NT / 64;
+    static_assert(RANK_SPANW % NT == 0 && WPT >= 1 && CAP % NT == 0, "bitmap words and entries must divide over the threads");
+    __shared__ RankRec rec[RANK_SPANW];
+    __shared__ T acc[CAP];
+    __shared__ int32_t qlo[NT];
+    __shared__ int32_t qlen[NT];
+    __shared__ T a_s[NT];
+    __shared__ int inc_s[NT];       // short slices: inclusive prefix of their lengths (flat product list)
+    __shared__ uint16_t lidx[NT];   // long slices, compacted: which slice, and the inclusive prefix of their 64-entry segments
+    __shared__ int lseg[NT];
+    __shared__ int wave_tot[NW];
+    __shared__ int wave_tot3[3][NW];
+    __shared__ int tot3[3];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    int64_t gi;  // XCD-affine runs of consecutive groups (see k_spgemm_part): the groups of a row share block starts and bitmap lines
+    {
+        const int64_t b = group_base + blockIdx.x;
+        const int64_t local = b >> 3, blk = local / RANK_XCD_RUN;
+        gi = RANK_XCD_RUN > 0 ? (blk * 8 + (b & 7)) * RANK_XCD_RUN + (local - blk * RANK_XCD_RUN) : b;
+        if (gi >= n_groups) return;
+    }
+    const RankGroup g = groups[gi];
+    const int64_t a0 = g.a0, a1 = g.a0 + g.na;
+    // the first NT nonzeros of the row: column, extent start (upper triangle: already right of the diagonal), value -- kept
+    const bool has0 = tid < g.na;
+    int32_t k0 = 0, x0 = 0;
+    T av0 = vt<T>::zero();
+    if (has0) {
+        k0 = acol[a0 + tid];
+        x0 = (int32_t)ext0[a0 + tid];
+        av0 = aval[a0 + tid];
+    }
+    // what an item starts with: its bits and, per nonzero of the first chunk, where its blocks start and end inside B's row
+    auto load_bits = [&](const RankItem& it, unsigned (&w)[WPT]) {
+        const int nw = it.nb * RANK_GW;
+        const unsigned* src = bm + (int64_t)it.slot * wpr + (int64_t)it.b0 * RANK_GW + tid * WPT;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) w[i] = 0u;
+        if (tid * WPT < nw) {  // nw is a multiple of RANK_GW = 128 words: a thread's WPT words are all inside or all outside
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) w[i] = src[i];
+        }
+    };
+    auto gather0 = [&](const RankItem& it, int32_t& s, int32_t& e) {
+        s = e = 0;
+        if (has0) {
+            const int32_t* bp = blkptr + (int64_t)k0 * nblk1 + it.b0;
+            s = bp[0];
+            e = bp[it.nb];
+        }
+    };
+    RankItem d = items[g.item0];
+    unsigned w_n[WPT];
+    int32_t s_g, e_g;
+    load_bits(d, w_n);
+    gather0(d, s_g, e_g);
+    for (int jt = 0; jt < g.n; ++jt) {
+        const int32_t c0 = d.b0 * RANK_G;
+        // this item's loads are consumed, the next item's issued
+        unsigned w[WPT];
+        int local = 0;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            w[i] = w_n[i];
+            local += __popc(w[i]);
+        }
+        int32_t s_n = s_g > x0 ? s_g : x0;
+        int32_t e_n = e_g > s_n ? e_g : s_n;
+        T a_n = av0;
+        const RankItem d_next = items[g.item0 + (jt + 1 < g.n ? jt + 1 : jt)];
+        if (jt + 1 < g.n) {
+            load_bits(d_next, w_n);
+            gather0(d_next, s_g, e_g);
+        }
+        // 1. bits -> rank records
+        block_scan_inclusive<NT>(local, inc_s, wave_tot, tid);
+        {
+            int rank = inc_s[tid] - local;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                rec[tid * WPT + i] = RankRec{w[i], (unsigned)rank};
+                rank += __popc(w[i]);
+            }
+        }
+        __syncthreads();
+        // the item's column indices, entry k by thread k mod NT: the word that holds it by bisection over the records (all of a
+        // thread's searches in lockstep), the bit inside the word by halving -- whole lines go out, in increasing order, so the
+        // row of C is SORTED.  (Word by word -- every lane walking the set bits of its own words -- was 26 ms of divergent loops
+        // on the literal configs[2], and its scattered stores another 6.)
+        {
+            int wi[OPT];
+#pragma unroll
+            for (int u = 0; u < OPT; ++u) wi[u] = 0;
+#pragma unroll
+            for (int step = RANK_SPANW / 2; step > 0; step >>= 1) {  // largest wi with rec[wi].before <= k
+                unsigned probe[OPT];
+#pragma unroll
+                for (int u = 0; u < OPT; ++u) probe[u] = rec[wi[u] + step].before;
+#pragma unroll
+                for (int u = 0; u < OPT; ++u)
+                    if ((int)probe[u] <= tid + u * NT) wi[u] += step;
+            }
+            RankRec r[OPT];
+#pragma unroll
+            for (int u = 0; u < OPT; ++u) r[u] = rec[wi[u]];
+#pragma unroll
+            for (int u = 0; u < OPT; ++u) {
+                const int k = tid + u * NT;
+                if (k >= d.count) continue;
+                unsigned x = r[u].bits;
+                int need = k - (int)r[u].before, pos = 0, c;  // the need-th (0-based) set bit of x
+                c = __popc(x & 0xffffu);
+                if (need >= c) { pos = 16; need -= c; }
+                c = __popc((x >> pos) & 0xffu);
+                if (need >= c) { pos += 8; need -= c; }
+                c = __popc((x >> pos) & 0xfu);
+                if (need >= c) { pos += 4; need -= c; }
+                c = __popc((x >> pos) & 0x3u);
+                if (need >= c) { pos += 2; need -= c; }
+                c = (int)((x >> pos) & 1u);
+                if (need >= c) pos += 1;
+                ccol[d.out0 + k] = c0 + wi[u] * 32 + pos;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < OPT; ++u) acc[tid + u * NT] = vt<T>::zero();
+        // 2. the selected rows of B, NT at a time.  A slice of >= RANK_LONG entries is cut into SEGMENTS of 64 and the segments
+        //    are dealt to the waves in contiguous runs: the lanes of a wave sit on consecutive entries of ONE slice; slice, start
+        //    and the value of A are wave-uniform (found once per segment, not once per product) and the loads are whole lines.
+        //    The short slices are walked as one flat list of products (position -> slice by lockstep bisection).
+        for (int64_t base = a0; base < a1; base += NT) {
+            const int len = e_n - s_n;
+            const bool is_long = len >= RANK_LONG;
+            qlo[tid] = s_n;
+            qlen[tid] = len;
+            a_s[tid] = a_n;
+            {  // the next chunk of a row of more than NT nonzeros (rare: hub rows of A): loaded while this one is walked
+                const int64_t p = base + NT + tid;
+                s_n = e_n = 0;
+                if (p < a1) {
+                    const int32_t* bp = blkptr + (int64_t)acol[p] * nblk1 + d.b0;
+                    const int32_t xx = (int32_t)ext0[p];
+                    const int32_t s = bp[0], e = bp[d.nb];
+                    s_n = s > xx ? s : xx;
+                    e_n = e > s_n ? e : s_n;
+                    a_n = aval[p];
+                }
+            }
+            int p_short = is_long ? 0 : len, p_seg = is_long ? (len + 63) >> 6 : 0, p_cnt = is_long ? 1 : 0;
+            block_scan3<NT>(p_short, p_seg, p_cnt, wave_tot3, tid);
+            inc_s[tid] = p_short;
+            if (is_long) {
+                lidx[p_cnt - 1] = (uint16_t)tid;
+                lseg[p_cnt - 1] = p_seg;
+            }
+            if (tid == NT - 1) {
+                tot3[0] = p_short;
+                tot3[1] = p_seg;
+                tot3[2] = p_cnt;
+            }
+            __syncthreads();
+            const int total = tot3[0], tot_seg = tot3[1], n_long = tot3[2];
+            // 2a + 2b in ONE loop: a round computes the addresses of up to RANK_SEG_UNROLL segments (long slices) and U flat positions
+            // (short slices), issues all their loads together and then consumes them -- one memory round trip per round.  (As two
+            // loops, one after the other, a chunk paid two: ~3 us each with two workgroups per CU to hide them behind.)
+            int sg = 0, sg1 = 0, c = 0, c_end = 0, c_base = 0;
+            if (tot_seg > 0) {
+                const int per = (tot_seg + NW - 1) / NW;
+                sg = wave * per;
+                sg1 = sg + per < tot_seg ? sg + per : tot_seg;
+                if (sg < sg1) {
+                    int lo = 0, hi = n_long;  // first long slice whose segments end beyond sg
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (lseg[mid] <= sg) lo = mid + 1; else hi = mid;
+                    }
+                    // everything about a segment but the lane is the SAME in all lanes: kept in scalar registers
+                    c = wave_uniform(lo);
+                    c_end = wave_uniform(lseg[c]);
+                    c_base = wave_uniform(c ? lseg[c - 1] : 0);
+                }
+            }
+            const int* inc = inc_s;
+            for (int g0 = 0; g0 < total || sg < sg1; g0 += NT * U, sg += RANK_SEG_UNROLL) {
+                // addresses: segments
+                int qb[RANK_SEG_UNROLL], nn[RANK_SEG_UNROLL];
+                T sav[RANK_SEG_UNROLL];
+#pragma unroll
+                for (int u = 0; u < RANK_SEG_UNROLL; ++u) {
+                    const int gg = sg + u;
+                    qb[u] = 0;
+                    nn[u] = 0;
+                    sav[u] = vt<T>::zero();
+                    if (gg < sg1) {
+                        while (gg >= c_end) {
+                            c_base = c_end;
+                            ++c;
+                            c_end = wave_uniform(lseg[c]);
+                        }
+                        const int sl = wave_uniform((int)lidx[c]);
+                        const int off = (gg - c_base) << 6;
+                        qb[u] = wave_uniform(qlo[sl]) + off;
+                        nn[u] = wave_uniform(qlen[sl]) - off;
+                        sav[u] = wave_uniform_val(a_s[sl]);
+                    }
+                }
+                // addresses: flat positions
+                const int f0 = g0 + tid;
+                int32_t q[U];
+                T av[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    q[u] = 0;
+                    av[u] = vt<T>::zero();
+                }
+                if (g0 < total) {
+                    int fs[U], ls[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) fs[u] = f0 + u * NT < total ? f0 + u * NT : (f0 < total ? f0 : 0);
+                    flat_find_lockstep<NT, U>(inc, fs, ls);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        q[u] = qlo[ls[u]] + (fs[u] - (ls[u] ? inc[ls[u] - 1] : 0));
+                        av[u] = a_s[ls[u]];
+                    }
+                }
+                // loads, all together
+                int32_t sj[RANK_SEG_UNROLL], j[U];
+                T sv[RANK_SEG_UNROLL], v[U];
+#pragma unroll
+                for (int u = 0; u < RANK_SEG_UNROLL; ++u) {
+                    const int32_t qq = lane < nn[u] ? qb[u] + lane : 0;
+                    sj[u] = bcol[qq];
+                    sv[u] = bval[qq];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    j[u] = bcol[q[u]];
+                    v[u] = bval[q[u]];
+                }
+                // consume
+#pragma unroll
+                for (int u = 0; u < RANK_SEG_UNROLL; ++u) {
+                    if (lane >= nn[u]) continue;
+                    const int rel = sj[u] - c0;
+                    const RankRec r = rec[rel >> 5];
+                    const int rank = (int)r.before + __popc(r.bits & ((1u << (rel & 31)) - 1u));
+                    atomic_accum(&acc[rank], vt<T>::mul(sav[u], sv[u]));
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (f0 + u * NT >= total) continue;
+                    const int rel = j[u] - c0;
+                    const RankRec r = rec[rel >> 5];
+                    const int rank = (int)r.before + __popc(r.bits & ((1u << (rel & 31)) - 1u));
+                    atomic_accum(&acc[rank], vt<T>::mul(av[u], v[u]));
+                }
+            }
+            __syncthreads();
+        }
+        // 3. the values, in column order
+#pragma unroll
+        for (int u = 0; u < OPT; ++u)
+            if (tid + u * NT < d.count) cval[d.out0 + tid + u * NT] = acc[tid + u * NT];
+        d = d_next;
+        __syncthreads();  // rec / acc are rewritten by the next item
+    }
+}
+
 // ---- dense-output variant (spmmd): one wave per row, products scattered with L2 atomics ------------
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -1672,6 +2217,14 @@ struct BigRows {
     DevBuf bounds;             // int32: range starts, P_max = ceil(min(ub, cols) / cap) slots per big row
     DevBuf ext0, extlen;       // per nonzero of A: first counted entry of B's row (int64) and their number (int32) -- k_row_ub
     bool grp = false;          // every row of B has <= 32 entries: the LDS bins up to 512 products run k_spgemm_grp
+    // round 4, accumulate-by-rank path (k_spgemm_rank): the symbolic phase's bitmaps and what the numeric phase needs with them
+    bool have_rank = false;
+    int nblk = 0;              // blocks of RANK_G columns
+    int64_t wpr = 0;           // bitmap words per stored row
+    DevBuf bm_store;           // unsigned[nbig * wpr]
+    DevBuf blkcnt;             // uint16[nbig * nblk]
+    DevBuf slot_of;            // int32[A.rows]: slot of a big row in bm_store / blkcnt
+    DevBuf blkptr;             // int32[B.rows * (nblk + 1)]: where every block starts inside every row of B (k_blkptr)
 };
 
 // `lists`: in -- row lists to use instead of binning `cnt` (the symbolic phase's, when every row sits in an LDS class: a table
@@ -1695,7 +2248,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
     // the numeric one -- when B is narrow enough for a bitmap (and, numeric, its rows are sorted)
     const int first_big = sizeof(T) >= 16 ? 7 : 8;
     const bool use_bitmap = !force_global && options().spgemm_lds_parts &&
-                            (NUMERIC ? big.have_bounds
+                            (NUMERIC ? (big.have_bounds || big.have_rank)
                                      : (bitmap_lds_bytes(B.cols) <= (size_t)140 * 1024 && B.nnz < ((int64_t)1 << 31)));
 #define MI_SPGEMM_ARGS(list)                                                                                       \
     (const int32_t*)list, (const int64_t*)A.ptr, (const int32_t*)A.col, (const T*)A.val, (const int64_t*)B.ptr,   \
@@ -1776,7 +2329,38 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                               (const int32_t*)big_list, cnt, nbig, big.cap, B.cols, items);
                     n_bounds = exclusive_scan_i64(items, item_off, nbig);
                 }
-                if (big.b_sorted && n_bounds < ((int64_t)1 << 31)) {
+                // round 4: keep the bitmaps for k_spgemm_rank when they (and the block starts of B's rows) are affordable
+                bool rank_path = false;
+                if (big.b_sorted && options().spgemm_rank && sizeof(T) <= 8) {
+                    const int nblk = (int)ceil_div(B.cols, (int64_t)RANK_G);
+                    const int64_t wpr = (int64_t)nblk * RANK_GW;
+                    const size_t need = sizeof(unsigned) * (size_t)wpr * (size_t)nbig + sizeof(uint16_t) * (size_t)nblk * (size_t)nbig +
+                                        sizeof(int32_t) * (size_t)(nblk + 1) * (size_t)B.rows + sizeof(int32_t) * (size_t)A.rows;
+                    size_t free_b = 0, total_b = 0;
+                    MI_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+                    if (need < free_b / 3) {
+                        rank_path = true;
+                        big.nblk = nblk;
+                        big.wpr = wpr;
+                        big.bm_store.alloc(sizeof(unsigned) * (size_t)wpr * (size_t)nbig);
+                        big.blkcnt.alloc(sizeof(uint16_t) * (size_t)nblk * (size_t)nbig);
+                        big.slot_of.alloc(sizeof(int32_t) * (size_t)(A.rows + 1));
+                    }
+                }
+                if (rank_path) {
+                    BitmapStore bs;
+                    bs.bm = big.bm_store.as<unsigned>();
+                    bs.wpr = big.wpr;
+                    bs.blkcnt = big.blkcnt.as<uint16_t>();
+                    bs.slot_of = big.slot_of.as<int32_t>();
+                    bs.nblk = big.nblk;
+                    MI_LAUNCH_SMEM((k_spgemm_bitmap<BM_STORE>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
+                                   c.stream, nbig, (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr,
+                                   (const int64_t*)big.ext0.as<int64_t>(), (const int32_t*)big.extlen.as<int32_t>(),
+                                   (const int32_t*)B.col, gw, upper, row_nnz,
+                                   (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, counter, bs);
+                    big.have_rank = true;
+                } else if (big.b_sorted && n_bounds < ((int64_t)1 << 31)) {
                     big.boff_by_row.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
                     big.bounds.alloc(sizeof(int32_t) * (size_t)(n_bounds + 1));
                     MI_LAUNCH_SMEM((k_spgemm_bitmap<true>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
@@ -1784,14 +2368,54 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                                    (const int64_t*)big.ext0.as<int64_t>(), (const int32_t*)big.extlen.as<int32_t>(),
                                    (const int32_t*)B.col, gw, upper, row_nnz,
                                    (const int64_t*)item_off, big.cap, big.bounds.as<int32_t>(),
-                                   big.boff_by_row.as<int64_t>(), counter);
+                                   big.boff_by_row.as<int64_t>(), counter, BitmapStore{});
                     big.have_bounds = true;
                 } else {
                     MI_LAUNCH_SMEM((k_spgemm_bitmap<false>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
                                    c.stream, nbig, (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr,
                                    (const int64_t*)big.ext0.as<int64_t>(), (const int32_t*)big.extlen.as<int32_t>(),
                                    (const int32_t*)B.col, gw, upper, row_nnz,
-                                   (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, counter);
+                                   (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, counter,
+                                   BitmapStore{});
+                }
+            } else if (big.have_rank) {
+                // items (runs of blocks of a row) -> one workgroup each (k_spgemm_rank)
+                constexpr int CAP = rank_cap<T>();
+                if (!big.blkptr.p) {  // where every block starts inside every row of B: B only, built once per symbolic phase
+                    big.blkptr.alloc(sizeof(int32_t) * (size_t)(big.nblk + 1) * (size_t)(B.rows + 1));
+                    if (B.rows > 0)
+                        MI_LAUNCH(k_blkptr, dim3((unsigned)ceil_div(B.rows * WAVE, 256)), dim3(256), c.stream, B.rows,
+                                  (const int64_t*)B.ptr, (const int32_t*)B.col, big.nblk, big.blkptr.as<int32_t>());
+                }
+                const dim3 rgrid((unsigned)ceil_div(nbig, 256));
+                MI_LAUNCH(k_rank_items, rgrid, dim3(256), c.stream, nbig, (const int32_t*)big_list,
+                          (const int32_t*)big.slot_of.as<int32_t>(), (const uint16_t*)big.blkcnt.as<uint16_t>(), big.nblk, CAP, cptr,
+                          (const int64_t*)nullptr, items, (RankItem*)nullptr);
+                const int64_t n_items = exclusive_scan_i64(items, item_off, nbig);
+                if (options().trace_phases)
+                    fprintf(stderr, "[mi_sparse spgemm] big rows %lld, rank items %lld\n", (long long)nbig, (long long)n_items);
+                if (n_items) {
+                    RankItem* ritems = static_cast<RankItem*>(c.scratch_alloc(sizeof(RankItem) * (size_t)n_items));
+                    MI_LAUNCH(k_rank_items, rgrid, dim3(256), c.stream, nbig, (const int32_t*)big_list,
+                              (const int32_t*)big.slot_of.as<int32_t>(), (const uint16_t*)big.blkcnt.as<uint16_t>(), big.nblk, CAP,
+                              cptr, (const int64_t*)item_off, items, ritems);
+                    int64_t* groups_n = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                    int64_t* group_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
+                    MI_LAUNCH(k_rank_groups, rgrid, dim3(256), c.stream, nbig, (const int32_t*)big_list, (const int64_t*)A.ptr,
+                              (const int64_t*)item_off, (const int64_t*)nullptr, groups_n, (RankGroup*)nullptr);
+                    const int64_t n_groups = exclusive_scan_i64(groups_n, group_off, nbig);
+                    RankGroup* rgroups = static_cast<RankGroup*>(c.scratch_alloc(sizeof(RankGroup) * (size_t)(n_groups + 1)));
+                    MI_LAUNCH(k_rank_groups, rgrid, dim3(256), c.stream, nbig, (const int32_t*)big_list, (const int64_t*)A.ptr,
+                              (const int64_t*)item_off, (const int64_t*)group_off, groups_n, rgroups);
+                    const int64_t run8 = RANK_XCD_RUN > 0 ? (int64_t)RANK_XCD_RUN * 8 : 1;
+                    launch_batched(ceil_div(n_groups, run8) * run8, RANK_THREADS, [&](int64_t off, int64_t nblk_) {
+                        MI_LAUNCH((k_spgemm_rank<T, RANK_THREADS, RANK_UNROLL>), dim3((unsigned)nblk_), dim3(RANK_THREADS), c.stream,
+                                  off, n_groups, (const RankGroup*)rgroups, (const RankItem*)ritems,
+                                  (const unsigned*)big.bm_store.as<unsigned>(), big.wpr, (const int32_t*)A.col, (const T*)A.val,
+                                  (const int64_t*)big.ext0.as<int64_t>(), (const int32_t*)big.blkptr.as<int32_t>(), big.nblk + 1,
+                                  (const int32_t*)B.col, (const T*)B.val, ccol, cval);
+                    });
+                    note_kernel("k_spgemm_rank<%s,%d,%d>", type_name<T>(), RANK_THREADS, RANK_UNROLL);
                 }
             } else {
                 const int64_t CAP = big.cap;

@@ -719,6 +719,66 @@ def test_spgemm_hub_rows_lds_bitmap_and_partitioned_classes(gpu, dtype):
         _check_spgemm(got, want, dtype)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
+def test_spgemm_hub_rows_accumulate_by_rank(gpu, dtype):
+    """Option spgemm_rank = 1 (round 4): the symbolic phase keeps the big rows' column bitmaps, the numeric phase adds every
+    product at the RANK of its column (k_spgemm_rank).  Same structure and values as scipy, and the big rows come out SORTED
+    without mi_sparse_order.  Rows of A beyond one chunk of 512 nonzeros, rows of C beyond one item (4096 entries) and beyond
+    one group (16 items), slices of B on both sides of the 64-entry segment threshold; a staged product re-runs the numeric
+    phase on the kept pattern; the upper-triangle form goes through the same kernels (gram)."""
+    rng = np.random.default_rng(15)
+    k, n = 6000, 300000
+    a = sps.random(300, k, density=0.002, format="lil", random_state=11, dtype=np.float64)
+    a[0, rng.choice(k, 700, replace=False)] = 1.5
+    a[7, rng.choice(k, 90, replace=False)] = -0.5
+    a[13, rng.choice(k, 2500, replace=False)] = 0.25
+    a[299, rng.choice(k, 1500, replace=False)] = 0.75
+    a = a.tocsr().astype(dtype)
+    b = sps.random(k, n, density=60 / n, format="lil", random_state=12, dtype=np.float64)
+    for r in rng.choice(k, 40, replace=False):  # long rows of B: slices of hundreds of entries per item
+        b[r, rng.choice(n, 20000, replace=False)] = 0.5
+    b = b.tocsr().astype(dtype)
+    b.sort_indices()
+    if np.dtype(dtype).kind == "c":
+        a.data = a.data + 1j * a.data[::-1]
+        b.data = b.data * (1 - 0.5j)
+    want = (a.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64) @ b).tocsr()
+    want.sort_indices()
+    assert np.diff(want.indptr).max() > 16 * 4096
+    gpu.mi_set_option("spgemm_rank", 1)
+    try:
+        got = gpu.dot_product_mkl(a, b)
+        big = np.nonzero(np.diff(got.indptr) > 8192)[0]
+        assert big.size >= 3
+        if np.dtype(dtype) != np.complex128:  # complex double stays on the hash path (accumulators of a block do not fit)
+            for r in big:
+                assert np.all(np.diff(got.indices[got.indptr[r]:got.indptr[r + 1]]) > 0), "big rows come out sorted"
+        _check_spgemm(got, want, dtype)
+        got = gpu.dot_product_mkl(a, b, reorder_output=True)
+        assert np.array_equal(got.indices, want.indices)
+    finally:
+        gpu.mi_set_option("spgemm_rank", 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gram_sparse_hub_rows_accumulate_by_rank(gpu, dtype):
+    """Upper triangle of A^T A with hub rows through k_spgemm_rank (extents cut at the diagonal)."""
+    rng = np.random.default_rng(16)
+    a = sps.random(3000, 30000, density=20 / 30000, format="lil", random_state=13, dtype=np.float64)
+    a[rng.choice(3000, 800, replace=False), 5] = 1.0
+    a[rng.choice(3000, 1500, replace=False), 29000] = 2.0
+    a[rng.choice(3000, 1200, replace=False), 14000] = 0.5
+    a = a.tocsr().astype(dtype)
+    want = sps.triu((a.T.astype(np.float64) @ a.astype(np.float64))).tocsr()
+    want.sort_indices()
+    gpu.mi_set_option("spgemm_rank", 1)
+    try:
+        got = gpu.gram_matrix_mkl(a)
+    finally:
+        gpu.mi_set_option("spgemm_rank", 0)
+    _check_spgemm(got, want, dtype)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_gram_sparse_hub_rows(gpu, dtype):
     """A^T A (upper triangle, mkl_sparse_syrk semantics) with hub rows in the product."""
