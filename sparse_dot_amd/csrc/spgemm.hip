@@ -1019,6 +1019,8 @@ __global__ void __launch_bounds__(1024)
     const int tid = threadIdx.x, threads = 1024;  // launched with 1024 threads
     const int64_t words = (ncols + 31) / 32;
     const int64_t padded = BITMAP_IDX(words) + 1;
+    // cap need not be a power of two (5/8 of the range kernel's table): n / cap as a multiplication, exact for n < 2^21 <= 2^40 / cap / 2^7
+    const unsigned long long cap_magic = MODE == BM_BOUNDS ? (((1ull << 40) + (unsigned long long)cap - 1) / (unsigned long long)cap) : 0ull;
     for (;;) {
         __syncthreads();
         if (tid == 0) {
@@ -1113,7 +1115,6 @@ __global__ void __launch_bounds__(1024)
             }
         } else {
             // rank of every set bit -> the column where each range of `cap` distinct columns starts
-            const int cap_log2 = 63 - __builtin_clzll((unsigned long long)cap);
             const int64_t per = (words + threads - 1) / threads;
             const int64_t w0 = (int64_t)tid * per, w1 = w0 + per < words ? w0 + per : words;
             int local = 0;
@@ -1131,7 +1132,7 @@ __global__ void __launch_bounds__(1024)
                 const int c = __popc(w);
                 if (c) {
                     // boundaries b*cap (b >= 1) with rank <= b*cap < rank + c
-                    int64_t b = (rank + cap - 1) >> cap_log2;  // cap is a power of two
+                    int64_t b = (int64_t)(((unsigned long long)(rank + cap - 1) * cap_magic) >> 40);  // ceil(rank / cap), exact for rank < 2^21
                     if (b == 0) b = 1;
                     int taken = 0;  // set bits of the word already skipped
                     for (; b * cap < rank + c; ++b) {
@@ -2633,7 +2634,10 @@ static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C
     big.log2s = (sizeof(T) >= 16 ? 10 : 11) + (B.cols <= 65536 ? 1 : 0) + (int)options().spgemm_part_log2s_bias;
     if (big.log2s < (sizeof(T) >= 16 ? 10 : 11)) big.log2s = sizeof(T) >= 16 ? 10 : 11;
     if (big.log2s > (sizeof(T) >= 16 ? 11 : 12)) big.log2s = sizeof(T) >= 16 ? 11 : 12;
-    big.cap = ((int64_t)1 << big.log2s) / 2;
+#ifndef MI_PART_FILL_8THS
+#define MI_PART_FILL_8THS 5
+#endif
+    big.cap = ((int64_t)1 << big.log2s) * MI_PART_FILL_8THS / 8;  // distinct columns per range: the fill of the range kernel's table
     C.rows = A.rows;
     C.cols = B.cols;
     C.ptr_own.alloc(sizeof(int64_t) * (size_t)(C.rows + 1));
