@@ -451,7 +451,7 @@ struct Csr {
     void* val = nullptr;     // nnz
     DevBuf ptr_own, col_own, val_own;  // storage when the library owns it (else aliases caller HBM)
     bool valid = false;
-    bool sorted = false;  // column indices known to be ascending inside every row
+    mutable bool sorted = false;  // column indices known to be ascending inside every row (rows_sorted records a positive answer: the structure of a handle never changes)
     // generation of the ENTRY ORDER inside the rows: a fresh value (next_order_gen) whenever the entries are (re)laid out --
     // built, transposed into, re-sorted.  Anything that indexes per-entry tables by position (the staged product's B-row
     // extents, spgemm.hip) records it and checks it again before trusting those tables.

@@ -402,6 +402,7 @@ bool rows_sorted(const Csr& a)
     int hflag = 0;
     MI_HIP_CHECK(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+    if (!hflag) a.sorted = true;  // asked again by every product this matrix takes part in: 0.13 ms + a synchronisation per call at 2^20 rows
     return !hflag;
 }
 
