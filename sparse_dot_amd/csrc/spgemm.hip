@@ -958,7 +958,7 @@ __global__ void __launch_bounds__(256)
 #define MI_PART_UNROLL 2
 #endif
 #ifndef MI_BITMAP_UNROLL
-#define MI_BITMAP_UNROLL 8
+#define MI_BITMAP_UNROLL 16
 #endif
 #ifndef MI_PART_THREADS
 #define MI_PART_THREADS 512
@@ -1167,9 +1167,12 @@ __global__ void k_part_items(const int32_t* __restrict__ row_list, const int64_t
 // own B row -- a bisection plus galloping per thread, 5+ private cache lines each: 54 ms and ~200 GB of fetches
 // for the literal configs[2]; inside k_spgemm_part the same searches are dependent loads in a
 // workgroup-synchronous phase, which is slower still.)
-constexpr int SLICE_EB = 32;  // nonzeros of A per wave
+#ifndef MI_SLICE_EB
+#define MI_SLICE_EB 16
+#endif
+constexpr int SLICE_EB = MI_SLICE_EB;  // nonzeros of A per wave
 #ifndef MI_SLICE_ILP
-#define MI_SLICE_ILP 4
+#define MI_SLICE_ILP 2
 #endif
 constexpr int SLICE_ILP = MI_SLICE_ILP;  // bisections in flight per lane
 
@@ -1193,7 +1196,7 @@ __global__ void __launch_bounds__(256)
                   const int64_t* __restrict__ boff_by_row, const int64_t* __restrict__ aptr,
                   const int32_t* __restrict__ acol, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, int upper, const int64_t* __restrict__ slice_base,
-                  int32_t* __restrict__ bnd)
+                  int32_t* __restrict__ bnd, const int32_t* __restrict__ work_t)
 {
     __shared__ int32_t tile_all[4][64][SLICE_EB + 1];  // [wave][range lane][nonzero]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1201,13 +1204,9 @@ __global__ void __launch_bounds__(256)
     const int64_t total = work_off[nb];
     const int64_t g = (block_base + blockIdx.x) * 4 + wave;  // wave index = work item
     if (g >= total) return;  // whole wave
-    // row of this work item: largest t with work_off[t] <= g (same search in every lane: broadcast loads)
-    int64_t lo = 0, hi = nb;
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (work_off[mid] <= g) lo = mid; else hi = mid;
-    }
-    const int64_t t = lo;
+    // row of this work item: precomputed (k_part_item_map) -- found here by a 19-step search over work_off it was ~10 us of
+    // dependent loads at the start of every one of millions of waves (the same fix k_spgemm_part got in round 2)
+    const int64_t t = work_t[g];
     const int32_t row = row_list[t];
     const int64_t a0 = aptr[row], na = aptr[row + 1] - a0;
     const int64_t P = item_off[t + 1] - item_off[t];
@@ -2441,11 +2440,17 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                 int32_t* bnd = nullptr;
                 if (pre) {
                     bnd = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(total_slices + 1)));
+                    int32_t* work_t = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(total_work + 1)));
+                    if (total_work) {
+                        const int64_t wb = ceil_div(total_work, 256);
+                        MI_LAUNCH(k_part_item_map, dim3((unsigned)(wb < (1 << 20) ? wb : (1 << 20))), dim3(256), c.stream, total_work,
+                                  nbig, (const int64_t*)work_off, work_t);
+                    }
                     launch_batched(ceil_div(total_work, 4), 256, [&](int64_t off, int64_t nblk) {  // total_work = waves
                         MI_LAUNCH(k_part_slices, dim3((unsigned)nblk), dim3(256), c.stream, off, (const int32_t*)big_list, nbig,
                                   (const int64_t*)work_off, (const int64_t*)item_off, bounds, brow, (const int64_t*)A.ptr,
                                   (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, upper,
-                                  (const int64_t*)slice_base, bnd);
+                                  (const int64_t*)slice_base, bnd, (const int32_t*)work_t);
                     });
                 }
                 // work items of the numeric kernel: groups of PART_GROUP consecutive ranges of a row
