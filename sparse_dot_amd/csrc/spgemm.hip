@@ -539,17 +539,12 @@ __global__ void __launch_bounds__(WAVES * 64)
     int64_t* qlo = qlo_all[wave];
     T* a_s = a_all[wave];
     int* inc = inc_all[wave];
-#ifdef MI_ONEPASS_PERSIST  // experiment: co-resident persistent workgroups, sub-block = iteration * grid + workgroup (no ticket)
-    const int64_t nblk_all = (rows + WAVES - 1) / WAVES;
-    for (int64_t blk = blockIdx.x; blk < nblk_all; blk += gridDim.x) {
-#elif defined(MI_ONEPASS_BLOCKIDX)  // experiment: dispatch order instead of a ticket
+#ifdef MI_ONEPASS_BLOCKIDX  // experiment: dispatch order instead of a ticket
     const int64_t blk = blockIdx.x;
-    {
 #else
     if (tid == 0) ticket_s = (long long)atomicAdd(ticket_counter, 1ull);
     __syncthreads();
     const int64_t blk = ticket_s;
-    {
 #endif
     const int64_t row = blk * WAVES + wave;
     int nnz_row = 0, log2e = 6;
@@ -698,10 +693,6 @@ __global__ void __launch_bounds__(WAVES * 64)
             written += cnt;
         }
         if (lane == 0) cptr[row + 1] = out0 + nnz_row;
-    }
-#ifdef MI_ONEPASS_PERSIST
-    __syncthreads();  // row_n / block_excl are rewritten by the next sub-block
-#endif
     }
 }
 
@@ -2738,7 +2729,8 @@ static bool spgemm_onepass(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     if (!options().spgemm_onepass || options().spgemm_force_global) return false;
     // every workgroup draws its ticket from ONE counter (~12 ns each at the memory side) and rows retire in order: measured
     // faster than two phases up to ~10^5 rows (fewer launches and host round trips: 2^14 x 2^14, 16 / row: 0.30 -> 0.17 ms)
-    // and slower beyond (2^20 rows: 4.0 -> 4.6 ms); option value 2 forces it
+    // and slower beyond (2^20 rows: 2.9 -> 4.6 ms; 3.4 ms without any look-back, 4.1-4.5 ms with block indices / persistent
+    // workgroups instead of tickets: profiles/r04_spgemm_onepass_variants.log); option value 2 forces it
     if (options().spgemm_onepass == 1 && A.rows > 65536) return false;
     if (A.rows < 1 || bd.max_ub > 512 || bd.sum_ub < 1) return false;
     const size_t per = sizeof(int32_t) + sizeof(T);
@@ -2762,14 +2754,7 @@ static bool spgemm_onepass(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     auto launch = [&](auto log2s_tag) {
         constexpr int L = decltype(log2s_tag)::value;
         constexpr int WAVES = onepass_waves(L, sizeof(T));
-#ifdef MI_ONEPASS_PERSIST
-        int per_cu = 0;
-        MI_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_spgemm_onepass<T, L, WAVES>, WAVES * 64, 0));
-        const int64_t grid_blocks = std::min<int64_t>(nblocks, (int64_t)std::max(per_cu, 1) * c.cus);
-#else
-        const int64_t grid_blocks = nblocks;
-#endif
-        launch_batched(grid_blocks, WAVES * 64, [&](int64_t, int64_t nb) {  // tickets, not block indices, pick the rows
+        launch_batched(nblocks, WAVES * 64, [&](int64_t, int64_t nb) {  // tickets, not block indices, pick the rows
             MI_LAUNCH((k_spgemm_onepass<T, L, WAVES>), dim3((unsigned)nb), dim3(WAVES * 64), c.stream, A.rows,
                       (const int64_t*)A.ptr, (const int64_t*)bd.ub, (const int64_t*)st.big.ext0.as<int64_t>(),
                       (const int32_t*)st.big.extlen.as<int32_t>(), (const T*)A.val, (const int32_t*)B.col, (const T*)B.val,
