@@ -1280,7 +1280,9 @@ __global__ void __launch_bounds__(256)
     const int wl = lane % SLICE_EB, wp = lane / SLICE_EB;  // 2 ranges x 32 nonzeros per step
     for (int po = 0; po < np; po += 64 / SLICE_EB) {
         const int pp = po + wp;
-        if (pp < np && wl < ne) out[(p0 + pp) * na + wl] = tile[pp][wl];
+        // non-temporal: the table is read back by k_spgemm_part long after it has left every cache; plain stores displaced the
+        // lines of B the bisections re-use (round 4, with the stores of k_spgemm_part: literal configs[2] 158.8 -> 152.5 ms)
+        if (pp < np && wl < ne) __builtin_nontemporal_store(tile[pp][wl], &out[(p0 + pp) * na + wl]);
     }
 }
 
@@ -1484,8 +1486,11 @@ __global__ void __launch_bounds__(PART_THREADS)
             const int32_t key = keys[k];
             if (key != HASH_EMPTY) {
                 const int pos = atomicAdd(&n_out, 1);
-                ccol[out0 + pos] = key;
-                cval[out0 + pos] = vals[k];
+                // non-temporal: 117 GB of C on the literal configs[2], written once -- as plain stores they evict the slices of
+                // B that neighbouring ranges share (profiles/r04_spgemm_nt_stores_ab.log: 158.2 -> 153.5 ms)
+                __builtin_nontemporal_store(key, &ccol[out0 + pos]);
+                if constexpr (!vt<T>::is_complex) __builtin_nontemporal_store(vals[k], &cval[out0 + pos]);
+                else cval[out0 + pos] = vals[k];
                 keys[k] = HASH_EMPTY;
                 vals[k] = vt<T>::zero();
             }
