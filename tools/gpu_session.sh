@@ -4,7 +4,8 @@
 #   tests[:<pytest -k expression>]   pytest -m gpu (the whole suite, or the selected tests) with durations
 #   bench                            python bench.py --steps 20 --warmup 5   (what the driver runs; secondaries + live counter traffic)
 #   stats                            rocprofv3 --kernel-trace --stats of bench.py (headline only / secondaries only)
-#   pmc-spmm | pmc-gram              separate rocprofv3 --pmc passes for the headline SpMM kernel / the dense gram kernel (tools/pmc_kernels.py)
+#   pmc-spmm | pmc-gram | pmc-spgemm separate rocprofv3 --pmc passes for the headline SpMM kernel / the dense gram kernel / every SpGEMM kernel of the
+#                                    literal and the uniform configs[2] (tools/pmc_kernels.py)
 #   probes                           tools/probes: spmm_gather_probe (+ counters for H = 16384), lds_atomic_probe, host_register_probe
 #   phases                           SpGEMM phase trace (uniform + literal) and kernel stats of the uniform call
 #   api                              host-array call breakdown, stager on / off
@@ -41,6 +42,8 @@ PY
       cp $(find $O/st2 -name "*kernel_stats.csv" | head -1) $O/secondary_kernel_stats.csv; rm -rf $O/st2; head -8 $O/secondary_kernel_stats.csv | cut -c1-160 ;;
     pmc-spmm) pmc pmc_spmm python $R/tools/spmm_sweep.py --launches 5 --variants 0:8192:256 --adopt-tags ;;
     pmc-gram) pmc pmc_gram python $R/tools/bench_ops.py gram --dense --cols 262144 --rows-log2 22 --reps 1 ;;
+    pmc-spgemm) pmc pmc_spgemm_literal python $R/tools/bench_ops.py spgemm --kind rmat --scale 20 --per-row 16 --no-order --reps 1
+                pmc pmc_spgemm_uniform python $R/tools/bench_ops.py spgemm --no-order --reps 2 ;;
     probes)
       tools/probes/spmm_gather_probe > $O/spmm_gather_probe.log 2>&1; tail -3 $O/spmm_gather_probe.log
       ( cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $O/gp -o p -- $R/tools/probes/spmm_gather_probe H=16384 > $O/spmm_gather_probe_pmc.log 2>&1 )
