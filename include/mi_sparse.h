@@ -484,6 +484,8 @@ const char *mi_sparse_last_error(void);
  *                   out sorted, 0 (default): range-partitioned LDS hash)                              (SpGEMM big-row paths)
  *   spgemm_onepass (1: a product whose rows all have <= 512 products runs as ONE kernel -- no symbolic pass, the rows of the
  *                   result are placed by a decoupled look-back; 0: always symbolic + numeric)
+ *   spgemm_narrow_ptr (1: the upper-bound pass gathers B's row extents from an int32 copy of its row pointer made per call when
+ *                   nnz(B) < 2^31; 0: from the int64 pointer)
  *   gram_sliced (1: slice-table walk when the slices are short, 2: whenever the rows are sorted, 0: never),
  *   gram_heads (1: slice bounds travel with the entries of X^T when rows have <= 255 entries; 0: per-row table),
  *   gram_tile_kb (0: 152 KiB tiles where they save a tile per output row, else 128; 64 / 128 / 152 force), gram_persistent (-1 auto, 0: one workgroup per tile, k: k workgroups per LDS slot),

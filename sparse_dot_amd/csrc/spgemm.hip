@@ -42,31 +42,86 @@ __device__ __forceinline__ int64_t lower_bound_col(const int32_t* __restrict__ c
 // triangle already cut off -- is WRITTEN OUT here (ext0 / extlen, 12 bytes per nonzero of A, streamed) and read back by the
 // symbolic and numeric kernels.  bptr[k] for a random k is a 128-byte line fill for 16 useful bytes, and it was gathered
 // three times (here, symbolic, numeric): with 16-entry rows of B that was one line in 2.5 (symbolic) / 4.5 (numeric).
+// Round 4: BP = int32_t reads a narrowed copy of B's row pointer (k_narrow_ptr, scratch of the call).  The gather of bptr[k] is a
+// 128-byte line per nonzero of A wherever it misses, and the 8 MB pointer of a 2^20-row B is twice an XCD's L2: on the uniform
+// configs[2] the kernel fetched 1.5 GB for 67 MB of column indices (L2 hit 0.42, profiles/r04_pmc_spgemm_uniform_kernels.jsonl).
+__global__ void k_narrow_ptr(const int64_t* __restrict__ src, int64_t n, int32_t* __restrict__ dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (int32_t)src[i];
+}
+
+constexpr int ROWUB_LPR_LOG2 = 4;    // lanes per row of A
+constexpr int ROWUB_LONG = 512;      // rows of A with more nonzeros go to k_row_ub_long (a workgroup each)
+
+__device__ __forceinline__ void row_ub_one(int64_t p, int32_t row, const int32_t* __restrict__ acol, int64_t b0, int64_t b1,
+                                           const int32_t* __restrict__ bcol, int upper, int64_t& s, int64_t* __restrict__ ext0,
+                                           int32_t* __restrict__ extlen)
+{
+    if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, row);
+    s += b1 - b0;
+    ext0[p] = b0;
+    extlen[p] = (int32_t)(b1 - b0);
+}
+
+// 16 lanes per row; rows with more than ROWUB_LONG nonzeros are only LISTED here.  Round 4: with 8 lanes per row and one
+// dependent acol -> bptr chain per step the hub rows of A set the kernel's duration -- 0.96 ms on R-MAT 2^18 and 3.0 ms on the
+// literal configs[2] for 17 M nonzeros, against 0.18 ms for the uniform matrix of the same size.
+template <typename BP>
 __global__ void __launch_bounds__(256)
     k_row_ub(int64_t rows, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
-             const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub,
-             int64_t* __restrict__ ext0, int32_t* __restrict__ extlen)
+             const BP* __restrict__ bptr, const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub,
+             int64_t* __restrict__ ext0, int32_t* __restrict__ extlen, int32_t* __restrict__ long_list,
+             unsigned* __restrict__ long_count)
 {
-    // 8 lanes per row
+    constexpr int LPR = 1 << ROWUB_LPR_LOG2;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = t >> 3;
-    const int sub = (int)(t & 7);
+    const int64_t row = t >> ROWUB_LPR_LOG2;
+    const int sub = (int)(t & (LPR - 1));
     int64_t s = 0;
+    bool is_long = false;
     if (row < rows) {
-        for (int64_t p = aptr[row] + sub; p < aptr[row + 1]; p += 8) {
-            const int32_t k = acol[p];
-            int64_t b0 = bptr[k];
-            const int64_t b1 = bptr[k + 1];
-            if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, (int32_t)row);
-            s += b1 - b0;
-            ext0[p] = b0;
-            extlen[p] = (int32_t)(b1 - b0);
+        const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+        is_long = a1 - a0 > ROWUB_LONG;
+        if (is_long) {
+            if (sub == 0) long_list[atomicAdd(long_count, 1u)] = (int32_t)row;
+        } else {
+            for (int64_t p = a0 + sub; p < a1; p += LPR) {
+                const int32_t k = acol[p];
+                row_ub_one(p, (int32_t)row, acol, (int64_t)bptr[k], (int64_t)bptr[k + 1], bcol, upper, s, ext0, extlen);
+            }
         }
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
-    if (row < rows && sub == 0) ub[row] = s;
+#pragma unroll
+    for (int d = 1; d < LPR; d <<= 1) s += __shfl_xor(s, d);
+    if (row < rows && sub == 0 && !is_long) ub[row] = s;
+}
+
+// the listed rows: one workgroup per row, every thread one nonzero per step (no lane waits on a chain longer than
+// nnz(row) / 256 steps); the grid is fixed, the number of rows is read on the device
+template <typename BP>
+__global__ void __launch_bounds__(256)
+    k_row_ub_long(const int32_t* __restrict__ long_list, const unsigned* __restrict__ long_count,
+                  const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol, const BP* __restrict__ bptr,
+                  const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub, int64_t* __restrict__ ext0,
+                  int32_t* __restrict__ extlen)
+{
+    __shared__ long long wave_s[4];
+    const unsigned n = *long_count;
+    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+        const int32_t row = long_list[i];
+        const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+        int64_t s = 0;
+        for (int64_t p = a0 + threadIdx.x; p < a1; p += 256) {
+            const int32_t k = acol[p];
+            row_ub_one(p, row, acol, (int64_t)bptr[k], (int64_t)bptr[k + 1], bcol, upper, s, ext0, extlen);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) s += __shfl_xor(s, d);
+        __syncthreads();  // the previous row's totals have been read
+        if ((threadIdx.x & 63) == 0) wave_s[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) ub[row] = wave_s[0] + wave_s[1] + wave_s[2] + wave_s[3];
+    }
 }
 
 // ---- binning -------------------------------------------------------------------------------------
@@ -2625,6 +2680,35 @@ static void trace_mark(const char* what, std::chrono::steady_clock::time_point& 
     t_last = now;
 }
 
+// k_row_ub + k_row_ub_long on the context's stream.  B's row extents are gathered from an int32 copy of its row pointer made
+// here (scratch of the call) when nnz(B) < 2^31: half the table, twice the pointers per 128-byte line.
+static void launch_row_ub(const Csr& A, const Csr& B, int upper_mode, int64_t* ub, int64_t* ext0, int32_t* extlen)
+{
+    Context& c = ctx();
+    if (A.rows <= 0) return;
+    const size_t max_long = (size_t)(A.nnz / ROWUB_LONG + 1);
+    int32_t* long_list = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (max_long + 1)));
+    unsigned* long_count = reinterpret_cast<unsigned*>(long_list + max_long);
+    MI_HIP_CHECK(hipMemsetAsync(long_count, 0, sizeof(unsigned), c.stream));
+    const dim3 grid((unsigned)ceil_div(A.rows << ROWUB_LPR_LOG2, 256));
+    const unsigned long_grid = (unsigned)std::min<size_t>(max_long, (size_t)8 * (size_t)std::max(c.cus, 1));
+    auto run = [&](auto* bptr) {
+        using BP = std::remove_cv_t<std::remove_pointer_t<decltype(bptr)>>;
+        MI_LAUNCH(k_row_ub<BP>, grid, dim3(256), c.stream, A.rows, (const int64_t*)A.ptr, (const int32_t*)A.col, (const BP*)bptr,
+                  (const int32_t*)B.col, upper_mode, ub, ext0, extlen, long_list, long_count);
+        MI_LAUNCH(k_row_ub_long<BP>, dim3(long_grid), dim3(256), c.stream, (const int32_t*)long_list, (const unsigned*)long_count,
+                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const BP*)bptr, (const int32_t*)B.col, upper_mode, ub, ext0, extlen);
+    };
+    if (options().spgemm_narrow_ptr && B.nnz < ((int64_t)1 << 31) - 1 && A.nnz >= ((int64_t)1 << 18) && B.rows >= ((int64_t)1 << 16)) {
+        int32_t* bptr32 = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(B.rows + 1)));
+        MI_LAUNCH(k_narrow_ptr, dim3((unsigned)std::min<int64_t>(ceil_div(B.rows + 1, 256), 4096)), dim3(256), c.stream,
+                  (const int64_t*)B.ptr, B.rows + 1, bptr32);
+        run((const int32_t*)bptr32);
+    } else {
+        run((const int64_t*)B.ptr);
+    }
+}
+
 template <typename T>
 static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st)
 {
@@ -2660,10 +2744,7 @@ static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C
         if (B.gram_max_row < 0) B.gram_max_row = device_max_row_len(B);
         big.grp = B.gram_max_row <= 32;
     }
-    if (A.rows > 0)
-        MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows,
-                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, bd.ub,
-                  big.ext0.as<int64_t>(), big.extlen.as<int32_t>());
+    launch_row_ub(A, B, st.upper_mode, bd.ub, big.ext0.as<int64_t>(), big.extlen.as<int32_t>());
     st.a_gen = A.order_gen;
     st.b_gen = B.order_gen;
     st.a_nnz = A.nnz;
@@ -2811,10 +2892,7 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
         // order (and, upper triangle of a sorted B, B's) -- one streamed pass rebuilds them.  A B that was unsorted at the
         // symbolic phase keeps mode 1 (every product tested), which is valid for any order.
         int64_t* ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
-        if (A.rows > 0)
-            MI_LAUNCH(k_row_ub, dim3((unsigned)ceil_div(A.rows * 8, 256)), dim3(256), c.stream, A.rows, (const int64_t*)A.ptr,
-                      (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, st.upper_mode, ub,
-                      st.big.ext0.as<int64_t>(), st.big.extlen.as<int32_t>());
+        launch_row_ub(A, B, st.upper_mode, ub, st.big.ext0.as<int64_t>(), st.big.extlen.as<int32_t>());
         st.a_gen = A.order_gen;
         st.b_gen = B.order_gen;
     }

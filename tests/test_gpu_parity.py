@@ -734,10 +734,16 @@ def test_spgemm_hub_rows_accumulate_by_rank(gpu, dtype):
     a[13, rng.choice(k, 2500, replace=False)] = 0.25
     a[299, rng.choice(k, 1500, replace=False)] = 0.75
     a = a.tocsr().astype(dtype)
-    b = sps.random(k, n, density=60 / n, format="lil", random_state=12, dtype=np.float64)
-    for r in rng.choice(k, 40, replace=False):  # long rows of B: slices of hundreds of entries per item
-        b[r, rng.choice(n, 20000, replace=False)] = 0.5
-    b = b.tocsr().astype(dtype)
+    # ~60 entries per row drawn directly (scipy's sps.random samples k * n = 1.8e9 positions without replacement: minutes)
+    rb = np.random.default_rng(12)
+    bi, bj = np.repeat(np.arange(k), 60), rb.integers(0, n, 60 * k)
+    bv = rb.uniform(0.1, 1.0, 60 * k)
+    long_rows = rng.choice(k, 40, replace=False)  # long rows of B: slices of hundreds of entries per item
+    keep = ~np.isin(bi, long_rows)
+    li = np.repeat(long_rows, 20000)
+    lj = np.concatenate([rng.choice(n, 20000, replace=False) for _ in long_rows])
+    b = sps.coo_matrix((np.concatenate([bv[keep], np.full(li.size, 0.5)]), (np.concatenate([bi[keep], li]), np.concatenate([bj[keep], lj]))),
+                       shape=(k, n)).tocsr().astype(dtype)  # duplicates of the random part are summed
     b.sort_indices()
     if np.dtype(dtype).kind == "c":
         a.data = a.data + 1j * a.data[::-1]
