@@ -733,7 +733,11 @@ def test_spgemm_hub_rows_accumulate_by_rank(gpu, dtype):
     a[7, rng.choice(k, 90, replace=False)] = -0.5
     a[13, rng.choice(k, 2500, replace=False)] = 0.25
     a[299, rng.choice(k, 1500, replace=False)] = 0.75
-    a = a.tocsr().astype(dtype)
+    a = a.tocsr()
+    seg = a.data[a.indptr[7]:a.indptr[8]]
+    seg[seg > 0] = 0  # row 7 is negative throughout, every other row positive: no sum of a row of C cancels
+    a.eliminate_zeros()
+    a = a.astype(dtype)
     # ~60 entries per row drawn directly (scipy's sps.random samples k * n = 1.8e9 positions without replacement: minutes)
     rb = np.random.default_rng(12)
     bi, bj = np.repeat(np.arange(k), 60), rb.integers(0, n, 60 * k)
