@@ -614,6 +614,41 @@ def _check_spgemm(got, want, dtype):
     assert rel_err(g.data, want.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64).data) <= tol(dtype)
 
 
+@pytest.mark.parametrize("upper", [False, True])
+def test_spgemm_upper_bound_pass_long_rows_and_narrow_pointer(gpu, upper):
+    """Phase 0 (k_row_ub / k_row_ub_long / k_narrow_ptr, round 4): rows of A on both sides of the 512-nonzero limit of the
+    16-lane kernel (512, 513, 600, 5000: the longer ones are taken by a workgroup each), operands large enough for the int32
+    copy of B's row pointer (>= 2^18 nonzeros of A, >= 2^16 rows of B), the option on and off; product and upper triangle
+    of a gram matrix (extents cut at the diagonal by a search inside both kernels)."""
+    rng = np.random.default_rng(81)
+    n = 70000
+    def uniform(rows, cols, per_row, seed):
+        r = np.random.default_rng(seed)
+        m = sps.coo_matrix((r.uniform(0.5, 1.5, rows * per_row), (np.repeat(np.arange(rows), per_row), r.integers(0, cols, rows * per_row))),
+                           shape=(rows, cols)).tocsr()
+        m.sort_indices()
+        return m
+    a = uniform(n, n, 4, 82).tolil()
+    for row, cnt in ((3, 512), (4, 513), (1000, 600), (69999, 5000)):
+        a[row, :] = 0
+        a[row, rng.choice(n, cnt, replace=False)] = 0.75
+    for col, cnt in ((7, 513), (9, 700)):  # long rows of A^T (the gram's left operand)
+        a[rng.choice(np.arange(10, n - 10), cnt, replace=False), col] = 0.5
+    a = a.tocsr()
+    a.eliminate_zeros()
+    assert a.nnz >= 1 << 18 and sorted(np.diff(a.indptr))[-4:] == [512, 513, 600, 5000] and (np.diff(a.tocsc().indptr) > 512).sum() == 2
+    b = a if upper else uniform(n, n, 4, 83)
+    want = (sps.triu(a.T @ a) if upper else a @ b).tocsr()
+    want.sort_indices()
+    for narrow in (1, 0):
+        gpu.mi_set_option("spgemm_narrow_ptr", narrow)
+        try:
+            got = gpu.gram_matrix_mkl(a) if upper else gpu.dot_product_mkl(a, b)
+        finally:
+            gpu.mi_set_option("spgemm_narrow_ptr", 1)
+        _check_spgemm(got, want, np.float64)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
 def test_spgemm_all_bins(gpu, oracle, dtype):
     """Rows whose product count falls in every LDS bin (<=32, <=256, <=2048) and beyond (global hash)."""
