@@ -1205,7 +1205,7 @@ def main():
                          "spgemm_rmat_literal": (["spgemm", "--kind", "rmat", "--scale", "20", "--per-row", "16", "--no-order", "--reps", "1"], 2),
                          "gram_dense": (["gram", "--dense", "--cols", "262144", "--rows-log2", "22", "--reps", "1"], 2)}[key]
                 inc = ("k_syrkd",) if key == "gram_dense" else ("mi::",)
-                exc = ("k_spmv", "k_spmm", "k_check_", "k_widen_ptr", "k_rows_unsorted")
+                exc = ("k_spmv", "k_spmm", "k_check_", "k_widen_ptr", "k_count_descents", "k_count_start_descents")
                 need = {"spgemm_uniform": 16 << 30, "spgemm_rmat_literal": 150 << 30, "gram_dense": 272 << 30}[key]
                 attach_traffic(secondary[key], child[0], child[1], inc, not args.no_pmc, exclude=exc, need_free_bytes=need)
         line["secondary"] = secondary
