@@ -484,6 +484,8 @@ const char *mi_sparse_last_error(void);
  *                   out sorted, 0 (default): range-partitioned LDS hash)                              (SpGEMM big-row paths)
  *   spgemm_onepass (1: a product whose rows all have <= 512 products runs as ONE kernel -- no symbolic pass, the rows of the
  *                   result are placed by a decoupled look-back; 0: always symbolic + numeric)
+ *   transpose_lds_hist (1: the column histogram of a device transpose -- CSC operands, gram matrices -- runs through LDS ranges of
+ *                   32768 counters when the matrix has >= 2^22 entries and <= 2^20 columns; 0: one global atomic per entry)
  *   spgemm_narrow_ptr (1: the upper-bound pass gathers B's row extents from an int32 copy of its row pointer made per call when
  *                   nnz(B) < 2^31; 0: from the int64 pointer)
  *   gram_sliced (1: slice-table walk when the slices are short, 2: whenever the rows are sorted, 0: never),

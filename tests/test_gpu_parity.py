@@ -614,6 +614,29 @@ def _check_spgemm(got, want, dtype):
     assert rel_err(g.data, want.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64).data) <= tol(dtype)
 
 
+@pytest.mark.parametrize("shape", [(1 << 19, 200000, 10), (1 << 18, 1 << 20, 20)])
+def test_transpose_column_histogram_through_lds(gpu, shape):
+    """A CSC operand is transposed on the device (counting sort by column, handle.hip).  From 2^22 entries on, the column
+    histogram runs through LDS ranges of 32 768 counters (k_col_hist_lds, round 4; 7 and 32 ranges here, a hub column in the
+    first range and one in the last); option transpose_lds_hist = 0 is the one-atomic-per-entry kernel.  Same product either way."""
+    m, n, per = shape
+    rng = np.random.default_rng(91)
+    cols = rng.integers(0, n, m * per)
+    cols[rng.choice(m * per, 50000, replace=False)] = 5          # hub columns: many counts on one LDS word
+    cols[rng.choice(m * per, 30000, replace=False)] = n - 3
+    a = sps.coo_matrix((rng.uniform(0.5, 1.5, m * per), (np.repeat(np.arange(m), per), cols)), shape=(m, n)).tocsc()
+    assert a.nnz >= 1 << 22
+    b = rng.uniform(0.5, 1.5, (n, 3))
+    want = a @ b
+    for opt in (1, 0):
+        gpu.mi_set_option("transpose_lds_hist", opt)
+        try:
+            got = gpu.dot_product_mkl(a, b)
+        finally:
+            gpu.mi_set_option("transpose_lds_hist", 1)
+        assert rel_err(got, want) <= 1e-12
+
+
 @pytest.mark.parametrize("upper", [False, True])
 def test_spgemm_upper_bound_pass_long_rows_and_narrow_pointer(gpu, upper):
     """Phase 0 (k_row_ub / k_row_ub_long / k_narrow_ptr, round 4): rows of A on both sides of the 512-nonzero limit of the
