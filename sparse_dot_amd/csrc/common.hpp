@@ -502,6 +502,7 @@ struct AsyncWord {
     bool ready();              // true once a posted copy has landed (non-blocking)
 };
 
+struct SpmmKpart;
 struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.hip)
     int chunk = 0;
     int64_t nchunks = 0;
@@ -528,6 +529,16 @@ struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.h
     DevBuf col_tagged;             // int32[nnz]
     DevBuf hot_decision;           // int64[8] on the device: {flag, thr, nhot, covered, total}
     AsyncWord hot_word;
+    // column-partitioned form of the LONG rows (SpmmKpart, spmm.hip): 0 not looked at yet, 1 declined (the matrix has no
+    // long rows worth it), 2 ready.  Holds a copy of the VALUES: mi_sparse_?_set_values / mi_sparse_order drop it.
+    int kpart_state = 0;
+    std::shared_ptr<SpmmKpart> kpart;
+    void reset_kpart()
+    {
+        kpart_state = 0;
+        kpart.reset();
+        uses = 0;
+    }
     void reset_hot()
     {
         hot_rows_budget = -1;
@@ -536,6 +547,23 @@ struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.h
         hot_coverage = 0.0;
         col_tagged.release();
     }
+};
+
+// Column-partitioned SpMM plan (round 5, spmm.hip).  Rows of at least `min_row` entries ("long" rows) are split by
+// part(column) into P sub-rows; the sub-rows of partition p form the p-th block of rows of `cat` and are multiplied by the
+// workgroups of ONE set of XCDs only, so that set's L2 only ever holds rows of B of partition p -- the eight 4 MB L2s keep
+// P times more DISTINCT rows of B between them.  The price is one partial output row per (long row, partition), summed in a
+// fixed order (k_kp_combine).  Every other row stays in `shrt` (all rows of A, the long ones empty) and is multiplied
+// row-owned as before.
+struct SpmmKpart {
+    int P = 0;            // column partitions (8, 4 or 2); the dense operand is cut into 8 / P column slices on top
+    int64_t min_row = 0;  // rows of at least this many entries are partitioned
+    int64_t n_long = 0, nnz_long = 0;
+    Csr cat;              // rows = P * n_long (block p = partition p, rows in the order of rowid), cols = A's
+    Csr shrt;             // rows = A's, entries of the short rows only
+    DevBuf rowid;         // int32[n_long]: row of A behind every long row
+    int64_t cs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // chunks [cs[p], cs[p + 1]) of cat's plan belong to partition p
+    SpmmPlan plan_cat, plan_short;
 };
 
 }  // namespace mi
@@ -597,6 +625,9 @@ struct Options {
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_slices = 0;       // XCD-affine column slices of the dense operand: 0 = by row width (256-byte slices), else 1, 2, 4, 8
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
+    int64_t spmm_kpart = 1;        // column-partitioned long rows (SpmmKpart) from the third product of a handle on: 0 never, 1 when it pays, 2 always (tests)
+    int64_t spmm_kpart_min_row = 32;  // ... rows of at least this many entries
+    int64_t spmm_kpart_parts = 8;  // ... column partitions: 8, 4 or 2 (x 1, 2, 4 column slices of the dense operand)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)
     int64_t spgemm_part_log2s_bias = 0;  // tuning: +1 / -1 forces the larger / smaller table of the numeric big-row kernel
@@ -630,6 +661,9 @@ struct Counters {
     double spmm_last_slices = 1.0;    // column slices the last SpMM ran with
     double spmm_plan_ms = 0.0;        // host wall time spent building plans (partition + fix-up schedule), accumulated
     double spmm_plans_built = 0.0;
+    double spmm_last_kpart = 0.0;     // column partitions the last SpMM ran its long rows with (0: row-owned only)
+    double spmm_kpart_long_share = 0.0;  // share of the nonzeros in partitioned rows (last SpMM)
+    double spmm_kpart_build_ms = 0.0; // host wall time spent building column-partitioned plans, accumulated
     double bsr_native_calls = 0.0;    // products served by the BSR block kernel
 };
 Counters& counters();  // per host thread

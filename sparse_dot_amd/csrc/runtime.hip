@@ -778,6 +778,15 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
         } else if (!strcmp(name, "spmm_hot_kb")) {
             if (value < 0) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_hot_kb must be >= 0");
             o.spmm_hot_kb = value;
+        } else if (!strcmp(name, "spmm_kpart")) {
+            if (value < 0 || value > 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart must be 0, 1 or 2");
+            o.spmm_kpart = value;
+        } else if (!strcmp(name, "spmm_kpart_min_row")) {
+            if (value < 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_min_row must be >= 2");
+            o.spmm_kpart_min_row = value;
+        } else if (!strcmp(name, "spmm_kpart_parts")) {
+            if (value != 8 && value != 4 && value != 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_parts must be 8, 4 or 2");
+            o.spmm_kpart_parts = value;
         } else if (!strcmp(name, "spmm_slices")) {
             if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
                 mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_slices must be 0 (automatic), 1, 2, 4 or 8");
@@ -873,6 +882,9 @@ mi_sparse_status_t mi_sparse_get_counter(const char* name, double* value)
         else if (!strcmp(name, "spmm_last_slices")) *value = k.spmm_last_slices;
         else if (!strcmp(name, "spmm_plan_ms")) *value = k.spmm_plan_ms;
         else if (!strcmp(name, "spmm_plans_built")) *value = k.spmm_plans_built;
+        else if (!strcmp(name, "spmm_last_kpart")) *value = k.spmm_last_kpart;
+        else if (!strcmp(name, "spmm_kpart_long_share")) *value = k.spmm_kpart_long_share;
+        else if (!strcmp(name, "spmm_kpart_build_ms")) *value = k.spmm_kpart_build_ms;
         else if (!strcmp(name, "bsr_native_calls")) *value = k.bsr_native_calls;
         else mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown counter '%s'", name);
     });

@@ -3209,6 +3209,8 @@ static int set_values_generic(mi_sparse_matrix_t A, const T* values)
         }
         // the derived representation and the packed records of the dense gram (nothing else: plans depend on the pattern only) are stale
         primary.gram_rec.release();
+        h->plan.reset_kpart();  // the column-partitioned SpMM plans hold copies of the values
+        h->planT.reset_kpart();
         Csr& other = created_csc ? h->csr : h->csrT;
         other = Csr();
         c.sync();

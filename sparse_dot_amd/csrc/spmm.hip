@@ -183,12 +183,21 @@ __host__ __device__ constexpr size_t spmm_wave_lds(int ch)
 //     are merged by the compiler and the hint is dropped -- through a second pointer argument, an under-aligned vector
 //     type or a select of pointers alike (the policy is an immediate only on the buffer forms).
 constexpr int SPMM_TAG_NONE = 0, SPMM_TAG_BUFFER = 1;
+
+// Column-partitioned launch (SpmmKpart, common.hpp): the matrix is the concatenation of P sub-matrices, the chunks
+// [cs[p], cs[p + 1]) of its plan belong to sub-matrix p, and sub-matrix p is processed by the XCDs x with x % P == p only
+// (x / P picks one of the 8 / P column slices of the dense operand).  P == 0: the plain mapping.
+struct SpmmParts {
+    int64_t cs[9];
+    int P;
+};
+
 template <typename T, int V, int LPN, int U, int TAG>
 __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ? 8 : 1)
     k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
            const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
            const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
-           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices)
+           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices, SpmmParts parts)
 {
     MI_DYN_SMEM(smem);
     constexpr int NG = WAVE / LPN;  // lane groups per wave, each on its own nonzero
@@ -200,16 +209,28 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     // N, i.e. S times more hot rows.  Each chunk of A is then processed once per slice.
     int64_t cb = blockIdx.x;
     int64_t jlo = 0, jhi = N;
-    if (slices > 1) {  // slices in {2, 4, 8}
+    int64_t w;
+    bool active;
+    if (parts.P > 0) {  // column partitions: XCD x works on sub-matrix x % P, column slice x / P (slices == 8 / P)
         const int xcd = (int)(blockIdx.x & 7u);
-        const int per = 8 / slices;  // XCDs per slice
-        cb = (int64_t)(blockIdx.x >> 3) * per + (xcd % per);
+        const int pp = xcd % parts.P;
         const int64_t ns = N / slices;
-        jlo = (xcd / per) * ns;
+        jlo = (xcd / parts.P) * ns;
         jhi = jlo + ns;
+        w = parts.cs[pp] + (int64_t)(blockIdx.x >> 3) * SPMM_WAVES + wave_in_block;
+        active = w < parts.cs[pp + 1];
+    } else {
+        if (slices > 1) {  // slices in {2, 4, 8}
+            const int xcd = (int)(blockIdx.x & 7u);
+            const int per = 8 / slices;  // XCDs per slice
+            cb = (int64_t)(blockIdx.x >> 3) * per + (xcd % per);
+            const int64_t ns = N / slices;
+            jlo = (xcd / per) * ns;
+            jhi = jlo + ns;
+        }
+        w = cb * SPMM_WAVES + wave_in_block;
+        active = w < nchunks;
     }
-    const int64_t w = cb * SPMM_WAVES + wave_in_block;
-    const bool active = w < nchunks;
 
     // carve this wave's LDS: staged nonzeros first (largest alignment), then the row ends
     const size_t per_wave = (spmm_wave_lds<T>(ch) + 15) & ~size_t(15);
@@ -763,10 +784,9 @@ static void poll_hot_analysis(SpmmPlan& p, bool wait)
     p.hot_state = 2;
 }
 
-static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, int chunk, int64_t hot_rows)
+static SpmmPlan& get_plan(SpmmPlan& p, std::mutex& mtx, const Csr& m, int chunk, int64_t hot_rows)
 {
-    SpmmPlan& p = transposed ? h->planT : h->plan;
-    std::lock_guard<std::mutex> lk(h->mtx);
+    std::lock_guard<std::mutex> lk(mtx);
     Context& c = ctx();
     if (!(p.chunk == chunk && p.chunk_row.p)) {
         // the row partition and the fix-up schedule: two small kernels, nothing read back here
@@ -804,32 +824,38 @@ static SpmmPlan& get_plan(mi_sparse_matrix* h, bool transposed, const Csr& m, in
 }
 
 // called after a product has been enqueued: count the use and start the analysis when reuse is proven
-static void plan_after_product(mi_sparse_matrix* h, bool transposed, const Csr& m, int64_t hot_rows)
+// (`hold_hot`: the column-partitioned form may still replace this plan -- the analysis waits until that is decided)
+static void plan_after_product(SpmmPlan& p, std::mutex& mtx, const Csr& m, int64_t hot_rows, bool hold_hot)
 {
-    SpmmPlan& p = transposed ? h->planT : h->plan;
-    std::lock_guard<std::mutex> lk(h->mtx);
+    std::lock_guard<std::mutex> lk(mtx);
     ++p.uses;
-    if (p.uses == 2 && p.hot_state == 0 && p.hot_rows_budget < 0) enqueue_hot_analysis(p, m, hot_rows);
+    if (p.uses >= 2 && !hold_hot && p.hot_state == 0 && p.hot_rows_budget < 0) enqueue_hot_analysis(p, m, hot_rows);
 }
 
 template <typename T, int V, int LPN, int U>
 static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
                           int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
-                          int tag_mode, int slices)
+                          int tag_mode, int slices, const SpmmParts& parts)
 {
     Context& c = ctx();
     const size_t per_wave = (spmm_wave_lds<T>(p.chunk) + 15) & ~size_t(15);
     const size_t lds = per_wave * SPMM_WAVES;
     unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
-    if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
+    if (parts.P > 0) {  // eight interleaved block lists, each as long as the longest partition's
+        int64_t mx = 0;
+        for (int q = 0; q < parts.P; ++q) mx = std::max(mx, parts.cs[q + 1] - parts.cs[q]);
+        grid = (unsigned)ceil_div(mx, SPMM_WAVES) * 8u;
+        if (grid == 0) return;
+    } else if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
-    note_kernel("mi::k_spmm<%s, V=%d, LPN=%d, U=%d, TAG=%d> x %d column slice%s", type_name<T>(), V, LPN, U,
-                (V * sizeof(T) == 16) ? tag_mode : 0, slices, slices > 1 ? "s" : "");
+    note_kernel("mi::k_spmm<%s, V=%d, LPN=%d, U=%d, TAG=%d> x %d column slice%s%s", type_name<T>(), V, LPN, U,
+                (V * sizeof(T) == 16) ? tag_mode : 0, slices, slices > 1 ? "s" : "",
+                parts.P > 0 ? " (long rows by column partition + short rows row-owned)" : "");
 #define MI_SPMM_LAUNCH(TAGMODE, COLS)                                                                                  \
     MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz, \
                    (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,                                      \
                    (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,      \
-                   c_cs, N, alpha, beta, beta_zero, carry_val, slices)
+                   c_cs, N, alpha, beta, beta_zero, carry_val, slices, parts)
     if constexpr (V * sizeof(T) == 16) {
         if (tag_mode == SPMM_TAG_BUFFER) {
             MI_SPMM_LAUNCH(SPMM_TAG_BUFFER, p.col_tagged.as<int32_t>());
@@ -843,19 +869,19 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
 template <typename T, int V, int LPN>
 static void launch_spmm(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
                         int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
-                        int tag_mode, int slices)
+                        int tag_mode, int slices, const SpmmParts& parts)
 {
     // U = independent 16-byte loads in flight per lane.  The deeper variant exists for the 512-byte
     // row shapes of the headline configs only (keeps the instantiation count down).
     if constexpr (V > 1 && LPN >= 32) {
         if (options().spmm_unroll == 8) {
             launch_spmm_u<T, V, LPN, 8>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val,
-                                        tag_mode, slices);
+                                        tag_mode, slices, parts);
             return;
         }
     }
     launch_spmm_u<T, V, LPN, 4>(m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, tag_mode,
-                                slices);
+                                slices, parts);
 }
 
 // every byte offset (row * ld + column) * elem of the operand, plus the 16 bytes one load covers, fits 32 bits
@@ -864,34 +890,262 @@ static inline bool dense_bytes_below_4g(int64_t rows, int64_t ld, size_t elem)
     return (double)rows * (double)ld * (double)elem + 16.0 < 4294967295.0;
 }
 
-// Core executor on DEVICE pointers.  m is the CSR of op(A) (rows of m = rows of C).
-template <typename T>
-void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a, T alpha, int layout, const T* B,
-                 int64_t N, int64_t ldb, T beta, T* C, int64_t ldc)
+// ------------------------------------------------------------------------------------------------
+// column-partitioned plan (SpmmKpart, common.hpp): build
+// ------------------------------------------------------------------------------------------------
+// part(column): a multiplicative hash, so that every partition gets the same share of the heavy columns of a power-law
+// matrix whatever their numbering (measured on the headline R-MAT: partitions within 1.5 % of each other, the same as a
+// round-robin over the columns ranked by count -- profiles/r05_spmm_kpart_probe.log)
+__host__ __device__ __forceinline__ int kp_part(int32_t c, int P) { return (int)((((uint32_t)c * 0x9E3779B1u) >> 16) & (uint32_t)(P - 1)); }
+
+__global__ void k_kp_flag(const int64_t* __restrict__ ptr, int64_t rows, int64_t min_row, int64_t* __restrict__ flag,
+                          int64_t* __restrict__ short_len)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int64_t len = ptr[r + 1] - ptr[r];
+    const bool lg = len >= min_row;
+    flag[r] = lg ? 1 : 0;
+    short_len[r] = lg ? 0 : len;
+}
+
+__global__ void k_kp_rowid(const int64_t* __restrict__ flag, const int64_t* __restrict__ lidx, int64_t rows,
+                           int32_t* __restrict__ rowid)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows && flag[r]) rowid[lidx[r]] = (int32_t)r;
+}
+
+// one wave per long row: entries per partition -> cnt[p * n_long + i]
+__global__ void __launch_bounds__(256)
+    k_kp_count(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const int32_t* __restrict__ rowid,
+               int64_t n_long, int P, int64_t* __restrict__ cnt)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (i >= n_long) return;
+    const int64_t r = rowid[i], b = ptr[r], e = ptr[r + 1];
+    int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t k = b + lane; k < e; k += WAVE) {
+        const int q = kp_part(col[k], P);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) mine[t] += (q == t) ? 1 : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        int v = mine[t];
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) v += __shfl_xor(v, d);
+        if (lane == 0 && t < P) cnt[(int64_t)t * n_long + i] = v;
+    }
+}
+
+// one wave per long row: stable split of its entries into the P sub-rows (the order inside a sub-row is the row's own)
+template <typename W>
+__global__ void __launch_bounds__(256)
+    k_kp_fill_long(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const W* __restrict__ val,
+                   const int32_t* __restrict__ rowid, int64_t n_long, int P, const int64_t* __restrict__ cat_ptr,
+                   int32_t* __restrict__ cat_col, W* __restrict__ cat_val)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (i >= n_long) return;
+    const int64_t r = rowid[i], b = ptr[r], e = ptr[r + 1];
+    int64_t run[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) run[t] = t < P ? cat_ptr[(int64_t)t * n_long + i] : 0;
+    for (int64_t k0 = b; k0 < e; k0 += WAVE) {
+        const int64_t k = k0 + lane;
+        const bool ok = k < e;
+        const int32_t c = ok ? col[k] : 0;
+        const int q = ok ? kp_part(c, P) : -1;
+        int64_t dst = -1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int total;
+            const int rk = wave_rank(q == t, total);
+            if (q == t) dst = run[t] + rk;
+            run[t] += total;
+        }
+        if (ok) {
+            cat_col[dst] = c;
+            cat_val[dst] = val[k];
+        }
+    }
+}
+
+// eight lanes per short row: its entries move to the compacted arrays as they are
+template <typename W>
+__global__ void __launch_bounds__(256)
+    k_kp_fill_short(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const W* __restrict__ val,
+                    int64_t rows, int64_t min_row, const int64_t* __restrict__ s_ptr, int32_t* __restrict__ s_col,
+                    W* __restrict__ s_val)
+{
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 8;
+    const int li = threadIdx.x % 8;
+    if (r >= rows) return;
+    const int64_t b = ptr[r], len = ptr[r + 1] - b;
+    if (len >= min_row) return;
+    const int64_t d = s_ptr[r];
+    for (int64_t k = li; k < len; k += 8) {
+        s_col[d + k] = col[b + k];
+        s_val[d + k] = val[b + k];
+    }
+}
+
+struct KpWord16 {
+    uint64_t a, b;
+};
+
+// C[rowid[i]] += alpha * (partial[0 * n_long + i] + ... + partial[(P - 1) * n_long + i]): one lane group per long row, the P
+// partial rows in flight together, summed in partition order -- the same bits on every call
+template <typename T, int V, int LPN>
+__global__ void __launch_bounds__(256)
+    k_kp_combine(const T* __restrict__ partial, int64_t n_long, int P, const int32_t* __restrict__ rowid, int64_t N,
+                 T* __restrict__ C, int64_t c_rs, T alpha)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPN;
+    const int li = threadIdx.x % LPN;
+    if (i >= n_long) return;
+    T* crow = C + (int64_t)rowid[i] * c_rs;
+    for (int64_t j = (int64_t)li * V; j < N; j += (int64_t)LPN * V) {  // V divides N on this path
+        vec<T, V> part[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < P) part[t] = *reinterpret_cast<const vec<T, V>*>(partial + ((int64_t)t * n_long + i) * N + j);
+        vec<T, V> out = *reinterpret_cast<const vec<T, V>*>(crow + j);
+        T sum[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) sum[v] = part[0].v[v];
+#pragma unroll
+        for (int t = 1; t < 8; ++t)
+            if (t < P) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], part[t].v[v]);
+            }
+#pragma unroll
+        for (int v = 0; v < V; ++v) out.v[v] = vt<T>::fma(alpha, sum[v], out.v[v]);
+        *reinterpret_cast<vec<T, V>*>(crow + j) = out;
+    }
+}
+
+// Build the column-partitioned form of `m` (synchronous: three scans whose totals size the arrays; ~1 ms of device time at
+// the headline's 31 M entries, paid once, ahead of the third product of a handle).  Sets p.kpart_state to 1 (declined) or 2.
+static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
 {
     Context& c = ctx();
-    if (m.rows == 0 || N == 0) return;
-    if (layout == MI_SPARSE_LAYOUT_COLUMN_MAJOR && N > 1 && !options().spmm_force_generic) {
-        // Column-major operands: a gather of B "rows" would touch one element per cache line.
-        // Re-lay B (and C when beta != 0) as row-major scratch copies with a 16-byte-aligned
-        // leading dimension, run the coalesced kernel, and write C back column-major: two extra
-        // streaming passes over the dense operands instead of an N-fold amplified gather.
-        constexpr int64_t A16 = 16 / (int64_t)sizeof(T);
-        const int64_t ldt = ceil_div(N, A16) * A16;
-        T* bt = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)m.cols * (size_t)ldt));
-        T* ct = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)m.rows * (size_t)ldt));
-        convert_layout<T>(m.cols, N, B, 1, ldb, bt, ldt, 1);
-        if (!vt<T>::is_zero(beta)) convert_layout<T>(m.rows, N, C, 1, ldc, ct, ldt, 1);
-        spmm_device<T>(h, transposed, m, conj_a, alpha, MI_SPARSE_LAYOUT_ROW_MAJOR, bt, N, ldt, beta, ct, ldt);
-        convert_layout<T>(m.rows, N, ct, ldt, 1, C, 1, ldc);
+    const Options& o = options();
+    const int P = (int)o.spmm_kpart_parts;
+    const int64_t min_row = o.spmm_kpart_min_row;
+    p.kpart_state = 1;
+    p.kpart.reset();
+    if (m.rows == 0 || m.nnz == 0) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    MI_HIP_CHECK(hipEventCreate(&e0));
+    MI_HIP_CHECK(hipEventCreate(&e1));
+    MI_HIP_CHECK(hipEventRecord(e0, c.stream));
+    const size_t vb = value_bytes(vtype);
+    DevBuf flag_b, lidx_b, slen_b;
+    flag_b.alloc(sizeof(int64_t) * (size_t)(m.rows + 1));
+    lidx_b.alloc(sizeof(int64_t) * (size_t)(m.rows + 1));
+    slen_b.alloc(sizeof(int64_t) * (size_t)(m.rows + 1));
+    int64_t* flag = flag_b.as<int64_t>();
+    int64_t* lidx = lidx_b.as<int64_t>();
+    MI_LAUNCH(k_kp_flag, dim3((unsigned)ceil_div(m.rows, 256)), dim3(256), c.stream, (const int64_t*)m.ptr, m.rows, min_row,
+              flag, slen_b.as<int64_t>());
+    const int64_t n_long = exclusive_scan_i64(flag, lidx, m.rows);
+    auto kp = std::make_shared<SpmmKpart>();
+    kp->P = P;
+    kp->min_row = min_row;
+    kp->n_long = n_long;
+    Csr& sh = kp->shrt;
+    sh.rows = m.rows;
+    sh.cols = m.cols;
+    sh.ptr_own.alloc(sizeof(int64_t) * (size_t)(m.rows + 1));
+    sh.ptr = sh.ptr_own.as<int64_t>();
+    sh.nnz = exclusive_scan_i64(slen_b.as<int64_t>(), sh.ptr, m.rows);
+    kp->nnz_long = m.nnz - sh.nnz;
+    // worth it when the long rows carry a real share of the gather (their partial rows cost 2 P row widths each, so a row
+    // must gather a multiple of that) and there is something left to balance across the chip
+    const bool pays = n_long > 0 && kp->nnz_long * 4 >= m.nnz;
+    if (!(pays || (o.spmm_kpart == 2 && n_long > 0))) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
         return;
     }
+    kp->rowid.alloc(sizeof(int32_t) * (size_t)n_long);
+    MI_LAUNCH(k_kp_rowid, dim3((unsigned)ceil_div(m.rows, 256)), dim3(256), c.stream, (const int64_t*)flag, (const int64_t*)lidx,
+              m.rows, kp->rowid.as<int32_t>());
+    Csr& cat = kp->cat;
+    cat.rows = (int64_t)P * n_long;
+    cat.cols = m.cols;
+    cat.ptr_own.alloc(sizeof(int64_t) * (size_t)(cat.rows + 1));
+    cat.ptr = cat.ptr_own.as<int64_t>();
+    DevBuf cnt_b;
+    cnt_b.alloc(sizeof(int64_t) * (size_t)(cat.rows + 1));
+    MI_LAUNCH(k_kp_count, dim3((unsigned)ceil_div(n_long * WAVE, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
+              (const int32_t*)m.col, (const int32_t*)kp->rowid.as<int32_t>(), n_long, P, cnt_b.as<int64_t>());
+    cat.nnz = exclusive_scan_i64(cnt_b.as<int64_t>(), cat.ptr, cat.rows);
+    if (cat.nnz != kp->nnz_long) fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "column-partitioned plan: entry counts disagree");
+    cat.col_own.alloc(sizeof(int32_t) * (size_t)cat.nnz);
+    cat.val_own.alloc(vb * (size_t)cat.nnz);
+    cat.col = cat.col_own.as<int32_t>();
+    cat.val = cat.val_own.p;
+    sh.col_own.alloc(sizeof(int32_t) * (size_t)sh.nnz);
+    sh.val_own.alloc(vb * (size_t)sh.nnz);
+    sh.col = sh.col_own.as<int32_t>();
+    sh.val = sh.val_own.p;
+    auto fill = [&](auto word) {
+        using W = decltype(word);
+        MI_LAUNCH((k_kp_fill_long<W>), dim3((unsigned)ceil_div(n_long * WAVE, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
+                  (const int32_t*)m.col, (const W*)m.val, (const int32_t*)kp->rowid.as<int32_t>(), n_long, P,
+                  (const int64_t*)cat.ptr, cat.col, (W*)cat.val);
+        if (sh.nnz)
+            MI_LAUNCH((k_kp_fill_short<W>), dim3((unsigned)ceil_div(m.rows * 8, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
+                      (const int32_t*)m.col, (const W*)m.val, m.rows, min_row, (const int64_t*)sh.ptr, sh.col, (W*)sh.val);
+    };
+    if (vb == 4) fill(uint32_t{});
+    else if (vb == 8) fill(uint64_t{});
+    else fill(KpWord16{});
+    cat.valid = sh.valid = true;
+    cat.sorted = sh.sorted = false;
+    // chunk ranges of the partitions: partition q starts at item cat.ptr[q n_long] + q n_long of cat's item sequence
+    {
+        std::vector<int64_t> starts((size_t)P + 1, 0);
+        for (int q = 1; q < P; ++q)
+            MI_HIP_CHECK(hipMemcpyAsync(&starts[(size_t)q], cat.ptr + (int64_t)q * n_long, sizeof(int64_t), hipMemcpyDeviceToHost,
+                                        c.stream));
+        MI_HIP_CHECK(hipEventRecord(e1, c.stream));
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+        const int64_t chunk = o.spmm_chunk;
+        const int64_t nchunks = ceil_div(cat.nnz + cat.rows, chunk);
+        kp->cs[0] = 0;
+        for (int q = 1; q < P; ++q) kp->cs[q] = (starts[(size_t)q] + (int64_t)q * n_long) / chunk;
+        for (int q = P; q <= 8; ++q) kp->cs[q] = nchunks;
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    counters().spmm_kpart_build_ms += ms;
+    p.kpart = std::move(kp);
+    p.kpart_state = 2;
+}
+
+// One product with plan `p` of matrix `m` (row-major or column-major strides as given; see spmm_device for the layouts).
+// `parts`: column-partitioned launch of a concatenated matrix (slices = 8 / parts->P), else the plain mapping.
+template <typename T>
+static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T alpha, int layout, const T* B, int64_t N,
+                     int64_t ldb, T beta, T* C, int64_t ldc, const SpmmKpart* parts, bool hold_hot)
+{
+    Context& c = ctx();
     // XCD-affine column slices (k_spmm): each set of XCDs works on N / S dense columns only
     constexpr int V16 = 16 / (int)sizeof(T);
     int slices = 1;
     {
         int64_t want = options().spmm_slices;
-        if (want == 0) {
+        if (parts) want = 8 / parts->P;
+        else if (want == 0) {
             // by row width only (never by the matrix: the column split fixes the summation order, so a handle
             // returns the same bits on every call): 256-byte slices, 128-byte ones for 256-byte rows.  Measured on
             // the headline matrix (profiles/r02_spmm_slices_pmc.jsonl): 512-byte rows 2.00 -> 1.79 ms with 2 slices,
@@ -904,21 +1158,23 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
             slices = (int)want;
     }
     const int64_t slice_bytes = N / slices * (int64_t)sizeof(T);  // bytes of one B row one XCD's L2 sees
-    // hot-set budget in rows of B for this call's row width (row-major operands only)
+    // hot-set budget in rows of B for this call's row width (row-major operands only); the partitioned launch gathers
+    // untagged (every XCD's reference stream is an eighth of the columns: non-temporal cold loads cost more than the
+    // evictions they prevent -- long pass 0.81 ms untagged, 0.94-1.04 ms tagged, profiles/r05_spmm_kpart_probe.log)
     int64_t hot_rows = 0;
-    if (layout == MI_SPARSE_LAYOUT_ROW_MAJOR && options().spmm_hot_kb > 0 &&
+    if (!parts && layout == MI_SPARSE_LAYOUT_ROW_MAJOR && options().spmm_hot_kb > 0 &&
         (N * (int64_t)sizeof(T) >= 512 || options().spmm_hot_force))
         hot_rows = options().spmm_hot_kb * 1024 / slice_bytes;
-    const SpmmPlan& p = get_plan(h, transposed, m, (int)options().spmm_chunk, hot_rows);
+    const SpmmPlan& pl = get_plan(p, mtx, m, (int)options().spmm_chunk, hot_rows);
     // fix-up grid: the exact task count once it has reached the host, else its upper bound
-    const int64_t fix_tasks = p.n_tasks >= 0 ? p.n_tasks : p.nchunks;
+    const int64_t fix_tasks = pl.n_tasks >= 0 ? pl.n_tasks : pl.nchunks;
     // one workgroup per task, grid-stride beyond the grid.  While the exact count is still on its way to the host the bound is
     // the chunk count -- hundreds of thousands of workgroups that would read the count and exit on exactly the first calls:
     // a few workgroups per CU stride over whatever the count turns out to be
     int64_t fix_grid = fix_tasks < ((int64_t)1 << 20) ? fix_tasks : ((int64_t)1 << 20);
-    if (p.n_tasks < 0 && c.cus > 0 && fix_grid > (int64_t)8 * c.cus) fix_grid = (int64_t)8 * c.cus;
-    const unsigned long long* n_tasks_dev = static_cast<const unsigned long long*>(p.n_tasks_dev.p);
-    T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)p.nchunks * (size_t)N));
+    if (pl.n_tasks < 0 && c.cus > 0 && fix_grid > (int64_t)8 * c.cus) fix_grid = (int64_t)8 * c.cus;
+    const unsigned long long* n_tasks_dev = static_cast<const unsigned long long*>(pl.n_tasks_dev.p);
+    T* carry_val = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)pl.nchunks * (size_t)N));
     const bool row_major = (layout == MI_SPARSE_LAYOUT_ROW_MAJOR);
     const int64_t b_rs = row_major ? ldb : 1, b_cs = row_major ? 1 : ldb;
     const int64_t c_rs = row_major ? ldc : 1, c_cs = row_major ? 1 : ldc;
@@ -928,26 +1184,30 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
                         ((reinterpret_cast<uintptr_t>(carry_val) % 16) == 0);
     if (N == 1 && !options().spmm_force_generic) {
         // SpMV: lanes over nonzeros (k_spmv); same plan, carries and fix-up as the wide kernel
-        const size_t pw = ((size_t)(p.chunk + SPMM_SPLIT) * sizeof(T) + (size_t)(p.chunk + 2) * sizeof(int32_t) + 15) & ~size_t(15);
+        const size_t pw = ((size_t)(pl.chunk + SPMM_SPLIT) * sizeof(T) + (size_t)(pl.chunk + 2) * sizeof(int32_t) + 15) & ~size_t(15);
         counters().spmm_last_tagged = 0.0;
         note_kernel("mi::k_spmv<%s>", type_name<T>());
-        MI_LAUNCH_SMEM((k_spmv<T>), dim3((unsigned)ceil_div(p.nchunks, SPMM_WAVES)), dim3(SPMM_WAVES * WAVE),
+        MI_LAUNCH_SMEM((k_spmv<T>), dim3((unsigned)ceil_div(pl.nchunks, SPMM_WAVES)), dim3(SPMM_WAVES * WAVE),
                        pw * SPMM_WAVES, c.stream, m.rows, m.nnz, (const int64_t*)m.ptr, (const int32_t*)m.col,
-                       (const T*)m.val, (const SpmmChunk*)p.chunk_desc.as<SpmmChunk>(), p.nchunks, p.chunk, conj_a, B, b_rs,
+                       (const T*)m.val, (const SpmmChunk*)pl.chunk_desc.as<SpmmChunk>(), pl.nchunks, pl.chunk, conj_a, B, b_rs,
                        C, c_rs, alpha, beta, (int)(vt<T>::is_zero(beta) ? 1 : 0), carry_val);
         if (fix_tasks)
             MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)fix_grid), dim3(8 * 16), c.stream,
-                      n_tasks_dev, (const int32_t*)p.tasks.as<int32_t>(), (const T*)carry_val, N, C, c_rs, c_cs, alpha);
-        plan_after_product(h, transposed, m, hot_rows);
+                      n_tasks_dev, (const int32_t*)pl.tasks.as<int32_t>(), (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+        plan_after_product(p, mtx, m, hot_rows, hold_hot);
         return;
     }
     // tagged (hot / cold) gather: raw buffer loads, i.e. 32-bit byte offsets must reach all of B
-    const int tag_mode = (p.tagged && vec_ok && dense_bytes_below_4g(m.cols, ldb, sizeof(T))) ? SPMM_TAG_BUFFER : SPMM_TAG_NONE;
+    const int tag_mode = (pl.tagged && vec_ok && dense_bytes_below_4g(m.cols, ldb, sizeof(T))) ? SPMM_TAG_BUFFER : SPMM_TAG_NONE;
     counters().spmm_last_tagged = (double)tag_mode;
-    counters().spmm_hot_coverage = p.hot_coverage;
+    counters().spmm_hot_coverage = pl.hot_coverage;
     if (!vec_ok) slices = 1;
+    if (parts && slices != 8 / parts->P) fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "column-partitioned launch on an unaligned operand");
     counters().spmm_last_slices = (double)slices;
-#define MI_SPMM_ARGS m, p, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, tag_mode, slices
+    SpmmParts kparts;
+    kparts.P = parts ? parts->P : 0;
+    for (int q = 0; q < 9; ++q) kparts.cs[q] = parts ? parts->cs[q] : 0;
+#define MI_SPMM_ARGS m, pl, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, tag_mode, slices, kparts
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool prof = options().profile_events != 0;
     if (prof) {
@@ -979,7 +1239,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         (void)hipEventDestroy(ev1);
     }
     if (fix_tasks) {
-        const int32_t* tk = p.tasks.as<int32_t>();
+        const int32_t* tk = pl.tasks.as<int32_t>();
         if (vec_ok) {
             if (N / V16 > 16)
                 MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)fix_grid), dim3(8 * 32), c.stream,
@@ -992,7 +1252,78 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
                       n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         }
     }
-    plan_after_product(h, transposed, m, hot_rows);
+    plan_after_product(p, mtx, m, hot_rows, hold_hot);
+}
+
+// Core executor on DEVICE pointers.  m is the CSR of op(A) (rows of m = rows of C).
+template <typename T>
+void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a, T alpha, int layout, const T* B,
+                 int64_t N, int64_t ldb, T beta, T* C, int64_t ldc)
+{
+    Context& c = ctx();
+    if (m.rows == 0 || N == 0) return;
+    if (layout == MI_SPARSE_LAYOUT_COLUMN_MAJOR && N > 1 && !options().spmm_force_generic) {
+        // Column-major operands: a gather of B "rows" would touch one element per cache line.
+        // Re-lay B (and C when beta != 0) as row-major scratch copies with a 16-byte-aligned
+        // leading dimension, run the coalesced kernel, and write C back column-major: two extra
+        // streaming passes over the dense operands instead of an N-fold amplified gather.
+        constexpr int64_t A16 = 16 / (int64_t)sizeof(T);
+        const int64_t ldt = ceil_div(N, A16) * A16;
+        T* bt = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)m.cols * (size_t)ldt));
+        T* ct = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)m.rows * (size_t)ldt));
+        convert_layout<T>(m.cols, N, B, 1, ldb, bt, ldt, 1);
+        if (!vt<T>::is_zero(beta)) convert_layout<T>(m.rows, N, C, 1, ldc, ct, ldt, 1);
+        spmm_device<T>(h, transposed, m, conj_a, alpha, MI_SPARSE_LAYOUT_ROW_MAJOR, bt, N, ldt, beta, ct, ldt);
+        convert_layout<T>(m.rows, N, ct, ldt, 1, C, 1, ldc);
+        return;
+    }
+    SpmmPlan& p = transposed ? h->planT : h->plan;
+    // Column-partitioned long rows (SpmmKpart): for operands the vector path takes, rows of B of at least 256 bytes, a B
+    // beyond what the L2s hold between them, and a matrix large enough for the split to matter.  Looked at ahead of the
+    // THIRD product of a handle (two products prove the reuse; a single-use handle never pays for the build).  The
+    // partial sums of a partitioned row are added in a fixed order, so results stay bitwise reproducible call to call --
+    // but they are not the bits of the row-owned product (another summation order): option deterministic keeps the
+    // row-owned kernel for good.
+    constexpr int V16 = 16 / (int)sizeof(T);
+    const Options& o = options();
+    const int kp_slices = 8 / (int)o.spmm_kpart_parts;
+    const bool kp_shape = o.spmm_kpart != 0 && !o.deterministic && !o.spmm_force_generic && N > 1 &&
+                          layout == MI_SPARSE_LAYOUT_ROW_MAJOR && N % (V16 * kp_slices) == 0 &&
+                          (N / kp_slices) * (int64_t)sizeof(T) >= 64 && (ldb * (int64_t)sizeof(T)) % 16 == 0 &&
+                          (ldc * (int64_t)sizeof(T)) % 16 == 0 && (reinterpret_cast<uintptr_t>(B) % 16) == 0 &&
+                          (reinterpret_cast<uintptr_t>(C) % 16) == 0 &&
+                          (o.spmm_kpart == 2 || (N * (int64_t)sizeof(T) >= 256 && m.nnz >= ((int64_t)1 << 22) &&
+                                                 (double)m.cols * (double)N * (double)sizeof(T) >= 64.0 * 1048576.0));
+    bool hold_hot = false;
+    if (kp_shape) {
+        std::lock_guard<std::mutex> lk(h->mtx);
+        if (p.kpart_state == 2 && (p.kpart->P != (int)o.spmm_kpart_parts || p.kpart->min_row != o.spmm_kpart_min_row))
+            p.kpart_state = 0;  // the options changed (tools): build again
+        if (p.kpart_state == 0 && (p.uses >= 2 || o.spmm_plan_sync || o.spmm_kpart == 2)) build_kpart(p, m, h->vtype);
+        hold_hot = p.kpart_state != 1;
+    }
+    if (kp_shape && p.kpart_state == 2) {
+        SpmmKpart& kp = *p.kpart;
+        counters().spmm_last_kpart = (double)kp.P;
+        counters().spmm_kpart_long_share = m.nnz ? (double)kp.nnz_long / (double)m.nnz : 0.0;
+        // short rows, row-owned, straight into C (the long rows are empty there: they get beta * C)
+        spmm_run<T>(kp.plan_short, h->mtx, kp.shrt, conj_a, alpha, layout, B, N, ldb, beta, C, ldc, nullptr, false);
+        // long rows: partial[q * n_long + i] = (sub-row q of long row i) * B, then C[rowid[i]] += alpha * sum over q
+        T* partial = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)kp.cat.rows * (size_t)N));
+        spmm_run<T>(kp.plan_cat, h->mtx, kp.cat, conj_a, vt<T>::one(), layout, B, N, ldb, vt<T>::zero(), partial, N, &kp, true);
+        const int64_t lanes = N / V16;
+        if (lanes > 16)
+            MI_LAUNCH((k_kp_combine<T, V16, 32>), dim3((unsigned)ceil_div(kp.n_long * 32, 256)), dim3(256), c.stream,
+                      (const T*)partial, kp.n_long, kp.P, (const int32_t*)kp.rowid.as<int32_t>(), N, C, ldc, alpha);
+        else
+            MI_LAUNCH((k_kp_combine<T, V16, 8>), dim3((unsigned)ceil_div(kp.n_long * 8, 256)), dim3(256), c.stream,
+                      (const T*)partial, kp.n_long, kp.P, (const int32_t*)kp.rowid.as<int32_t>(), N, C, ldc, alpha);
+        std::lock_guard<std::mutex> lk(h->mtx);
+        ++p.uses;
+        return;
+    }
+    counters().spmm_last_kpart = 0.0;
+    spmm_run<T>(p, h->mtx, m, conj_a, alpha, layout, B, N, ldb, beta, C, ldc, nullptr, hold_hot);
 }
 
 template void spmm_device<float>(mi_sparse_matrix*, bool, const Csr&, int, float, int, const float*, int64_t, int64_t,
