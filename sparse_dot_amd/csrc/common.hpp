@@ -64,6 +64,7 @@ using f32x16 = mi_f32x16;
 using f64x4 = mi_f64x4;
 #else
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 #endif
@@ -625,8 +626,9 @@ struct Options {
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_slices = 0;       // XCD-affine column slices of the dense operand: 0 = by row width (256-byte slices), else 1, 2, 4, 8
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
+    int64_t spmm_flat = 1;         // SpMM walk inside a wave: 1 = the wave streams the chunk's nonzeros across row ends (k_spmm_flat); 0 = row by row (k_spmm)
     int64_t spmm_kpart = 1;        // column-partitioned long rows (SpmmKpart) from the third product of a handle on: 0 never, 1 when it pays, 2 always (tests)
-    int64_t spmm_kpart_min_row = 32;  // ... rows of at least this many entries
+    int64_t spmm_kpart_min_row = 128;  // ... rows of at least this many entries
     int64_t spmm_kpart_parts = 8;  // ... column partitions: 8, 4 or 2 (x 1, 2, 4 column slices of the dense operand)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)

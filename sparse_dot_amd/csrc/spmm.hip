@@ -401,6 +401,234 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     }
 }
 
+// k_spmm_flat (round 5) -- the same partition, ownership rules, staging, lane layout (LPN lanes x V values across the
+// row of B, 64 / LPN lane groups on consecutive nonzeros) and carries as k_spmm, another walk inside the wave.  k_spmm takes
+// the rows of a chunk one after the other: a row of 7 nonzeros is one (mostly empty) batch of loads and one full memory round
+// trip, so a chunk of 30 short rows is 30 dependent round trips where its 220 nonzeros would fill 14 batches (the short-row
+// half of the column-partitioned product ran at 0.58 ms for a 0.32 ms gather).  Here the wave streams through the chunk's
+// staged nonzeros NG x U at a time WHATEVER the row structure: lane group g takes the nonzeros p + g, p + g + NG, ... of the
+// stream, the row state (current row, its end) is wave-uniform -- scalar registers, scalar branches -- and a row end inside a
+// batch combines the groups' accumulators (xor shuffles), writes the row (or the cut row's carry) and clears them.  The
+// summation order is a function of the chunk alone: the same bits on every call.
+template <typename T, int V>
+__device__ __forceinline__ vec<T, V> spmm_tagged_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, bool cold)
+{
+    constexpr int BYTES = V * (int)sizeof(T);
+    static_assert(BYTES == 16, "tagged gather: 16-byte pieces");
+    u32x4 r;
+    if (cold) r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2);  // nt
+    else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return __builtin_bit_cast(vec<T, V>, r);
+}
+
+template <typename T, int V, int LPN, int U, int TAG>
+__global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ? 8 : 1)
+    k_spmm_flat(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
+                const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
+                int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices, SpmmParts parts)
+{
+    MI_DYN_SMEM(smem);
+    constexpr int NG = WAVE / LPN;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const int lane = threadIdx.x % WAVE;
+    int64_t cb = blockIdx.x;
+    int64_t jlo = 0, jhi = N;
+    int64_t w;
+    bool active;
+    if (parts.P > 0) {
+        const int xcd = (int)(blockIdx.x & 7u);
+        const int pp = xcd % parts.P;
+        const int64_t ns = N / slices;
+        jlo = (xcd / parts.P) * ns;
+        jhi = jlo + ns;
+        w = parts.cs[pp] + (int64_t)(blockIdx.x >> 3) * SPMM_WAVES + wave_in_block;
+        active = w < parts.cs[pp + 1];
+    } else {
+        if (slices > 1) {
+            const int xcd = (int)(blockIdx.x & 7u);
+            const int per = 8 / slices;
+            cb = (int64_t)(blockIdx.x >> 3) * per + (xcd % per);
+            const int64_t ns = N / slices;
+            jlo = (xcd / per) * ns;
+            jhi = jlo + ns;
+        }
+        w = cb * SPMM_WAVES + wave_in_block;
+        active = w < nchunks;
+    }
+    const size_t per_wave = (spmm_wave_lds<T>(ch) + 15) & ~size_t(15);
+    char* base = smem + per_wave * wave_in_block;
+    SpEntry<T>* s_nz = reinterpret_cast<SpEntry<T>*>(base);
+    int32_t* s_end = reinterpret_cast<int32_t*>(base + sizeof(SpEntry<T>) * (size_t)(ch + SPMM_SPLIT));
+
+    int64_t r0 = 0, P0 = 0;
+    int n_owned = 0, has_trail = 0, len = 0;
+    if (active) {  // identical to k_spmm's prologue
+        const int64_t total = nnz + rows;
+        const int64_t s = w * ch;
+        const int64_t e = (s + ch < total) ? s + ch : total;
+        const int64_t ra = chunk_row[w];
+        const int64_t rb = chunk_row[w + 1];
+        {
+            const int64_t pa = ptr[ra], pa1 = ptr[ra + 1];
+            const bool before = (pa + ra) < s;
+            const bool is_long = (pa1 - pa + 1) > SPMM_SPLIT;
+            if (before && !is_long) {
+                r0 = ra + 1;
+                P0 = pa1;
+            } else {
+                r0 = ra;
+                P0 = before ? s - ra : pa;
+            }
+        }
+        int64_t r_stop, P1;
+        if (rb < rows && (ptr[rb] + rb) < e) {
+            const int64_t pb = ptr[rb], pb1 = ptr[rb + 1];
+            r_stop = rb + 1;
+            if ((pb1 - pb + 1) > SPMM_SPLIT) {
+                P1 = (e - rb < pb1) ? e - rb : pb1;
+                has_trail = 1;
+            } else {
+                P1 = pb1;
+            }
+        } else {
+            r_stop = rb;
+            P1 = (rb < rows) ? ptr[rb] : nnz;
+        }
+        if (r_stop < r0) r_stop = r0;
+        const int nproc = (int)(r_stop - r0);
+        n_owned = nproc - has_trail;
+        for (int k = lane; k < nproc; k += WAVE) {
+            int64_t en = ptr[r0 + k + 1];
+            if (k == nproc - 1) en = P1;
+            s_end[k] = (int32_t)(en - P0);
+        }
+        len = (int)(P1 - P0);
+        if (len < 0) len = 0;
+        for (int k = lane; k < len; k += WAVE) {
+            const T a = val[P0 + k];
+            SpEntry<T> en;
+            en.c = col[P0 + k];
+            en.v = conj_a ? vt<T>::conj(a) : a;
+            s_nz[k] = en;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    const int g = lane / LPN;
+    const int li = lane % LPN;
+    const int nproc = n_owned + has_trail;
+    __amdgpu_buffer_rsrc_t b_rsrc;
+    if constexpr (TAG == SPMM_TAG_BUFFER) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0xffffffff, 0x00020000);
+    constexpr int E_NONE = 0x7fffffff;
+
+    for (int64_t j0 = jlo; j0 < jhi; j0 += (int64_t)LPN * V) {
+        const int64_t jc = j0 + (int64_t)li * V;
+        const bool col_ok = jc < jhi;  // V divides N on the vector path
+        const T* bcol = B + (col_ok ? jc : jlo) * b_cs;
+        int k = 0;  // current row (wave-uniform); Ek = its end among the staged nonzeros
+        int Ek = __builtin_amdgcn_readfirstlane(nproc > 0 ? s_end[0] : E_NONE);
+        T acc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = vt<T>::zero();
+        auto fin = [&]() {  // row k ends here: its groups' sums are combined; C for an owned row, the carry for the cut one
+#pragma unroll
+            for (int off = LPN; off < WAVE; off <<= 1) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] = vt<T>::add(acc[v], shfl_xor_val(acc[v], off));
+            }
+            if (g == 0 && col_ok) {
+                if (k < n_owned) {
+                    T* crow = C + (r0 + k) * c_rs + jc * c_cs;
+                    vec<T, V> out;
+                    if (beta_zero) {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) out.v[v] = vt<T>::mul(alpha, acc[v]);
+                    } else {
+                        vec<T, V> old;
+                        if (V > 1) old = *reinterpret_cast<const vec<T, V>*>(crow);
+                        else old.v[0] = crow[0];
+#pragma unroll
+                        for (int v = 0; v < V; ++v) out.v[v] = vt<T>::fma(alpha, acc[v], vt<T>::mul(beta, old.v[v]));
+                    }
+                    if (V > 1) *reinterpret_cast<vec<T, V>*>(crow) = out;
+                    else crow[0] = out.v[0];
+                } else {
+                    T* cv = carry_val + w * N + jc;
+                    if (V > 1) {
+                        vec<T, V> out;
+#pragma unroll
+                        for (int v = 0; v < V; ++v) out.v[v] = acc[v];
+                        *reinterpret_cast<vec<T, V>*>(cv) = out;
+                    } else {
+                        cv[0] = acc[0];
+                    }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = vt<T>::zero();
+            ++k;
+            Ek = __builtin_amdgcn_readfirstlane(k < nproc ? s_end[k] : E_NONE);
+        };
+        for (int p = 0; p < len; p += NG * U) {
+            SpEntry<T> nz[U];
+            vec<T, V> b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pp = p + u * NG + g;
+                nz[u] = s_nz[pp < len ? pp : len - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if constexpr (TAG == SPMM_TAG_BUFFER) {
+                    const int32_t cidx = nz[u].c & 0x7fffffff;
+                    const unsigned voff = (unsigned)(((int64_t)cidx * b_rs + (col_ok ? jc : jlo)) * (int64_t)sizeof(T));
+                    b[u] = spmm_tagged_load<T, V>(b_rsrc, voff, nz[u].c < 0);
+                } else {
+                    const T* src = bcol + (int64_t)nz[u].c * b_rs;
+                    if (V > 1) b[u] = *reinterpret_cast<const vec<T, V>*>(src);
+                    else b[u].v[0] = src[0];
+                }
+            }
+            if (p + NG * U <= Ek) {  // no row ends inside this batch (Ek <= len): straight multiply-adds
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[v] = vt<T>::fma(nz[u].v, b[u].v[v], acc[v]);
+                }
+            } else {
+                // row ends inside the batch: NG nonzeros at a time, the batch rotating through slot 0 (one copy of the
+                // row-end code)
+#pragma unroll 1
+                for (int u = 0; u < U; ++u) {
+                    const int q = p + u * NG;
+                    if (q + NG <= Ek) {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) acc[v] = vt<T>::fma(nz[0].v, b[0].v[v], acc[v]);
+                    } else {
+#pragma unroll 1
+                        for (int gg = 0; gg < NG; ++gg) {
+                            if (q + gg >= len) break;
+                            while (q + gg >= Ek) fin();
+                            if (g == gg) {
+#pragma unroll
+                                for (int v = 0; v < V; ++v) acc[v] = vt<T>::fma(nz[0].v, b[0].v[v], acc[v]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t + 1 < U; ++t) {
+                        nz[t] = nz[t + 1];
+                        b[t] = b[t + 1];
+                    }
+                }
+            }
+        }
+        while (Ek <= len) fin();  // the rows that end with the chunk's last nonzero, empty rows included
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // SpMV (N = 1): y := alpha * A x + beta * y  -- the lanes span NONZEROS instead of dense columns.
 // Same work partition, ownership rules and carry / fix-up machinery as k_spmm.
@@ -832,6 +1060,8 @@ static void plan_after_product(SpmmPlan& p, std::mutex& mtx, const Csr& m, int64
     if (p.uses >= 2 && !hold_hot && p.hot_state == 0 && p.hot_rows_budget < 0) enqueue_hot_analysis(p, m, hot_rows);
 }
 
+static inline const char* flat_name() { return options().spmm_flat ? "_flat" : ""; }
+
 template <typename T, int V, int LPN, int U>
 static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
                           int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
@@ -848,14 +1078,23 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
         if (grid == 0) return;
     } else if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
-    note_kernel("mi::k_spmm<%s, V=%d, LPN=%d, U=%d, TAG=%d> x %d column slice%s%s", type_name<T>(), V, LPN, U,
+    note_kernel("mi::k_spmm%s<%s, V=%d, LPN=%d, U=%d, TAG=%d> x %d column slice%s%s", flat_name(), type_name<T>(), V, LPN, U,
                 (V * sizeof(T) == 16) ? tag_mode : 0, slices, slices > 1 ? "s" : "",
                 parts.P > 0 ? " (long rows by column partition + short rows row-owned)" : "");
+    const bool flat = options().spmm_flat != 0;
 #define MI_SPMM_LAUNCH(TAGMODE, COLS)                                                                                  \
-    MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz, \
-                   (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,                                      \
-                   (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,      \
-                   c_cs, N, alpha, beta, beta_zero, carry_val, slices, parts)
+    do {                                                                                                               \
+        if (flat)                                                                                                      \
+            MI_LAUNCH_SMEM((k_spmm_flat<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream,   \
+                           m.rows, m.nnz, (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,              \
+                           (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C,    \
+                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_val, slices, parts);                           \
+        else                                                                                                           \
+            MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream,        \
+                           m.rows, m.nnz, (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,              \
+                           (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C,    \
+                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_val, slices, parts);                           \
+    } while (0)
     if constexpr (V * sizeof(T) == 16) {
         if (tag_mode == SPMM_TAG_BUFFER) {
             MI_SPMM_LAUNCH(SPMM_TAG_BUFFER, p.col_tagged.as<int32_t>());

@@ -3,7 +3,7 @@
 headline matrix, in ONE process.
 
     python tools/gpu_kpart.py [--workload rmat|uniform] [--scale 20] [--ncols 128] [--launches 10]
-                              [--variants "off,32:8,64:8,128:8,32:4"]      (min_row:parts)
+                              [--variants "off,32:8,64:8,128:8,32:4"]      (min_row:parts[+option=value...])
 
 Every variant: a fresh handle, library defaults (plans adopted as a user's handle would adopt them: untimed calls first),
 whole-product time from events around K calls (all kernels of a product: short rows, long rows, fix-ups, combine), the
@@ -62,7 +62,13 @@ def main():
         if e > b:
             want[k] = (vals[b:e].double()[:, None] * B[indices[b:e].long()].double()).sum(0)
     ref = None
-    for var in args.variants.split(","):
+    defaults = {"spmm_flat": 1, "spmm_slices": 0, "spmm_hot_kb": 8192, "spmm_unroll": 4}
+    for full in args.variants.split(","):
+        var, *extra = full.split("+")
+        for name, value in defaults.items():
+            sda.mi_set_option(name, value)
+        for kv in extra:
+            sda.mi_set_option(kv.split("=")[0], int(kv.split("=")[1]))
         if var == "off":
             sda.mi_set_option("spmm_kpart", 0)
         else:
@@ -98,7 +104,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.launches
-        print(json.dumps({"variant": var, "product_ms": round(ms, 4), "alg_GBps": round(alg / ms / 1e6, 1),
+        print(json.dumps({"variant": full, "product_ms": round(ms, 4), "alg_GBps": round(alg / ms / 1e6, 1),
                           "frac_of_8TBps": round(alg / ms / 1e6 / 8000.0, 4),
                           "kpart": int(sda.mi_get_counter("spmm_last_kpart")),
                           "long_share": round(sda.mi_get_counter("spmm_kpart_long_share"), 4),
