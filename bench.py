@@ -282,10 +282,12 @@ def measured_copy_gbs(torch, dev):
 
 
 def measure_traffic_live(timeout_s=150):
-    """HBM bytes per launch of the dominant SpMM kernel from rocprofv3 PMC counters, collected NOW: two separate
+    """HBM bytes per PRODUCT of the headline SpMM from rocprofv3 PMC counters, collected NOW: two separate
     `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE, WRITE_SIZE -- MI355X_MICROARCH.md, HBM section) over
-    tools/spmm_sweep.py, which launches this very configuration (same generator, seeds, library defaults) in a child
-    process.  gfx950 corrections as the guide prescribes: FETCH_SIZE (KB) x 2 for wide coalesced reads, WRITE_SIZE (KB)
+    tools/gpu_kpart.py, which runs this very configuration (same generator, seeds, library defaults, plans adopted by
+    untimed calls first) in a child process.  One product = every SpMM kernel the library launches for it (round 5: short
+    rows row-owned + long rows by column partition + their carry fix-ups + the combine); the bytes of all of them are
+    summed.  gfx950 corrections as the guide prescribes: FETCH_SIZE (KB) x 2 for wide coalesced reads, WRITE_SIZE (KB)
     as is.  Returns (bytes, description) or (None, reason)."""
     import csv
     import glob
@@ -298,30 +300,37 @@ def measure_traffic_live(timeout_s=150):
         return None, "rocprofv3 not on PATH"
     launches = 3
     out = {}
+    names = set()
     tmp = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
-                   sys.executable, os.path.join(ROOT, "tools", "spmm_sweep.py"), "--launches", str(launches), "--variants", "0:8192:256",
-                   "--adopt-tags"]
+                   sys.executable, os.path.join(ROOT, "tools", "gpu_kpart.py"), "--launches", str(launches), "--variants", "default"]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
             acc = defaultdict(float)
+            kname = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "k_spmm<" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    if row["Counter_Name"] == counter:
                         acc[int(row["Dispatch_Id"])] += float(row["Counter_Value"])
-            ids = sorted(acc)
-            if len(ids) < launches:
-                return None, "no k_spmm dispatches in the %s pass" % counter
-            tail = ids[-launches:]  # the timed launches (the warm-up / plan launches come first)
-            out[counter] = sum(acc[k] for k in tail) / len(tail)
+                        kname[int(row["Dispatch_Id"])] = row["Kernel_Name"]
+            marks = [k for k in kname if "FillFunctor" in kname[k]]
+            if not marks:
+                return None, "no marker dispatch in the %s pass" % counter
+            timed = [k for k in sorted(kname) if k > max(marks) and
+                     any(t in kname[k] for t in ("mi::k_spmm", "mi::k_kp_combine"))]
+            if len(timed) < launches:
+                return None, "no SpMM dispatches behind the marker in the %s pass" % counter
+            names.update(kname[k].split("(")[0].replace("void ", "") for k in timed)
+            out[counter] = sum(acc[k] for k in timed) / launches
         nbytes = out["FETCH_SIZE"] * 1024.0 * 2.0 + out["WRITE_SIZE"] * 1024.0
-        return nbytes, ("rocprofv3 --pmc, two passes in this run: FETCH_SIZE %.0f KB x 2 (gfx950 correction) + WRITE_SIZE %.0f KB, "
-                        "mean of the last %d k_spmm launches" % (out["FETCH_SIZE"], out["WRITE_SIZE"], launches))
+        return nbytes, ("rocprofv3 --pmc, two passes in this run: FETCH_SIZE %.0f KB x 2 (gfx950 correction) + WRITE_SIZE %.0f KB per "
+                        "product, mean of %d products, summed over its kernels: %s" % (out["FETCH_SIZE"], out["WRITE_SIZE"], launches,
+                                                                                        "; ".join(sorted(names))))
     except Exception as exc:  # noqa: BLE001
         return None, "%s: %s" % (type(exc).__name__, str(exc)[:200])
     finally:
@@ -964,16 +973,18 @@ def main():
         cold = first_calls()   # first handle of the process: also pays the scratch arena / block cache / pinned slab set-up
         warm = first_calls()   # a fresh handle in a warm process: what every later handle pays
         del C0
-        plan = {"first_call_ms": round(warm[0], 3), "second_call_ms_incl_hot_cold_analysis": round(warm[1], 3),
-                "later_calls_ms": [round(x, 3) for x in warm[2:]],
-                "plan_ms": round(max(0.0, warm[0] - min(warm[2:])), 3),
+        plan = {"first_call_ms": round(warm[0], 3), "second_call_ms": round(warm[1], 3),
+                "third_call_ms_incl_column_partition_build": round(warm[2], 3),
+                "later_calls_ms": [round(x, 3) for x in warm[3:]],
+                "plan_ms": round(max(0.0, warm[0] - warm[1]), 3),
+                "column_partition_build_ms": round(max(0.0, warm[2] - min(warm[3:])), 3),
                 "first_call_ms_cold_process": round(cold[0], 3),
-                "note": "one synchronised mi_sparse_s_mm per entry on a FRESH handle.  first call = row partition + fix-up "
-                        "schedule (two small kernels, no host synchronisation) + the untagged kernel; plan_ms = first call "
-                        "minus the steady state.  The hot / cold column analysis (sampled histogram -> threshold -> tags, "
-                        "all on the device) is enqueued behind the SECOND product and adopted by the first later call that "
-                        "finds it finished: a single-use handle never pays for it.  *_cold_process = the very first handle "
-                        "of the process (one-time arena / cache growth included)."}
+                "note": "one synchronised mi_sparse_s_mm per entry on a FRESH handle.  Calls 1-2 = the row-owned kernel (call 1 "
+                        "also builds the row partition + fix-up schedule: plan_ms = call 1 - call 2); two products prove the "
+                        "reuse, so call 3 builds the column-partitioned form of the long rows (three scans + two fill passes, "
+                        "synchronous) and runs with it, as every later call does; the short-row half adopts its hot / cold "
+                        "column tags two calls after that.  A single-use handle pays for none of it.  *_cold_process = the very "
+                        "first handle of the process (one-time arena / cache growth included)."}
 
     res = run_partitioned(torch, dist, dev, indptr, indices, vals, n, B, args.steps, args.warmup, make_local,
                           gather_mode=args.gather_mode, sync=torch.cuda.synchronize, bcast_mode=args.bcast_mode)
@@ -992,7 +1003,8 @@ def main():
     ms_per_step = t_step * 1e3
     gflops = 2.0 * nnz * N / t_step / 1e9
 
-    # ---- dominant-kernel duration with hipEvents on the launch stream (separate loop, this rank's block) ----
+    # ---- device time of one product (ALL its kernels: round 5 splits the product into short rows row-owned + long rows by
+    # column partition + carry fix-ups + combine) with hipEvents on the launch stream (separate loop, this rank's block) ----
     sda.mi_set_option("profile_events", 1)
     sda.mi_get_counter("reset")
     for _ in range(max(5, min(args.steps, 20))):
@@ -1003,6 +1015,8 @@ def main():
     sda.mi_set_option("profile_events", 0)
     tagged = bool(sda.mi_get_counter("spmm_last_tagged"))
     slices = int(sda.mi_get_counter("spmm_last_slices"))
+    kpart = int(sda.mi_get_counter("spmm_last_kpart"))
+    long_share = round(sda.mi_get_counter("spmm_kpart_long_share"), 4)
     hot_coverage = round(sda.mi_get_counter("spmm_hot_coverage"), 4)
     blk_nnz, blk_rows = res["block_nnz"], res["block_rows"]
     alg_bytes = blk_nnz * 8 + (blk_rows + 1) * 8 + n * N * 4 + blk_rows * N * 4  # this rank's launch
@@ -1019,7 +1033,9 @@ def main():
                 traffic_src += " (committed PMC summary; live collection unavailable: %s)" % why
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes}
+                "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
+                "kernel_ms_is": "device time of ONE product = the sum of its kernels (hipEvents on the launch stream around all "
+                                "of them): achieved = algorithmic bytes / that"}
     if world == 1:
         copy_gbs = measured_copy_gbs(torch, dev)
         roofline["measured_copy_GBps"] = round(copy_gbs, 1)
@@ -1050,9 +1066,10 @@ def main():
                                       if args.workload == "rmat" else "uniform 32/row", n, n, nnz, n, N),
                        "partition": ("one matrix, %d contiguous nnz-balanced row blocks (partition_rows), one per GPU; step = "
                                      "RCCL bcast(B) -> local kernel -> all-gatherv(C) [%s]" % (world, args.gather_mode))
-                       if world > 1 else "single GPU (step = the kernel + fix-up)",
+                       if world > 1 else "single GPU (step = one product: its kernels + carry fix-ups)",
                        "spmm_chunk": args.chunk or 256, "column_slices": slices,
-                       "hot_cold_tagged_gather": tagged, "hot_column_coverage": hot_coverage},
+                       "hot_cold_tagged_gather": tagged, "hot_column_coverage": hot_coverage,
+                       "column_partitions_of_long_rows": kpart, "nonzeros_in_partitioned_rows": long_share},
             "compute_only_ms": round(t_cmp * 1e3, 4), "end_to_end_ms": round(ms_per_step, 4),
             "roofline": roofline, "parity_max_rel_err_sample": worst,
         }

@@ -786,6 +786,9 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
         } else if (!strcmp(name, "spmm_kpart_min_row")) {
             if (value < 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_min_row must be >= 2");
             o.spmm_kpart_min_row = value;
+        } else if (!strcmp(name, "spmm_kpart_tslices")) {
+            if (value != 1 && value != 2 && value != 4) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_tslices must be 1, 2 or 4");
+            o.spmm_kpart_tslices = value;
         } else if (!strcmp(name, "spmm_kpart_parts")) {
             if (value != 8 && value != 4 && value != 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_parts must be 8, 4 or 2");
             o.spmm_kpart_parts = value;

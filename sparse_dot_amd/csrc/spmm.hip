@@ -187,9 +187,14 @@ constexpr int SPMM_TAG_NONE = 0, SPMM_TAG_BUFFER = 1;
 // Column-partitioned launch (SpmmKpart, common.hpp): the matrix is the concatenation of P sub-matrices, the chunks
 // [cs[p], cs[p + 1]) of its plan belong to sub-matrix p, and sub-matrix p is processed by the XCDs x with x % P == p only
 // (x / P picks one of the 8 / P column slices of the dense operand).  P == 0: the plain mapping.
+// On top, the partitioned launch may walk its chunks T times, once per column slice IN TIME (blocks are dispatched in
+// order: pass t + 1 starts when pass t drains): during a pass an XCD's L2 sees 1 / T of every row of B only, so T times
+// more rows of its partition stay resident, at the price of streaming the sub-matrix T times.
 struct SpmmParts {
     int64_t cs[9];
     int P;
+    int T;         // passes in time (>= 1)
+    int64_t nblk;  // workgroups per XCD and pass
 };
 
 template <typename T, int V, int LPN, int U, int TAG>
@@ -214,10 +219,12 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     if (parts.P > 0) {  // column partitions: XCD x works on sub-matrix x % P, column slice x / P (slices == 8 / P)
         const int xcd = (int)(blockIdx.x & 7u);
         const int pp = xcd % parts.P;
-        const int64_t ns = N / slices;
-        jlo = (xcd / parts.P) * ns;
+        const int64_t ns = N / slices;  // slices = (8 / P) in space x T in time
+        const int64_t bi = (int64_t)(blockIdx.x >> 3);
+        const int64_t tt = bi / parts.nblk, lb = bi - tt * parts.nblk;
+        jlo = ((xcd / parts.P) * parts.T + tt) * ns;
         jhi = jlo + ns;
-        w = parts.cs[pp] + (int64_t)(blockIdx.x >> 3) * SPMM_WAVES + wave_in_block;
+        w = parts.cs[pp] + lb * SPMM_WAVES + wave_in_block;
         active = w < parts.cs[pp + 1];
     } else {
         if (slices > 1) {  // slices in {2, 4, 8}
@@ -439,10 +446,12 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     if (parts.P > 0) {
         const int xcd = (int)(blockIdx.x & 7u);
         const int pp = xcd % parts.P;
-        const int64_t ns = N / slices;
-        jlo = (xcd / parts.P) * ns;
+        const int64_t ns = N / slices;  // slices = (8 / P) in space x T in time
+        const int64_t bi = (int64_t)(blockIdx.x >> 3);
+        const int64_t tt = bi / parts.nblk, lb = bi - tt * parts.nblk;
+        jlo = ((xcd / parts.P) * parts.T + tt) * ns;
         jhi = jlo + ns;
-        w = parts.cs[pp] + (int64_t)(blockIdx.x >> 3) * SPMM_WAVES + wave_in_block;
+        w = parts.cs[pp] + lb * SPMM_WAVES + wave_in_block;
         active = w < parts.cs[pp + 1];
     } else {
         if (slices > 1) {
@@ -1071,10 +1080,8 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
     const size_t per_wave = (spmm_wave_lds<T>(p.chunk) + 15) & ~size_t(15);
     const size_t lds = per_wave * SPMM_WAVES;
     unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
-    if (parts.P > 0) {  // eight interleaved block lists, each as long as the longest partition's
-        int64_t mx = 0;
-        for (int q = 0; q < parts.P; ++q) mx = std::max(mx, parts.cs[q + 1] - parts.cs[q]);
-        grid = (unsigned)ceil_div(mx, SPMM_WAVES) * 8u;
+    if (parts.P > 0) {  // eight interleaved block lists, each as long as the longest partition's, once per pass in time
+        grid = (unsigned)(parts.nblk * parts.T) * 8u;
         if (grid == 0) return;
     } else if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
@@ -1295,6 +1302,7 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
     const int64_t n_long = exclusive_scan_i64(flag, lidx, m.rows);
     auto kp = std::make_shared<SpmmKpart>();
     kp->P = P;
+    kp->tslices = (int)o.spmm_kpart_tslices;
     kp->min_row = min_row;
     kp->n_long = n_long;
     Csr& sh = kp->shrt;
@@ -1383,7 +1391,7 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
     int slices = 1;
     {
         int64_t want = options().spmm_slices;
-        if (parts) want = 8 / parts->P;
+        if (parts) want = 8 / parts->P * parts->tslices;
         else if (want == 0) {
             // by row width only (never by the matrix: the column split fixes the summation order, so a handle
             // returns the same bits on every call): 256-byte slices, 128-byte ones for 256-byte rows.  Measured on
@@ -1392,7 +1400,7 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
             const int64_t row_bytes = N * (int64_t)sizeof(T);
             want = row_bytes >= 2048 ? 8 : row_bytes >= 1024 ? 4 : row_bytes >= 256 ? 2 : 1;
         }
-        if (layout == MI_SPARSE_LAYOUT_ROW_MAJOR && (want == 2 || want == 4 || want == 8) && N % want == 0 &&
+        if (layout == MI_SPARSE_LAYOUT_ROW_MAJOR && (want == 2 || want == 4 || want == 8 || (parts && want == 16)) && N % want == 0 &&
             (N / want) % V16 == 0 && (N / want) * (int64_t)sizeof(T) >= 64)
             slices = (int)want;
     }
@@ -1441,19 +1449,16 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
     counters().spmm_last_tagged = (double)tag_mode;
     counters().spmm_hot_coverage = pl.hot_coverage;
     if (!vec_ok) slices = 1;
-    if (parts && slices != 8 / parts->P) fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "column-partitioned launch on an unaligned operand");
+    if (parts && slices != 8 / parts->P * parts->tslices) fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "column-partitioned launch on an unaligned operand");
     counters().spmm_last_slices = (double)slices;
     SpmmParts kparts;
     kparts.P = parts ? parts->P : 0;
+    kparts.T = parts ? parts->tslices : 1;
+    kparts.nblk = 0;
     for (int q = 0; q < 9; ++q) kparts.cs[q] = parts ? parts->cs[q] : 0;
+    if (parts)
+        for (int q = 0; q < parts->P; ++q) kparts.nblk = std::max(kparts.nblk, ceil_div(parts->cs[q + 1] - parts->cs[q], SPMM_WAVES));
 #define MI_SPMM_ARGS m, pl, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, tag_mode, slices, kparts
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    const bool prof = options().profile_events != 0;
-    if (prof) {
-        MI_HIP_CHECK(hipEventCreate(&ev0));
-        MI_HIP_CHECK(hipEventCreate(&ev1));
-        MI_HIP_CHECK(hipEventRecord(ev0, c.stream));
-    }
     if (vec_ok) {
         const int64_t lanes = N / slices / V16;  // 16-byte lanes needed for one (slice of a) row of B
         if (lanes >= 64) launch_spmm<T, V16, 64>(MI_SPMM_ARGS);
@@ -1467,16 +1472,6 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
         else launch_spmm<T, 1, 4>(MI_SPMM_ARGS);
     }
 #undef MI_SPMM_ARGS
-    if (prof) {
-        MI_HIP_CHECK(hipEventRecord(ev1, c.stream));
-        MI_HIP_CHECK(hipEventSynchronize(ev1));
-        float ms = 0.f;
-        MI_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-        counters().spmm_kernel_ms += ms;
-        counters().spmm_kernel_launches += 1.0;
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
-    }
     if (fix_tasks) {
         const int32_t* tk = pl.tasks.as<int32_t>();
         if (vec_ok) {
@@ -1516,6 +1511,30 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         convert_layout<T>(m.rows, N, ct, ldt, 1, C, 1, ldc);
         return;
     }
+    // option profile_events: hipEvents on the launch stream around EVERY kernel of the product (main kernels, carry fix-ups,
+    // the combine of a partitioned product) -- counter spmm_kernel_ms / spmm_kernel_launches = device time per product
+    struct ProductTimer {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        hipStream_t s;
+        explicit ProductTimer(hipStream_t st) : s(st)
+        {
+            if (!options().profile_events) return;
+            if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return;
+            (void)hipEventRecord(ev0, s);
+        }
+        ~ProductTimer()
+        {
+            if (ev0 && ev1 && hipEventRecord(ev1, s) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+                    counters().spmm_kernel_ms += ms;
+                    counters().spmm_kernel_launches += 1.0;
+                }
+            }
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+        }
+    } product_timer(c.stream);
     SpmmPlan& p = transposed ? h->planT : h->plan;
     // Column-partitioned long rows (SpmmKpart): for operands the vector path takes, rows of B of at least 256 bytes, a B
     // beyond what the L2s hold between them, and a matrix large enough for the split to matter.  Looked at ahead of the
@@ -1525,7 +1544,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     // row-owned kernel for good.
     constexpr int V16 = 16 / (int)sizeof(T);
     const Options& o = options();
-    const int kp_slices = 8 / (int)o.spmm_kpart_parts;
+    const int kp_slices = 8 / (int)o.spmm_kpart_parts * (int)o.spmm_kpart_tslices;
     const bool kp_shape = o.spmm_kpart != 0 && !o.deterministic && !o.spmm_force_generic && N > 1 &&
                           layout == MI_SPARSE_LAYOUT_ROW_MAJOR && N % (V16 * kp_slices) == 0 &&
                           (N / kp_slices) * (int64_t)sizeof(T) >= 64 && (ldb * (int64_t)sizeof(T)) % 16 == 0 &&
@@ -1538,6 +1557,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         std::lock_guard<std::mutex> lk(h->mtx);
         if (p.kpart_state == 2 && (p.kpart->P != (int)o.spmm_kpart_parts || p.kpart->min_row != o.spmm_kpart_min_row))
             p.kpart_state = 0;  // the options changed (tools): build again
+        if (p.kpart_state == 2) p.kpart->tslices = (int)o.spmm_kpart_tslices;
         if (p.kpart_state == 0 && (p.uses >= 2 || o.spmm_plan_sync || o.spmm_kpart == 2)) build_kpart(p, m, h->vtype);
         hold_hot = p.kpart_state != 1;
     }

@@ -62,7 +62,8 @@ def main():
         if e > b:
             want[k] = (vals[b:e].double()[:, None] * B[indices[b:e].long()].double()).sum(0)
     ref = None
-    defaults = {"spmm_flat": 1, "spmm_slices": 0, "spmm_hot_kb": 8192, "spmm_unroll": 4}
+    marker = torch.zeros(1, device=dev)
+    defaults = {"spmm_flat": 1, "spmm_kpart_tslices": 1, "spmm_slices": 0, "spmm_hot_kb": 8192, "spmm_unroll": 4}
     for full in args.variants.split(","):
         var, *extra = full.split("+")
         for name, value in defaults.items():
@@ -71,6 +72,10 @@ def main():
             sda.mi_set_option(kv.split("=")[0], int(kv.split("=")[1]))
         if var == "off":
             sda.mi_set_option("spmm_kpart", 0)
+        elif var == "default":  # the library's own choice (what bench.py times)
+            sda.mi_set_option("spmm_kpart", 1)
+            sda.mi_set_option("spmm_kpart_min_row", 128)
+            sda.mi_set_option("spmm_kpart_parts", 8)
         else:
             t, p = var.split(":")
             sda.mi_set_option("spmm_kpart", 1)
@@ -97,6 +102,7 @@ def main():
         else:
             err = float(((C - ref).abs() / ref.abs().clamp(min=1e-30)).max())
         nan = int(torch.isnan(C).sum())
+        marker.fill_(1.0)  # a one-element fill: the dispatches after the LAST of these are the timed products (bench.py's PMC passes)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.launches):

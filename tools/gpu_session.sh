@@ -4,6 +4,7 @@
 #   tests[:<pytest -k expression>]   pytest -m gpu (the whole suite, or the selected tests) with durations
 #   bench                            python bench.py --steps 20 --warmup 5   (what the driver runs; secondaries + live counter traffic)
 #   stats                            rocprofv3 --kernel-trace --stats of bench.py (headline only / secondaries only)
+#   pmc-kpart[:variant]              the same for tools/gpu_kpart.py (column-partitioned SpMM; variant e.g. 128:8 or off)
 #   pmc-spmm | pmc-gram | pmc-spgemm separate rocprofv3 --pmc passes for the headline SpMM kernel / the dense gram kernel / every SpGEMM kernel of the
 #                                    literal and the uniform configs[2] (tools/pmc_kernels.py)
 #   probes                           tools/probes: spmm_gather_probe (+ counters for H = 16384), lds_atomic_probe, host_register_probe
@@ -17,7 +18,7 @@ pmc() {  # $1 = output tag, rest = command; four counter groups, one pass each
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES"; do
     i=$((i+1)); ( cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/$tag/p$i -o p -- "$@" > $O/$tag.p$i.log 2>&1 )
   done
-  python tools/pmc_kernels.py $O/$tag | grep "mi::" > $O/$tag.jsonl; rm -rf $O/$tag; cut -c1-400 $O/$tag.jsonl | head -8
+  python tools/pmc_kernels.py $O/$tag | grep "mi::" > $O/$tag.jsonl; rm -rf $O/$tag; cut -c1-600 $O/$tag.jsonl | head -8
 }
 for step in "$@"; do
   echo "#### $step"
@@ -41,6 +42,7 @@ PY
       ( cd /tmp && TMPDIR=/tmp timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st2 -o s -- python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-pmc --secondary spgemm,spgemm_rmat,gram > $O/stats_secondary.log 2>&1 )
       cp $(find $O/st2 -name "*kernel_stats.csv" | head -1) $O/secondary_kernel_stats.csv; rm -rf $O/st2; head -8 $O/secondary_kernel_stats.csv | cut -c1-160 ;;
     pmc-spmm) pmc pmc_spmm python $R/tools/spmm_sweep.py --launches 5 --variants 0:8192:256 --adopt-tags ;;
+    pmc-kpart*) v=${step#pmc-kpart}; v=${v#:}; pmc pmc_kpart python $R/tools/gpu_kpart.py --variants ${v:-128:8} --launches 5 --warm 6 ;;
     pmc-gram) pmc pmc_gram python $R/tools/bench_ops.py gram --dense --cols 262144 --rows-log2 22 --reps 1 ;;
     pmc-spgemm) pmc pmc_spgemm_literal python $R/tools/bench_ops.py spgemm --kind rmat --scale 20 --per-row 16 --no-order --reps 1
                 pmc pmc_spgemm_uniform python $R/tools/bench_ops.py spgemm --no-order --reps 2 ;;
