@@ -514,8 +514,8 @@ struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.h
     // device in one pass; the count stays on the device (n_tasks_dev) and reaches the host
     // asynchronously -- until then the fix-up kernel is launched for the upper bound (nchunks).
     DevBuf tasks;        // int32[3 * nchunks]
-    DevBuf n_tasks_dev;  // unsigned long long
-    int64_t n_tasks = -1;  // -1: not known on the host yet
+    DevBuf n_tasks_dev;  // unsigned long long[2]: short tasks (front of the list), long ones (from its back)
+    int64_t n_tasks = -1, n_tasks_long = -1;  // -1: not known on the host yet
     AsyncWord n_tasks_word;
     // hot / cold column tagging (see spmm.hip): copy of the column indices with bit 31 set on
     // entries whose column is NOT in the hot set that is meant to stay L2 resident.  The analysis

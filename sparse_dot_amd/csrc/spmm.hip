@@ -77,9 +77,14 @@ __device__ __forceinline__ int32_t spmm_trail_row(const int64_t* ptr, const int3
     return -1;
 }
 
+// Fix-up tasks with at most FIX_SMALL carries are summed by one lane group each, longer ones by a whole workgroup
+// (k_spmm_fixup): the plan keeps them in two lists -- short tasks from the front of `tasks`, long ones from its back.
+constexpr int FIX_SMALL = 8;
+
 // one thread per chunk: the first chunk of every run of chunks that carry into the same row emits
-// the fix-up task (row, first chunk, last chunk).  Tasks are independent, so their order in the list
-// (atomic cursor) does not matter; there are at most nchunks of them (runs are disjoint).
+// the fix-up task (row, first chunk, last chunk).  Tasks are independent, so their order in the lists
+// (atomic cursors: n_tasks[0] short ones, n_tasks[1] long ones) does not matter; there are at most nchunks of them in all
+// (runs are disjoint).
 __global__ void k_spmm_plan_tasks(const int64_t* ptr, const int32_t* chunk_row, int64_t rows, int64_t nnz, int64_t ch,
                                   int64_t nchunks, int32_t* tasks, unsigned long long* n_tasks)
 {
@@ -90,7 +95,9 @@ __global__ void k_spmm_plan_tasks(const int64_t* ptr, const int32_t* chunk_row, 
     if (w > 0 && spmm_trail_row(ptr, chunk_row, rows, nnz, ch, w - 1) == row) return;
     int64_t last = w;
     while (last + 1 < nchunks && spmm_trail_row(ptr, chunk_row, rows, nnz, ch, last + 1) == row) ++last;
-    const unsigned long long t = atomicAdd(n_tasks, 1ull);
+    int64_t t;
+    if (last - w < FIX_SMALL) t = (int64_t)atomicAdd(n_tasks, 1ull);
+    else t = nchunks - 1 - (int64_t)atomicAdd(n_tasks + 1, 1ull);
     tasks[3 * t + 0] = row;
     tasks[3 * t + 1] = (int32_t)w;
     tasks[3 * t + 2] = (int32_t)last;
@@ -561,7 +568,11 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
 #pragma unroll
                         for (int v = 0; v < V; ++v) out.v[v] = vt<T>::fma(alpha, acc[v], vt<T>::mul(beta, old.v[v]));
                     }
-                    if (V > 1) *reinterpret_cast<vec<T, V>*>(crow) = out;
+                    // the output row is written once and not read again by this product: non-temporal stores keep it from
+                    // displacing rows of B in the L2 (headline 1.47 -> 1.35 ms, row-owned form 1.84 -> 1.75 ms,
+                    // profiles/r05_spmm_nt_store_ab.log; non-temporal loads of A changed nothing)
+                    if constexpr (V * sizeof(T) == 16) nt_store16(crow, out.v);
+                    else if (V > 1) *reinterpret_cast<vec<T, V>*>(crow) = out;
                     else crow[0] = out.v[0];
                 } else {
                     T* cv = carry_val + w * N + jc;
@@ -736,69 +747,115 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE)
     }
 }
 
-// add the carries of every cut row to the row its owner wrote.  The schedule (which chunks carry
-// into which row) depends only on A and the chunk size, so it is precomputed in the plan.  One WORKGROUP per task
-// (round 3; one lane group before): eight lane groups of LPN lanes x V values take the chunks first + g, first + g + 8, ...
-// with four carry loads in flight each -- a hub row is cut into hundreds of chunks, which one lane group summed in ~30
-// dependent round trips -- and group 0 combines the eight partial sums through LDS in a FIXED order and does the one
-// read-modify-write of C: the same partition and the same order as before, so the same bits, run to run.
+// add the carries of every cut row to the row its owner wrote.  The schedule (which chunks carry into which row) depends
+// only on A and the chunk size, so it is precomputed in the plan (k_spmm_plan_tasks: a list of short tasks, a list of
+// long ones).  Workgroups of eight lane groups (LPN lanes x V values); the first ceil(short / 8) workgroups of the
+// (virtual) grid take eight short tasks each, the others one long task each (round 5; one task of either kind per
+// workgroup before -- the column-partitioned product cuts ~50 000 sub-rows of two or three carries each, and a workgroup
+// with two barriers per task spent 68 us on them):
+//   * a short task belongs to ONE lane group: carries in chunk order, four loads in flight, one read-modify-write of C,
+//     no LDS, no barrier;
+//   * a long task (a hub row is cut into hundreds of chunks) is shared by the eight groups: group g takes the chunks
+//     first + g, first + g + 8, ..., group 0 combines the eight partial sums through LDS in a FIXED tree.
+// Which form a task takes depends on its length only: the same bits on every call.
 template <typename T, int V, int LPN>
 __global__ void __launch_bounds__(8 * LPN)
-    k_spmm_fixup(const unsigned long long* __restrict__ n_tasks_dev, const int32_t* __restrict__ tasks,
+    k_spmm_fixup(const unsigned long long* __restrict__ n_tasks_dev, const int32_t* __restrict__ tasks, int64_t cap,
                  const T* __restrict__ carry_val, int64_t N, T* __restrict__ C, int64_t c_rs, int64_t c_cs, T alpha)
 {
     constexpr int G = 8, U = 4;
     __shared__ T part_s[G][LPN * V];
     const int g = threadIdx.x / LPN, li = threadIdx.x % LPN;
-    const int64_t n_tasks = (int64_t)*n_tasks_dev;  // the count lives on the device (the grid may be an upper bound, and is capped)
-    for (int64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
-    const int64_t row = tasks[3 * task], first = tasks[3 * task + 1], last = tasks[3 * task + 2];
-    for (int64_t j0 = 0; j0 < N; j0 += (int64_t)LPN * V) {
-        const int64_t jc = j0 + (int64_t)li * V;
-        const bool col_ok = jc < N;  // V divides N on the vector path
-        const int64_t jl = col_ok ? jc : j0;
-        T part[V];
+    // the counts live on the device (the grid may be an upper bound, and is capped)
+    const int64_t n_short = (int64_t)n_tasks_dev[0], n_long = (int64_t)n_tasks_dev[1];
+    const int64_t short_blocks = (n_short + G - 1) / G;
+    for (int64_t blk = blockIdx.x; blk < short_blocks + n_long; blk += gridDim.x) {
+        if (blk < short_blocks) {
+            const int64_t task = blk * G + g;
+            if (task >= n_short) continue;
+            const int64_t row = tasks[3 * task], first = tasks[3 * task + 1], last = tasks[3 * task + 2];
+            for (int64_t j0 = 0; j0 < N; j0 += (int64_t)LPN * V) {
+                const int64_t jc = j0 + (int64_t)li * V;
+                if (jc >= N) continue;  // V divides N on the vector path
+                T sum[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) part[v] = vt<T>::zero();
-        for (int64_t u = first + g; u <= last; u += (int64_t)G * U) {
-            vec<T, V> cvv[U];
+                for (int v = 0; v < V; ++v) sum[v] = vt<T>::zero();
+                for (int64_t u = first; u <= last; u += U) {
+                    vec<T, V> cvv[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const int64_t uu = (u + (int64_t)k * G <= last) ? u + (int64_t)k * G : last;  // clamp; masked out below
-                if (V > 1) cvv[k] = *reinterpret_cast<const vec<T, V>*>(carry_val + uu * N + jl);
-                else cvv[k].v[0] = carry_val[uu * N + jl];
-            }
+                    for (int k = 0; k < U; ++k) {
+                        const int64_t uu = (u + k <= last) ? u + k : last;
+                        if (V > 1) cvv[k] = *reinterpret_cast<const vec<T, V>*>(carry_val + uu * N + jc);
+                        else cvv[k].v[0] = carry_val[uu * N + jc];
+                    }
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                if (u + (int64_t)k * G <= last) {
+                    for (int k = 0; k < U; ++k) {
+                        if (u + k <= last) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) part[v] = vt<T>::add(part[v], cvv[k].v[v]);
+                            for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], cvv[k].v[v]);
+                        }
+                    }
+                }
+                T* c = C + row * c_rs + jc * c_cs;
+                if (V > 1) {
+                    vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(c);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) old.v[v] = vt<T>::fma(alpha, sum[v], old.v[v]);
+                    *reinterpret_cast<vec<T, V>*>(c) = old;
+                } else {
+                    *c = vt<T>::fma(alpha, sum[0], *c);
                 }
             }
+            continue;
         }
+        const int64_t task = cap - 1 - (blk - short_blocks);  // the long tasks fill the list from its back
+        const int64_t row = tasks[3 * task], first = tasks[3 * task + 1], last = tasks[3 * task + 2];
+        for (int64_t j0 = 0; j0 < N; j0 += (int64_t)LPN * V) {
+            const int64_t jc = j0 + (int64_t)li * V;
+            const bool col_ok = jc < N;  // V divides N on the vector path
+            const int64_t jl = col_ok ? jc : j0;
+            T part[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) part_s[g][li * V + v] = part[v];
-        __syncthreads();
-        if (g == 0 && col_ok) {
-            T sum[V];
+            for (int v = 0; v < V; ++v) part[v] = vt<T>::zero();
+            for (int64_t u = first + g; u <= last; u += (int64_t)G * U) {
+                vec<T, V> cvv[U];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const int x = li * V + v;
-                sum[v] = vt<T>::add(vt<T>::add(vt<T>::add(part_s[0][x], part_s[1][x]), vt<T>::add(part_s[2][x], part_s[3][x])),
-                                    vt<T>::add(vt<T>::add(part_s[4][x], part_s[5][x]), vt<T>::add(part_s[6][x], part_s[7][x])));
+                for (int k = 0; k < U; ++k) {
+                    const int64_t uu = (u + (int64_t)k * G <= last) ? u + (int64_t)k * G : last;  // clamp; masked out below
+                    if (V > 1) cvv[k] = *reinterpret_cast<const vec<T, V>*>(carry_val + uu * N + jl);
+                    else cvv[k].v[0] = carry_val[uu * N + jl];
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    if (u + (int64_t)k * G <= last) {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) part[v] = vt<T>::add(part[v], cvv[k].v[v]);
+                    }
+                }
             }
-            T* c = C + row * c_rs + jc * c_cs;
-            if (V > 1) {
-                vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(c);
 #pragma unroll
-                for (int v = 0; v < V; ++v) old.v[v] = vt<T>::fma(alpha, sum[v], old.v[v]);
-                *reinterpret_cast<vec<T, V>*>(c) = old;
-            } else {
-                *c = vt<T>::fma(alpha, sum[0], *c);
+            for (int v = 0; v < V; ++v) part_s[g][li * V + v] = part[v];
+            __syncthreads();
+            if (g == 0 && col_ok) {
+                T sum[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const int x = li * V + v;
+                    sum[v] = vt<T>::add(vt<T>::add(vt<T>::add(part_s[0][x], part_s[1][x]), vt<T>::add(part_s[2][x], part_s[3][x])),
+                                        vt<T>::add(vt<T>::add(part_s[4][x], part_s[5][x]), vt<T>::add(part_s[6][x], part_s[7][x])));
+                }
+                T* c = C + row * c_rs + jc * c_cs;
+                if (V > 1) {
+                    vec<T, V> old = *reinterpret_cast<const vec<T, V>*>(c);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) old.v[v] = vt<T>::fma(alpha, sum[v], old.v[v]);
+                    *reinterpret_cast<vec<T, V>*>(c) = old;
+                } else {
+                    *c = vt<T>::fma(alpha, sum[0], *c);
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
     }
 }
 
@@ -1034,8 +1091,8 @@ static SpmmPlan& get_plan(SpmmPlan& p, std::mutex& mtx, const Csr& m, int chunk,
                   (const int64_t*)m.ptr, m.rows, m.nnz, (int64_t)chunk, p.nchunks, p.chunk_row.as<int32_t>());
         p.chunk = chunk;
         p.tasks.alloc(sizeof(int32_t) * 3 * (size_t)(p.nchunks + 1));
-        p.n_tasks_dev.alloc(sizeof(unsigned long long));
-        MI_HIP_CHECK(hipMemsetAsync(p.n_tasks_dev.p, 0, sizeof(unsigned long long), c.stream));
+        p.n_tasks_dev.alloc(2 * sizeof(unsigned long long));
+        MI_HIP_CHECK(hipMemsetAsync(p.n_tasks_dev.p, 0, 2 * sizeof(unsigned long long), c.stream));
         MI_LAUNCH(k_spmm_plan_tasks, dim3((unsigned)ceil_div(p.nchunks, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
                   (const int32_t*)p.chunk_row.as<int32_t>(), m.rows, m.nnz, (int64_t)chunk, p.nchunks,
                   p.tasks.as<int32_t>(), static_cast<unsigned long long*>(p.n_tasks_dev.p));
@@ -1043,12 +1100,15 @@ static SpmmPlan& get_plan(SpmmPlan& p, std::mutex& mtx, const Csr& m, int chunk,
         MI_LAUNCH(k_spmm_plan_desc, dim3((unsigned)ceil_div(p.nchunks, 256)), dim3(256), c.stream, (const int64_t*)m.ptr,
                   (const int32_t*)p.chunk_row.as<int32_t>(), m.rows, m.nnz, (int64_t)chunk, p.nchunks,
                   p.chunk_desc.as<SpmmChunk>());
-        p.n_tasks = -1;
-        p.n_tasks_word.post(p.n_tasks_dev.p, sizeof(unsigned long long), c.stream);
+        p.n_tasks = p.n_tasks_long = -1;
+        p.n_tasks_word.post(p.n_tasks_dev.p, 2 * sizeof(unsigned long long), c.stream);
         p.uses = 0;
         counters().spmm_plans_built += 1.0;
     }
-    if (p.n_tasks < 0 && p.n_tasks_word.ready()) p.n_tasks = p.n_tasks_word.host[0];
+    if (p.n_tasks < 0 && p.n_tasks_word.ready()) {
+        p.n_tasks = p.n_tasks_word.host[0];
+        p.n_tasks_long = p.n_tasks_word.host[1];
+    }
     // hot / cold tags: analysed behind the SECOND product of a handle (a single-use handle never pays),
     // or at once when a test / tool asks for the synchronous form
     const bool sync_plan = options().spmm_plan_sync != 0 || options().spmm_hot_force != 0;
@@ -1414,7 +1474,7 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
         hot_rows = options().spmm_hot_kb * 1024 / slice_bytes;
     const SpmmPlan& pl = get_plan(p, mtx, m, (int)options().spmm_chunk, hot_rows);
     // fix-up grid: the exact task count once it has reached the host, else its upper bound
-    const int64_t fix_tasks = pl.n_tasks >= 0 ? pl.n_tasks : pl.nchunks;
+    const int64_t fix_tasks = pl.n_tasks >= 0 ? ceil_div(pl.n_tasks, 8) + pl.n_tasks_long : pl.nchunks;  // workgroups of the fix-up
     // one workgroup per task, grid-stride beyond the grid.  While the exact count is still on its way to the host the bound is
     // the chunk count -- hundreds of thousands of workgroups that would read the count and exit on exactly the first calls:
     // a few workgroups per CU stride over whatever the count turns out to be
@@ -1440,7 +1500,7 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
                        C, c_rs, alpha, beta, (int)(vt<T>::is_zero(beta) ? 1 : 0), carry_val);
         if (fix_tasks)
             MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)fix_grid), dim3(8 * 16), c.stream,
-                      n_tasks_dev, (const int32_t*)pl.tasks.as<int32_t>(), (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+                      n_tasks_dev, (const int32_t*)pl.tasks.as<int32_t>(), pl.nchunks, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         plan_after_product(p, mtx, m, hot_rows, hold_hot);
         return;
     }
@@ -1477,13 +1537,13 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
         if (vec_ok) {
             if (N / V16 > 16)
                 MI_LAUNCH((k_spmm_fixup<T, V16, 32>), dim3((unsigned)fix_grid), dim3(8 * 32), c.stream,
-                          n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+                          n_tasks_dev, tk, pl.nchunks, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
             else
                 MI_LAUNCH((k_spmm_fixup<T, V16, 8>), dim3((unsigned)fix_grid), dim3(8 * 8), c.stream,
-                          n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+                          n_tasks_dev, tk, pl.nchunks, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         } else {
             MI_LAUNCH((k_spmm_fixup<T, 1, 16>), dim3((unsigned)fix_grid), dim3(8 * 16), c.stream,
-                      n_tasks_dev, tk, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
+                      n_tasks_dev, tk, pl.nchunks, (const T*)carry_val, N, C, c_rs, c_cs, alpha);
         }
     }
     plan_after_product(p, mtx, m, hot_rows, hold_hot);
