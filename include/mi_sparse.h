@@ -387,7 +387,9 @@ mi_sparse_status_t mi_sparse_d_syprd(int op, mi_sparse_matrix_t A, const double 
  * (mkl_sparse_?_update_values): what makes NNZ_COUNT once / FINALIZE_MULT many times useful.
  * A handle created from DEVICE arrays aliases them, but it also keeps derived copies of the values (the cached
  * transpose, the packed records of the dense gram): values of aliased device arrays must therefore be changed through
- * this call, not by writing the arrays in place -- an in-place write leaves those copies stale. */
+ * this call, not by writing the arrays in place -- an in-place write leaves those copies stale.
+ * The STRUCTURE (row pointer, column indices) of aliased device arrays must not be modified at all while the handle lives:
+ * plans, sortedness answers and row-length bounds are cached on the handle for good. */
 mi_sparse_status_t mi_sparse_s_set_values(mi_sparse_matrix_t A, const float *values);
 mi_sparse_status_t mi_sparse_d_set_values(mi_sparse_matrix_t A, const double *values);
 mi_sparse_status_t mi_sparse_c_set_values(mi_sparse_matrix_t A, const mi_complex8 *values);

@@ -6,11 +6,7 @@
 // helpers.  gfx950 only: wavefront = 64 lanes everywhere.
 #pragma once
 
-#ifdef MI_HIP_EMU
-#include "hip_emu.hpp"  // tools/hip_emu: developer-only host emulation of the kernels' source
-#else
 #include <hip/hip_runtime.h>
-#endif
 
 #include <cstdint>
 #include <cstdio>
@@ -27,47 +23,32 @@
 
 namespace mi {
 // Launch helper: converts the arguments to the kernel's parameter types (so call sites need no
-// casts) and hides the <<< >>> syntax from the host-emulation build.
+// casts).
 [[noreturn]] void launch_too_large(unsigned long long threads);  // throws (runtime.hip)
 
 template <typename... KArgs, typename... Args>
 inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t stream, Args&&... args)
 {
-#ifdef MI_HIP_EMU
-    (void)stream;
-    hip_emu::launch(kernel, grid, block, smem, static_cast<KArgs>(args)...);
-#else
     // HIP runs at most 2^32 - 1 threads per grid dimension and silently drops the rest
     if ((unsigned long long)grid.x * block.x >= (1ull << 32)) launch_too_large((unsigned long long)grid.x * block.x);
     if (grid.y > 65535u || grid.z > 65535u) launch_too_large((unsigned long long)(grid.y > grid.z ? grid.y : grid.z));
     kernel<<<grid, block, smem, stream>>>(static_cast<KArgs>(args)...);
-#endif
 }
 }  // namespace mi
 #define MI_LAUNCH(kernel, grid, block, stream, ...) ::mi::launch_k(kernel, grid, block, 0, stream, __VA_ARGS__)
 #define MI_LAUNCH_SMEM(kernel, grid, block, smem, stream, ...) \
     ::mi::launch_k(kernel, grid, block, smem, stream, __VA_ARGS__)
-#ifdef MI_HIP_EMU
-#define MI_DYN_SMEM(name) char* name = hip_emu::dyn_smem()
-#else
 #define MI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
-#endif
 
 namespace mi {
 
 constexpr int WAVE = 64;
 
-// register-vector types of the buffer-load / MFMA builtins (the host emulation names its own)
-#ifdef MI_HIP_EMU
-using u32x4 = mi_u32x4;
-using f32x16 = mi_f32x16;
-using f64x4 = mi_f64x4;
-#else
+// register-vector types of the buffer-load / MFMA builtins
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // complex value type (layout-compatible with mi_complex8 / mi_complex16 and numpy complex)
@@ -164,11 +145,7 @@ __device__ __forceinline__ T nt_load(const T* p)
 template <typename T>
 __device__ __forceinline__ void nt_store(T* dst, T v)
 {
-#ifdef MI_HIP_EMU
-    *dst = v;
-#else
     __builtin_nontemporal_store(v, dst);
-#endif
 }
 template <typename T>
 __device__ __forceinline__ void nt_store16(T* dst, const T* src)
@@ -183,9 +160,6 @@ __device__ __forceinline__ void nt_store16(T* dst, const T* src)
 template <typename T>
 __device__ __forceinline__ T lane_bcast(T v, int src)
 {
-#ifdef MI_HIP_EMU
-    return __shfl(v, src);
-#else
     static_assert(sizeof(T) == 4 || sizeof(T) == 8, "lane_bcast: 4- or 8-byte values");
     int w[sizeof(T) / 4];
     __builtin_memcpy(w, &v, sizeof(T));
@@ -194,26 +168,14 @@ __device__ __forceinline__ T lane_bcast(T v, int src)
     T r;
     __builtin_memcpy(&r, w, sizeof(T));
     return r;
-#endif
 }
 
 // Position of this lane among the lanes of the wave whose `flag` is set, and their number (all 64 lanes call it together).
 __device__ __forceinline__ int wave_rank(bool flag, int& total)
 {
-#ifdef MI_HIP_EMU
-    int v = flag ? 1 : 0;
-    const int lane = (int)(threadIdx.x & 63);
-    for (int d = 1; d < 64; d <<= 1) {
-        const int n = __shfl_up(v, d);
-        if (lane >= d) v += n;
-    }
-    total = __shfl(v, 63);
-    return v - (flag ? 1 : 0);
-#else
     const unsigned long long m = __ballot(flag);
     total = __popcll(m);
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-#endif
 }
 
 // A 64-bit word other WORKGROUPS publish and poll (decoupled look-back of the one-pass SpGEMM): relaxed, agent scope -- the
@@ -228,7 +190,7 @@ __device__ __forceinline__ void agent_store(unsigned long long* p, unsigned long
 }
 
 // LDS written by some lanes of a wave and read by others of the SAME wave: the lanes run in lockstep, an LDS fence is all
-// the hardware needs (the host emulation synchronises its threads here)
+// the hardware needs
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -242,9 +204,7 @@ __device__ __forceinline__ void wave_lds_sync()
 template <typename T>
 __device__ __forceinline__ void pin_vgpr(T& x)
 {
-#ifndef MI_HIP_EMU
     asm volatile("" : "+v"(x));
-#endif
 }
 
 // atomic accumulate (LDS or global).  Real types map to the hardware float / double atomic add
@@ -276,7 +236,7 @@ struct lds_word {  // bit pattern of an fp32 cell; a dummy for every other type
     using type = unsigned;
 };
 // step 1 for a batch: returns the pattern the cell held -- 0: the product is in.  Nothing has to look at the result before
-// the other swaps of the batch have been issued.  Types without the swap (and the host emulator) report "taken".
+// the other swaps of the batch have been issued.  Types without the swap report "taken".
 template <typename T>
 __device__ __forceinline__ unsigned lds_accum_swap(T* p, T x)
 {
@@ -292,7 +252,6 @@ __device__ __forceinline__ unsigned lds_accum_retry(T* p, T x, unsigned seen)
     (void)x;
     return ~seen;
 }
-#ifndef MI_HIP_EMU
 template <>
 __device__ __forceinline__ unsigned lds_accum_swap<float>(float* p, float x)
 {
@@ -303,7 +262,6 @@ __device__ __forceinline__ unsigned lds_accum_retry<float>(float* p, float x, un
 {
     return atomicCAS(reinterpret_cast<unsigned*>(p), seen, __float_as_uint(__uint_as_float(seen) + x));
 }
-#endif
 // one product at a time
 template <typename T>
 __device__ __forceinline__ void lds_accum(T* p, T x)
@@ -445,6 +403,11 @@ struct Staged {
 constexpr uint32_t HANDLE_MAGIC = 0x4d495350u;  // 'MISP'
 
 // canonical device CSR: 64-bit row pointer, 32-bit column index, values of the handle's type
+template <typename X>
+inline X cache_get(const X& f) { return __atomic_load_n(&f, __ATOMIC_RELAXED); }
+template <typename X>
+inline void cache_set(X& f, X v) { __atomic_store_n(&f, v, __ATOMIC_RELAXED); }
+
 struct Csr {
     int64_t rows = 0, cols = 0, nnz = 0;
     int64_t* ptr = nullptr;  // rows + 1
@@ -452,7 +415,11 @@ struct Csr {
     void* val = nullptr;     // nnz
     DevBuf ptr_own, col_own, val_own;  // storage when the library owns it (else aliases caller HBM)
     bool valid = false;
-    mutable bool sorted = false;  // column indices known to be ascending inside every row (rows_sorted records a positive answer: the structure of a handle never changes)
+    // column indices known to be ascending inside every row.  rows_sorted() records a positive answer through a const
+    // reference (the structure of a handle never changes -- for arrays aliased from the caller that is part of the contract,
+    // include/mi_sparse.h): host threads sharing an operand may race on it, so these cached answers are only ever touched
+    // through cache_get / cache_set (relaxed atomics; every writer stores the same value)
+    mutable bool sorted = false;
     // generation of the ENTRY ORDER inside the rows: a fresh value (next_order_gen) whenever the entries are (re)laid out --
     // built, transposed into, re-sorted.  Anything that indexes per-entry tables by position (the staged product's B-row
     // extents, spgemm.hip) records it and checks it again before trusting those tables.

@@ -635,8 +635,8 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         // 15.8 vs 19.3 ms; literal configs[3], 8 per slice: 141 vs 116 ms)
         bool sliced = options().gram_sliced != 0 && x.nnz > 0;
         if (sliced && options().gram_sliced == 1 && x.nnz / (x.rows > 0 ? x.rows : 1) / tiles_per_row > 12) sliced = false;
-        if (sliced && !x.sorted) {
-            if (rows_sorted(x)) x.sorted = true; else sliced = false;
+        if (sliced && !cache_get(x.sorted)) {
+            if (!rows_sorted(x)) sliced = false;  // (a positive answer is recorded by rows_sorted)
         }
         if (x.nnz >= ((int64_t)1 << 31) - 64) sliced = false;  // 32-bit absolute positions in the slice table
         size_t need = sizeof(int32_t) * (size_t)x.rows * (size_t)(tiles_per_row + 1);
@@ -704,7 +704,7 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
         // slice bounds travelling with the entries of X^T (rows of X of at most 255 entries, at most 11 tiles per row)
         const GramHead* head = nullptr;
         if (sliced && off && tiles_per_row <= GRAM_HEAD_MAXG && options().gram_heads) {
-            if (x.gram_max_row < 0) {
+            if (cache_get(x.gram_max_row) < 0) {
                 long long* dm = static_cast<long long*>(c.scratch_alloc(sizeof(long long)));
                 MI_HIP_CHECK(hipMemsetAsync(dm, 0, sizeof(long long), c.stream));
                 MI_LAUNCH(k_gram_max_row, dim3((unsigned)(ceil_div(x.rows, 256) < 4096 ? ceil_div(x.rows, 256) : 4096)), dim3(256),
@@ -712,9 +712,9 @@ static int syrkd_generic(int op, mi_sparse_matrix_t A, T alpha, T beta, T* C, in
                 long long hm = 0;
                 MI_HIP_CHECK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, c.stream));
                 MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-                x.gram_max_row = (int64_t)hm;
+                cache_set(x.gram_max_row, (int64_t)hm);
             }
-            if (x.gram_max_row <= 255) {
+            if (cache_get(x.gram_max_row) <= 255) {
                 bool have = t.gram_head_w == tile && t.gram_head.p;
                 if (!have) {
                     try {  // 16 bytes per nonzero: with a 256 GiB output on the device there may be no room -- the table still works

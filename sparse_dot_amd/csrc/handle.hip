@@ -432,7 +432,7 @@ __global__ void k_count_start_descents(const int64_t* __restrict__ ptr, const in
 
 bool rows_sorted(const Csr& a)
 {
-    if (a.sorted || a.nnz < 2) return true;
+    if (cache_get(a.sorted) || a.nnz < 2) return true;
     Context& c = ctx();
     unsigned long long* cnt = static_cast<unsigned long long*>(c.scratch_alloc(2 * sizeof(unsigned long long)));
     MI_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), c.stream));
@@ -447,7 +447,7 @@ bool rows_sorted(const Csr& a)
     MI_HIP_CHECK(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, c.stream));
     MI_HIP_CHECK(hipStreamSynchronize(c.stream));
     const bool sorted = h[0] == h[1];
-    if (sorted) a.sorted = true;  // asked again by every product this matrix takes part in
+    if (sorted) cache_set(a.sorted, true);  // asked again by every product this matrix takes part in
     return sorted;
 }
 

@@ -300,7 +300,6 @@ void Context::sync()
 
 // ---- parallel staged copies of pageable host memory ------------------------------------------------
 namespace {
-#ifndef MI_HIP_EMU
 class CopyEngine {
 public:
     static constexpr size_t CHUNK = size_t(4) << 20;
@@ -472,7 +471,6 @@ private:
         }
     }
 };
-#endif
 constexpr size_t STAGED_COPY_MIN = size_t(8) << 20;  // below this a plain (driver-staged) copy is as fast
 }  // namespace
 
@@ -481,13 +479,11 @@ void copy_h2d(void* dst_dev, const void* src_host, size_t n)
     if (!n) return;
     Context& c = ctx();
     c.ensure();
-#ifndef MI_HIP_EMU
     if (n >= STAGED_COPY_MIN && options().staged_copies) {
         CopyEngine::get().run(0, const_cast<char*>(static_cast<const char*>(src_host)), static_cast<char*>(dst_dev), n,
                               c.device, c.stream);
         return;
     }
-#endif
     MI_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, n, hipMemcpyHostToDevice, c.stream));
 }
 
@@ -499,14 +495,12 @@ void copy_d2h(void* dst_host, const void* src_dev, size_t n)
         c.sync();
         return;
     }
-#ifndef MI_HIP_EMU
     if (n >= STAGED_COPY_MIN && options().staged_copies) {
         CopyEngine::get().run(1, static_cast<char*>(dst_host), const_cast<char*>(static_cast<const char*>(src_dev)), n,
                               c.device, c.stream);
         c.sync();  // same post-condition as the plain path: the caller's stream is idle, retired arenas can go
         return;
     }
-#endif
     MI_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, n, hipMemcpyDeviceToHost, c.stream));
     c.sync();
 }
@@ -525,9 +519,7 @@ Loc locate(const void* p)
     switch (attr.type) {
         case hipMemoryTypeDevice:
         case hipMemoryTypeManaged:
-#ifndef MI_HIP_EMU
         case hipMemoryTypeArray:
-#endif
             return Loc::Device;
         default:
             return Loc::Host;
@@ -702,11 +694,7 @@ mi_sparse_status_t mi_sparse_get_version_string(char* buf, int len)
         } else {
             (void)hipGetLastError();
         }
-#ifdef MI_HIP_EMU
-        snprintf(buf, (size_t)len, "mi_sparse 0.1.0 HOST-EMULATED DEVELOPER BUILD (not a product): %s", dev);
-#else
         snprintf(buf, (size_t)len, "mi_sparse 0.1.0 (HIP, gfx950 / CDNA4 kernels): %s", dev);
-#endif
     });
 }
 

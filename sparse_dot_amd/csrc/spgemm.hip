@@ -475,60 +475,6 @@ __global__ void __launch_bounds__(64)
         if (lane == 0) row_nnz[row] = local;
     } else {
         wave_lds_sync();
-#if defined(MI_GRP_KO_STORE)   // timing only: no output
-        if (keys[lane] == 12345678) ccol[out0] = 1;
-#elif defined(MI_GRP_STAGED)
-        // the row's entries compacted IN PLACE (an entry moves to a slot at or before its own; all reads of a step precede its
-        // writes), then written with 16 bytes per lane: whole 128-byte lines per store instruction instead of 4- / 8-byte
-        // pieces (the memory side saw 50 write requests of 64 bytes per row -- as many requests as the reads)
-        int n_out = 0;
-        for (int k0 = 0; k0 < S; k0 += 64) {
-            const int32_t key = keys[k0 + lane];
-            const T val = vals[k0 + lane];
-            int cnt;
-            const int pos = wave_rank(key != HASH_EMPTY, cnt);
-            wave_lds_sync();
-            if (key != HASH_EMPTY) {
-                keys[n_out + pos] = key;
-                vals[n_out + pos] = val;
-            }
-            n_out += cnt;
-        }
-        wave_lds_sync();
-        {   // columns: 4 per lane and store
-            int32_t* dst = ccol + out0;
-            int head = (int)((4 - (out0 & 3)) & 3);  // entries before the first 16-byte boundary
-            if (head > n_out) head = n_out;
-            if (lane < head) dst[lane] = keys[lane];
-            const int nvec = (n_out - head) / 4;
-            for (int i = lane; i < nvec; i += 64) {
-                u32x4 w;
-                w[0] = (unsigned)keys[head + 4 * i];
-                w[1] = (unsigned)keys[head + 4 * i + 1];
-                w[2] = (unsigned)keys[head + 4 * i + 2];
-                w[3] = (unsigned)keys[head + 4 * i + 3];
-                *reinterpret_cast<u32x4*>(dst + head + 4 * i) = w;
-            }
-            const int done = head + 4 * nvec;
-            if (lane < n_out - done) dst[done + lane] = keys[done + lane];
-        }
-        if constexpr (sizeof(T) == 8) {  // values: 2 per lane and store
-            T* dst = cval + out0;
-            const int head = (int)(out0 & 1) < n_out ? (int)(out0 & 1) : n_out;
-            if (lane < head) dst[lane] = vals[lane];
-            const int nvec = (n_out - head) / 2;
-            for (int i = lane; i < nvec; i += 64) {
-                vec<T, 2> w;
-                w.v[0] = vals[head + 2 * i];
-                w.v[1] = vals[head + 2 * i + 1];
-                *reinterpret_cast<vec<T, 2>*>(dst + head + 2 * i) = w;
-            }
-            const int done = head + 2 * nvec;
-            if (lane < n_out - done) dst[done + lane] = vals[done + lane];
-        } else {
-            for (int i = lane; i < n_out; i += 64) cval[out0 + i] = vals[i];
-        }
-#else
         int written = 0;
         for (int k0 = 0; k0 < S; k0 += 64) {
             const int32_t key = keys[k0 + lane];
@@ -540,7 +486,6 @@ __global__ void __launch_bounds__(64)
             }
             written += cnt;
         }
-#endif
     }
 }
 
@@ -594,13 +539,9 @@ __global__ void __launch_bounds__(WAVES * 64)
     int64_t* qlo = qlo_all[wave];
     T* a_s = a_all[wave];
     int* inc = inc_all[wave];
-#ifdef MI_ONEPASS_BLOCKIDX  // experiment: dispatch order instead of a ticket
-    const int64_t blk = blockIdx.x;
-#else
     if (tid == 0) ticket_s = (long long)atomicAdd(ticket_counter, 1ull);
     __syncthreads();
     const int64_t blk = ticket_s;
-#endif
     const int64_t row = blk * WAVES + wave;
     int nnz_row = 0, log2e = 6;
     if (row < rows) {  // whole wave
@@ -690,12 +631,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
     if (lane == 0) row_n[wave] = nnz_row;
     __syncthreads();
-#ifdef MI_ONEPASS_KO  // timing only: no look-back, rows at their upper-bound positions (valid for <= 256 products per row)
-    if (tid == 0) block_excl = blk * WAVES * 256;
-    if (false) {
-#else
     if (wave == 0) {
-#endif
         long long agg = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) agg += row_n[w];
@@ -730,11 +666,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     __syncthreads();
     if (row < rows) {
         int64_t out0 = block_excl;
-#ifdef MI_ONEPASS_KO
-        out0 += wave * 256;
-#else
         for (int w = 0; w < wave; ++w) out0 += row_n[w];
-#endif
         const int se = 1 << log2e;
         int written = 0;
         for (int k0 = 0; k0 < se; k0 += 64) {
@@ -1604,19 +1536,12 @@ constexpr int RANK_SEG_UNROLL = MI_RANK_SEG_UNROLL;  // segments in flight per w
 
 __device__ __forceinline__ int wave_uniform(int v)  // v is the same in every lane: keep it in a scalar register
 {
-#ifdef MI_HIP_EMU
-    return v;
-#else
     return __builtin_amdgcn_readfirstlane(v);
-#endif
 }
 
 template <typename T>
 __device__ __forceinline__ T wave_uniform_val(T v)  // the same for a value of any size that is a multiple of 4 bytes
 {
-#ifdef MI_HIP_EMU
-    return v;
-#else
     static_assert(sizeof(T) % 4 == 0, "wave_uniform_val: whole 32-bit words");
     int w[sizeof(T) / 4];
     __builtin_memcpy(w, &v, sizeof(T));
@@ -1625,7 +1550,6 @@ __device__ __forceinline__ T wave_uniform_val(T v)  // the same for a value of a
     T r;
     __builtin_memcpy(&r, w, sizeof(T));
     return r;
-#endif
 }
 
 // inclusive prefix sums of three ints per thread at once (one pair of barriers; see block_scan_inclusive)
@@ -2269,7 +2193,7 @@ static void launch_batched(int64_t nblocks, int threads, F&& f)
 
 // What the symbolic phase leaves for the numeric phase about the big rows (LDS bitmap path).
 struct BigRows {
-    int log2s = 11;            // table size of the numeric range kernel; a range holds cap = 2^log2s / 2 columns
+    int log2s = 11;            // table size of the numeric range kernel; a range holds cap = 2^log2s * MI_PART_FILL_8THS / 8 columns (5/8: not a power of two)
     int64_t cap = 1024;
     bool b_sorted = false;     // rows of B sorted (needed to cut B rows into column ranges by search)
     bool have_bounds = false;  // symbolic phase ran the bitmap kernel and stored the range starts
@@ -2423,7 +2347,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                 } else if (big.b_sorted && n_bounds < ((int64_t)1 << 31)) {
                     big.boff_by_row.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
                     big.bounds.alloc(sizeof(int32_t) * (size_t)(n_bounds + 1));
-                    MI_LAUNCH_SMEM((k_spgemm_bitmap<true>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
+                    MI_LAUNCH_SMEM((k_spgemm_bitmap<BM_BOUNDS>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
                                    c.stream, nbig, (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr,
                                    (const int64_t*)big.ext0.as<int64_t>(), (const int32_t*)big.extlen.as<int32_t>(),
                                    (const int32_t*)B.col, gw, upper, row_nnz,
@@ -2431,7 +2355,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                                    big.boff_by_row.as<int64_t>(), counter, BitmapStore{});
                     big.have_bounds = true;
                 } else {
-                    MI_LAUNCH_SMEM((k_spgemm_bitmap<false>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
+                    MI_LAUNCH_SMEM((k_spgemm_bitmap<BM_COUNT>), dim3((unsigned)nblocks), dim3(1024), bitmap_lds_bytes(B.cols),
                                    c.stream, nbig, (const int32_t*)big_list, B.cols, (const int64_t*)A.ptr,
                                    (const int64_t*)big.ext0.as<int64_t>(), (const int32_t*)big.extlen.as<int32_t>(),
                                    (const int32_t*)B.col, gw, upper, row_nnz,
@@ -2732,6 +2656,8 @@ static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C
 #define MI_PART_FILL_8THS 5
 #endif
     big.cap = ((int64_t)1 << big.log2s) * MI_PART_FILL_8THS / 8;  // distinct columns per range: the fill of the range kernel's table
+    // k_spgemm_bitmap forms ceil(rank / cap) as (rank + cap - 1) * ceil(2^40 / cap) >> 40: exact while (rank + cap) * cap < 2^40, rank <= 2^21 columns
+    static_assert((((uint64_t)1 << 21) + ((uint64_t)1 << 12)) * ((uint64_t)1 << 12) < ((uint64_t)1 << 40), "range-start division by multiplication");
     C.rows = A.rows;
     C.cols = B.cols;
     C.ptr_own.alloc(sizeof(int64_t) * (size_t)(C.rows + 1));
@@ -2741,8 +2667,8 @@ static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C
     big.ext0.alloc(sizeof(int64_t) * (size_t)(A.nnz + 1));
     big.extlen.alloc(sizeof(int32_t) * (size_t)(A.nnz + 1));
     if (options().spgemm_group && B.rows > 0 && B.nnz >= 6 * B.rows) {  // short, even rows of B: 16 lanes per row, no flat list
-        if (B.gram_max_row < 0) B.gram_max_row = device_max_row_len(B);
-        big.grp = B.gram_max_row <= 32;
+        if (cache_get(B.gram_max_row) < 0) cache_set(B.gram_max_row, device_max_row_len(B));
+        big.grp = cache_get(B.gram_max_row) <= 32;
     }
     launch_row_ub(A, B, st.upper_mode, bd.ub, big.ext0.as<int64_t>(), big.extlen.as<int32_t>());
     st.a_gen = A.order_gen;
@@ -2833,8 +2759,16 @@ static bool spgemm_onepass(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     unsigned long long* flags = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * (size_t)(nblocks + 1)));
     MI_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(unsigned long long) * (size_t)(nblocks + 1), c.stream));
     unsigned long long* ticket = flags + nblocks;
-    C.col_own.alloc(sizeof(int32_t) * (size_t)bd.sum_ub);
-    C.val_own.alloc(sizeof(T) * (size_t)bd.sum_ub);
+    try {  // sized for the bound: a device that is nearly full may still hold the exact result of the two-phase path
+        C.col_own.alloc(sizeof(int32_t) * (size_t)bd.sum_ub);
+        C.val_own.alloc(sizeof(T) * (size_t)bd.sum_ub);
+    } catch (const status_error& e) {
+        if (e.status != MI_SPARSE_STATUS_ALLOC_FAILED) throw;
+        C.col_own.release();
+        C.val_own.release();
+        clear_error();
+        return false;
+    }
     C.col = C.col_own.as<int32_t>();
     C.val = C.val_own.p;
     auto launch = [&](auto log2s_tag) {
@@ -2856,7 +2790,7 @@ static bool spgemm_onepass(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     MI_HIP_CHECK(hipMemcpyAsync(&C.nnz, C.ptr + A.rows, sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
     MI_HIP_CHECK(hipStreamSynchronize(c.stream));
     trace_mark("one pass", t_last);
-    if (C.nnz * 2 < bd.sum_ub) {  // the bound was loose: give the surplus back
+    if (C.nnz * 2 < bd.sum_ub || (size_t)(bd.sum_ub - C.nnz) * per > ((size_t)1 << 30)) {  // the bound was loose (or a GiB over): give the surplus back
         DevBuf col, val;
         col.alloc(sizeof(int32_t) * (size_t)C.nnz);
         val.alloc(sizeof(T) * (size_t)C.nnz);

@@ -56,8 +56,9 @@ MKL_NAMES_BOUND_BY_THE_REFERENCE = (
 
 def test_mkl_alias_library_exports_what_the_reference_binds():
     """libmi_mkl_rt.so (csrc/mkl_alias.cpp): the MKL-named face of the backend, so that the UNMODIFIED reference can be
-    pointed at it with $MKL_RT.  Import-level check here; tools/hip_emu/check_mkl_alias.sh runs the
-    reference's own test-suite through it on the host-emulated kernels (log under profiles/)."""
+    pointed at it with $MKL_RT.  Import-level check here; the MKL names are driven on the GPU by
+    tests/test_gpu_mkl_alias.py (round 3 also ran the reference's own test-suite through the alias on a host emulation of the
+    kernels, since removed: profiles/r03_reference_suite_on_alias.log)."""
     path = os.path.join(ROOT, "sparse_dot_amd", "libmi_mkl_rt.so")
     assert os.path.exists(path), "build first: python -c 'import __graft_entry__ as g; g.build()'"
     from sparse_dot_amd._mi_interface import _library  # loads torch's HIP runtime first when there is one

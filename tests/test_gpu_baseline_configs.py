@@ -52,8 +52,9 @@ def _abi():
 def test_config3_literal_rmat_spgemm(gpu):
     """BASELINE configs[2] as literally stated: two R-MAT scale-20 matrices, 16 edges/row (seeds 21, 23), fp64.
     (1) nnz(C) equals the count obtained in round 1 for these seeds and exceeds INT32_MAX;
-    (2) C 1 = A (B 1) to 1e-12;  (3) >= 64 sampled rows -- the 5 longest among them -- have bit-exact structure
-    (sorted column sets) and 1e-12 values against a host Gustavson of just those rows."""
+    (2) C 1 = A (B 1) to 1e-12;  (3) >= 64 sampled rows -- among them the 5 longest a host Gustavson can afford -- have
+    bit-exact structure (sorted column sets) and 1e-12 values against a host Gustavson of just those rows;  (4) the 5
+    ABSOLUTELY longest rows (> 1e9 products each) the same against a chunked fp64 Gustavson on the device (torch ops only)."""
     torch = pytest.importorskip("torch")
     import bench
     MI, matrix_descr, sparse_matrix_t, check = _abi()
@@ -101,8 +102,9 @@ def test_config3_literal_rmat_spgemm(gpu):
         clen = np.diff(cptr)
         a_ptr, a_idx, a_val = a[0].cpu().numpy().astype(np.int64), a[1].cpu().numpy(), av.cpu().numpy()
         b_ptr, b_idx, b_val = b[0].cpu().numpy().astype(np.int64), b[1].cpu().numpy(), bv.cpu().numpy()
-        # the five longest rows of C whose host Gustavson stays below 2e8 products each (the very longest rows have > 1e9:
-        # tens of GB of numpy temporaries and minutes on a busy host), always at least one of the 40 longest
+        # the five longest rows of C whose host Gustavson stays below 2e8 products each, searched among the 400 longest (the
+        # very longest rows have > 1e9: tens of GB of numpy temporaries and minutes on a busy host -- those are checked on
+        # the device in (4))
         b_len = np.diff(b_ptr)
         longest = []
         for r in np.argsort(clen)[::-1][:400].tolist():
@@ -133,6 +135,47 @@ def test_config3_literal_rmat_spgemm(gpu):
             assert np.array_equal(got_cols[order], want_cols), "row %d: structure differs" % r
             want_vals = acc[want_cols]
             err = np.max(np.abs(got_vals[order] - want_vals) / np.maximum(np.abs(want_vals), 1e-300)) if tot else 0.0
+            assert err <= F64_TOL, (r, err)
+        # (4) the five ABSOLUTELY longest rows of C (the hub rows that take the deepest path of the big-row kernels: > 1e9
+        # products each) against a Gustavson evaluation on the device in fp64 with torch ops only (index_add_ into a dense
+        # accumulator, a chunk of <= 1e8 products at a time) -- exact structure, 1e-12 values
+        ip_a, ip_b = a[0].to(torch.int64), b[0].to(torch.int64)
+        idx_b = b[1].to(torch.int64)
+        top = np.argsort(clen)[::-1][:5].tolist()
+        assert int(b_len[a_idx[a_ptr[top[0]]:a_ptr[top[0] + 1]]].sum()) > 1_000_000_000  # beyond what (3) can afford
+        for r in top:
+            lo, hi = int(a_ptr[r]), int(a_ptr[r + 1])
+            acc = torch.zeros(n, device=dev, dtype=torch.float64)
+            hit = torch.zeros(n, device=dev, dtype=torch.bool)
+            ks_all, av_all = a[1][lo:hi].to(torch.int64), av[lo:hi]
+            lens_all = ip_b[ks_all + 1] - ip_b[ks_all]
+            bounds = [0]
+            run = 0
+            for i, l in enumerate(lens_all.tolist()):
+                run += l
+                if run >= 100_000_000:
+                    bounds.append(i + 1)
+                    run = 0
+            if bounds[-1] != hi - lo:
+                bounds.append(hi - lo)
+            for c0, c1 in zip(bounds[:-1], bounds[1:]):
+                ks, lens = ks_all[c0:c1], lens_all[c0:c1]
+                tot = int(lens.sum())
+                if tot == 0:
+                    continue
+                first = torch.cumsum(lens, 0) - lens
+                pos = torch.repeat_interleave(ip_b[ks] - first, lens) + torch.arange(tot, device=dev)
+                cols_p = idx_b[pos]
+                acc.index_add_(0, cols_p, torch.repeat_interleave(av_all[c0:c1], lens) * bv[pos])
+                hit[cols_p] = True
+                del pos, cols_p
+            want_cols = torch.nonzero(hit).flatten()
+            got_cols = torch.from_numpy(_d2h(p_col.value, int(clen[r]), np.int32, int(cptr[r])).astype(np.int64)).to(dev)
+            got_vals = torch.from_numpy(_d2h(p_val.value, int(clen[r]), np.float64, int(cptr[r]))).to(dev)
+            order = torch.argsort(got_cols)
+            assert got_cols.numel() == want_cols.numel() and torch.equal(got_cols[order], want_cols), "hub row %d: structure differs" % r
+            want_vals = acc[want_cols]
+            err = float(((got_vals[order] - want_vals).abs() / want_vals.abs().clamp(min=1e-300)).max())
             assert err <= F64_TOL, (r, err)
     finally:
         for h in handles:
