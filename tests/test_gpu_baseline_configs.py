@@ -54,7 +54,7 @@ def test_config3_literal_rmat_spgemm(gpu):
     (1) nnz(C) equals the count obtained in round 1 for these seeds and exceeds INT32_MAX;
     (2) C 1 = A (B 1) to 1e-12;  (3) >= 64 sampled rows -- among them the 5 longest a host Gustavson can afford -- have
     bit-exact structure (sorted column sets) and 1e-12 values against a host Gustavson of just those rows;  (4) the 5
-    ABSOLUTELY longest rows (> 1e9 products each) the same against a chunked fp64 Gustavson on the device (torch ops only)."""
+    rows with the most products and the 3 longest rows of C -- whatever their size -- the same against a chunked fp64 Gustavson on the device (torch ops only)."""
     torch = pytest.importorskip("torch")
     import bench
     MI, matrix_descr, sparse_matrix_t, check = _abi()
@@ -136,13 +136,15 @@ def test_config3_literal_rmat_spgemm(gpu):
             want_vals = acc[want_cols]
             err = np.max(np.abs(got_vals[order] - want_vals) / np.maximum(np.abs(want_vals), 1e-300)) if tot else 0.0
             assert err <= F64_TOL, (r, err)
-        # (4) the five ABSOLUTELY longest rows of C (the hub rows that take the deepest path of the big-row kernels: > 1e9
-        # products each) against a Gustavson evaluation on the device in fp64 with torch ops only (index_add_ into a dense
+        # (4) the five rows with the MOST PRODUCTS and the three longest rows of C, without any size filter (the hub rows that
+        # take the deepest path of the big-row kernels) against a Gustavson evaluation on the device in fp64 with torch ops only (index_add_ into a dense
         # accumulator, a chunk of <= 1e8 products at a time) -- exact structure, 1e-12 values
         ip_a, ip_b = a[0].to(torch.int64), b[0].to(torch.int64)
         idx_b = b[1].to(torch.int64)
-        top = np.argsort(clen)[::-1][:5].tolist()
-        assert int(b_len[a_idx[a_ptr[top[0]]:a_ptr[top[0] + 1]]].sum()) > 1_000_000_000  # beyond what (3) can afford
+        prod_cum = np.concatenate([[0], np.cumsum(b_len[a_idx])])
+        prods = prod_cum[a_ptr[1:]] - prod_cum[a_ptr[:-1]]  # products per row of C
+        top = list(dict.fromkeys(np.argsort(prods)[::-1][:5].tolist() + np.argsort(clen)[::-1][:3].tolist()))
+        assert prods[top[0]] == prods.max() and int(np.argmax(clen)) in top
         for r in top:
             lo, hi = int(a_ptr[r]), int(a_ptr[r + 1])
             acc = torch.zeros(n, device=dev, dtype=torch.float64)
