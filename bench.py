@@ -574,6 +574,8 @@ def secondary_gram(torch, abi, dev, with_cpu):
         torch.cuda.synchronize()
         if rep:
             times.append(time.perf_counter() - t0)
+        else:
+            first_call = time.perf_counter() - t0
     t = min(times)
     colsq = torch.zeros(ncols, device=dev, dtype=torch.float64)
     for lo in range(0, int(idx.numel()), 1 << 24):  # in pieces: next to the 256 GiB output and the library's tables ~1 GiB is free
@@ -589,6 +591,11 @@ def secondary_gram(torch, abi, dev, with_cpu):
                                                                      ", NARROWER than stated: " + note, ncols, nnz,
                                                                      ncols * ncols * 4 / 2**30),
            "ms": round(t * 1e3, 2), "value": round(flops / t / 1e9, 2), "unit": "GFLOP/s", "dtype": "f32",
+           "first_call_ms": round(first_call * 1e3, 2),
+           "first_call_note": "mi_sparse_s_syrkd on a FRESH handle -- what the public gram_matrix_mkl pays on every call, as it "
+                              "creates its handle per call like the reference (_gram_matrix.py:121-127): the transpose of X "
+                              "(round 5: a stable radix sort of the entries, 2 passes here), the tile tables and the packed "
+                              "records, then the product; `ms` is the product alone on the same handle",
            "roofline": {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes,
                         "note": "nnz * 8 + (M + 1) * 8 + n (n + 1) / 2 * 4 (the triangle written once) over the "
@@ -602,7 +609,7 @@ def secondary_gram(torch, abi, dev, with_cpu):
         import scipy.sparse as sps
         sip, sidx, sval, _ = uniform_csr(torch, 1 << 18, 64, 3, dev, ncols=16384)
         a = sps.csr_matrix((sval.cpu().numpy(), sidx.cpu().numpy(), sip.cpu().numpy()), shape=(1 << 18, 16384))
-        out["cpu_baseline"] = cpu_baseline_gram(a, nrep=1)
+        out["cpu_baseline"] = cpu_baseline_gram(a, nrep=3)
         # the like-for-like partner of that CPU number: the SAME sample (2^18 x 16384, 64/row, dense 1 GiB output) on the GPU
         hs = abi.create("s", sip, sidx, sval, 1 << 18, 16384)
         Cs = torch.zeros((16384, 16384), device=dev, dtype=torch.float32)
@@ -1231,6 +1238,11 @@ def main():
         if world == 1 and with_cpu:
             line["cpu_baseline"] = cpu_baseline_spmm(indptr.cpu().numpy(), indices.cpu().numpy(), vals.cpu().numpy(), n, B.cpu().numpy())
     if rank == 0:
+        if world > 1:  # the three readings of an N-GPU run, labelled, for whoever reads the log (stderr: the contract line stays alone on stdout)
+            for label, key, what in (("value", "value", "end to end: bcast(B) -> local kernels -> all-gatherv(C), what the contract times"),
+                                     ("resident_B_value", "resident_B_value", "B already on every rank: local kernels -> all-gatherv(C)"),
+                                     ("compute_only_value", "compute_only_value", "the local kernels alone, max over ranks")):
+                print("[bench --gpus %d] %-18s %10.2f GFLOP/s   (%s)" % (world, label, line.get(key) or float("nan"), what), file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

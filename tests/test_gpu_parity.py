@@ -637,6 +637,56 @@ def test_transpose_column_histogram_through_lds(gpu, shape):
         assert rel_err(got, want) <= 1e-12
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
+@pytest.mark.parametrize("m,n,per", [(1 << 17, 1 << 18, 20), (40000, 300, 60), (1 << 16, (1 << 20) + 5, 36), (2500, 1 << 24, 900)])
+def test_transpose_stable_radix_sort(gpu, dtype, m, n, per):
+    """Transposes of 2^21 entries and more are a stable radix sort of the entries by column (handle.hip, round 5: two 9-bit
+    passes for 2^18 columns, one pass for 300, three for 2^20 + 5 and for 2^24): the CSC export of a CSR handle equals
+    scipy's canonical tocsc() EXACTLY -- pointers, sorted indices, values -- hub columns, empty columns and a ragged last
+    tile included; option transpose_radix = 0 (histogram + atomic scatter + row sort) gives the same arrays."""
+    from sparse_dot_amd._mi_interface import SparseHandle
+    rng = np.random.default_rng(5)
+    cols = rng.integers(0, n, m * per)
+    cols[rng.choice(m * per, 40000, replace=False)] = 7
+    cols[rng.choice(m * per, 20000, replace=False)] = n - 2
+    vals = rng.uniform(0.5, 1.5, m * per)
+    if np.dtype(dtype).kind == "c":
+        vals = vals + 1j * rng.uniform(0.5, 1.5, m * per)
+    a = sps.coo_matrix((vals.astype(dtype), (np.repeat(np.arange(m), per), cols)), shape=(m, n)).tocsr()
+    a.sort_indices()
+    assert a.nnz >= (1 << 21) and a.nnz % 8192 != 0
+    want = a.tocsc()
+    want.sort_indices()
+    for opt in (1, 0):
+        gpu.mi_set_option("transpose_radix", opt)
+        try:
+            with SparseHandle.from_scipy(a) as h:
+                got = h.export("csc_matrix")
+        finally:
+            gpu.mi_set_option("transpose_radix", 1)
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        assert np.array_equal(got.data, want.data)
+
+
+def test_transpose_stable_radix_sort_keeps_the_order_of_duplicates(gpu):
+    """Unsorted rows with duplicate entries: the transpose keeps both copies of a duplicate, in source order (stable)."""
+    from sparse_dot_amd._mi_interface import SparseHandle
+    rng = np.random.default_rng(6)
+    m, n, per = 70000, 5000, 32
+    ind = rng.integers(0, n, m * per).astype(np.int32)
+    ind[1::per] = ind[0::per]  # a duplicate in every row
+    dat = rng.uniform(0.5, 1.5, m * per)
+    ptr = np.arange(0, m * per + 1, per).astype(np.int32)
+    a = sps.csr_matrix((dat, ind, ptr), shape=(m, n))
+    assert a.nnz == m * per >= 1 << 21 and not a.has_canonical_format
+    with SparseHandle.from_scipy(a) as h:
+        got = h.export("csc_matrix")
+    order = np.argsort(ind, kind="stable")
+    assert np.array_equal(got.indices, np.repeat(np.arange(m), per)[order])
+    assert np.array_equal(got.data, dat[order])
+    assert np.array_equal(got.indptr, np.concatenate([[0], np.cumsum(np.bincount(ind, minlength=n))]))
+
+
 @pytest.mark.parametrize("upper", [False, True])
 def test_spgemm_upper_bound_pass_long_rows_and_narrow_pointer(gpu, upper):
     """Phase 0 (k_row_ub / k_row_ub_long / k_narrow_ptr, round 4): rows of A on both sides of the 512-nonzero limit of the
