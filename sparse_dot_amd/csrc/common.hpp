@@ -607,7 +607,8 @@ struct Options {
     int64_t spgemm_global_mode = 0;  // 0: one workgroup per row, L2-local atomics; 1: cooperative, agent-scope atomics
     int64_t spgemm_group = 1;        // short rows of B (<= 32 entries): one 16-lane group per selected row of B instead of the flat product list (a third of the instructions)
     int64_t spgemm_rank = 0;         // 1: big rows (sorted B, real or complex-float values): the symbolic phase keeps the row bitmaps, the numeric phase accumulates by rank (k_spgemm_rank) and the rows of C come out sorted; 0: range-partitioned LDS hash (k_spgemm_part) -- same kernel time on the literal configs[2] (round 4), without the 128 KiB per big row of stored bitmap
-    int64_t transpose_radix = 1;     // transposes of 2^21 entries and more: stable radix sort of the entries by column (no atomics, no per-row sort afterwards); 0: histogram + atomic scatter + row sort
+    int64_t transpose_radix = 1;     // transposes of 2^21 entries and more: stable radix sort of the entries by column (no atomics, no per-row sort afterwards); 2: the same with tiles of 8192 entries; 0: histogram + atomic scatter + row sort
+    int64_t transpose_radix_bits = 7;  // ... most bits of the column index per pass (4 .. 9): 2^18 columns = 3 passes of 6 bits (8.7 ms for 2.7e8 entries; 2 passes of 9 bits scatter 64-byte runs: 10.8 ms)
     int64_t transpose_lds_hist = 1;  // column histogram of a transpose through LDS ranges (>= 2^22 entries, <= 2^20 columns); 0: one global atomic per entry
     int64_t spgemm_narrow_ptr = 1;   // k_row_ub gathers B's row extents from an int32 copy of its row pointer made per call (nnz(B) < 2^31, >= 2^16 rows): half the table, twice the pointers per line
     int64_t spgemm_onepass = 1;      // products whose rows all fit the small LDS tables: ONE kernel (no symbolic pass), rows placed by a decoupled look-back; 0: always two phases

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(RADIX_THREADS)
 // One tile = RADIX_THREADS x IPT entries; wave w owns the entries [w * 64 IPT, (w + 1) * 64 IPT) of the tile, round r of it the
 // 64 entries from r * 64 on: the order of the entries is (wave, round, lane).  W = the value as an opaque 4- / 8- / 16-byte word.
 template <typename W, int IPT>
-__global__ void __launch_bounds__(RADIX_THREADS)
+__global__ void __launch_bounds__(RADIX_THREADS, IPT <= 4 ? 8 : 4)
     k_radix_scatter(const int32_t* __restrict__ keys_in, const int32_t* __restrict__ rows_in, const W* __restrict__ vals_in,
                     int64_t n, int shift, int bits, int64_t ntiles, const int64_t* __restrict__ offs,
                     int32_t* __restrict__ keys_out, int32_t* __restrict__ rows_out, W* __restrict__ vals_out)
@@ -194,8 +194,8 @@ __global__ void __launch_bounds__(RADIX_THREADS)
     constexpr int NBMAX = 1 << RADIX_MAX_BITS;
     MI_DYN_SMEM(smem);
     // LDS: per-wave digit counters | digit starts inside the tile | digit starts in the output | staged keys | staged payload
-    unsigned* wcnt = reinterpret_cast<unsigned*>(smem);                  // [RADIX_WAVES][NBMAX]
-    unsigned* dstart = wcnt + RADIX_WAVES * NBMAX;                       // [NBMAX + 1]
+    uint16_t* wcnt = reinterpret_cast<uint16_t*>(smem);                  // [RADIX_WAVES][NBMAX]  (a wave's share is 64 IPT <= 512 entries)
+    unsigned* dstart = reinterpret_cast<unsigned*>(wcnt + RADIX_WAVES * NBMAX);  // [NBMAX + 1]
     int64_t* goff = reinterpret_cast<int64_t*>(dstart + NBMAX + 16);     // [NBMAX]
     int32_t* skey = reinterpret_cast<int32_t*>(goff + NBMAX);            // [TILE]
     W* spay = reinterpret_cast<W*>(skey + TILE);                         // [TILE]  (rows reuse it as int32)
@@ -204,12 +204,12 @@ __global__ void __launch_bounds__(RADIX_THREADS)
     const int tid = threadIdx.x, wave = tid / WAVE, lane = tid % WAVE;
     const int64_t t0 = (int64_t)blockIdx.x * TILE;
     const int tile_n = (int)((n - t0) < TILE ? (n - t0) : TILE);
-    for (int k = tid; k < RADIX_WAVES * NBMAX; k += RADIX_THREADS) wcnt[k] = 0u;
+    for (int k = tid; k < RADIX_WAVES * NBMAX; k += RADIX_THREADS) wcnt[k] = (uint16_t)0;
     __syncthreads();
     // ---- phase A: every entry's rank among the entries of its digit inside its wave's share, in order ----
     int32_t key[IPT];
     unsigned rank[IPT];
-    unsigned* mine = wcnt + wave * NBMAX;
+    uint16_t* mine = wcnt + wave * NBMAX;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
     for (int r = 0; r < IPT; ++r) {
@@ -222,9 +222,9 @@ __global__ void __launch_bounds__(RADIX_THREADS)
             const unsigned long long m = __ballot((d >> bit) & 1u);
             same &= ((d >> bit) & 1u) ? m : ~m;
         }
-        const unsigned before = ok ? mine[d] : 0u;
+        const unsigned before = ok ? (unsigned)mine[d] : 0u;
         wave_lds_sync();
-        if (ok && (same & lt) == 0ull) mine[d] = before + (unsigned)__popcll(same);  // the first lane of each digit
+        if (ok && (same & lt) == 0ull) mine[d] = (uint16_t)(before + (unsigned)__popcll(same));  // the first lane of each digit
         wave_lds_sync();
         rank[r] = before + (unsigned)__popcll(same & lt);
     }
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(RADIX_THREADS)
         unsigned run = 0u;
         for (int w = 0; w < RADIX_WAVES; ++w) {
             const unsigned c = wcnt[w * NBMAX + d];
-            wcnt[w * NBMAX + d] = run;
+            wcnt[w * NBMAX + d] = (uint16_t)run;  // < the tile size (<= 8192)
             run += c;
         }
         dstart[d + 1] = run;  // the digit's total, scanned below
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(RADIX_THREADS)
     for (int r = 0; r < IPT; ++r) {
         const int idx = wave * (WAVE * IPT) + r * WAVE + lane;
         const unsigned d = ((unsigned)key[r] >> shift) & dmask;
-        lp[r] = dstart[d] + wcnt[wave * NBMAX + d] + rank[r];
+        lp[r] = dstart[d] + (unsigned)wcnt[wave * NBMAX + d] + rank[r];
         if (idx < tile_n) skey[lp[r]] = key[r];
     }
     __syncthreads();
@@ -721,10 +721,12 @@ static void transpose_radix(char vtype, const Csr& in, Csr& out)
     const int64_t n = in.nnz;
     int total_bits = 1;
     while (((int64_t)1 << total_bits) < in.cols) ++total_bits;
-    const int passes = (total_bits + RADIX_MAX_BITS - 1) / RADIX_MAX_BITS;
+    int max_bits = (int)options().transpose_radix_bits;
+    if (max_bits < 4 || max_bits > RADIX_MAX_BITS) max_bits = RADIX_MAX_BITS;
+    const int passes = (total_bits + max_bits - 1) / max_bits;
     const int bits = (total_bits + passes - 1) / passes;  // even digits: 18 bits = 9 + 9, 20 = 7 + 7 + 7 (the last may be short)
     const size_t vb = value_bytes(vtype);
-    const int ipt = vb >= 16 ? 4 : 8;
+    const int ipt = (vb >= 16 || options().transpose_radix != 2) ? 4 : 8;  // tiles of 4096 entries: two workgroups per CU (option value 2: 8192, one)
     const int tile = RADIX_THREADS * ipt;
     const int64_t ntiles = ceil_div(n, (int64_t)tile);
     // two temporary sets of (key, source row, value); the last pass writes straight into `out`
@@ -744,7 +746,7 @@ static void transpose_radix(char vtype, const Csr& in, Csr& out)
     const int64_t hist_n = ((int64_t)1 << bits) * ntiles;
     int64_t* hist = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(hist_n + 1)));
     int64_t* offs = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(hist_n + 1)));
-    const size_t lds = sizeof(unsigned) * (RADIX_WAVES * (1 << RADIX_MAX_BITS) + (1 << RADIX_MAX_BITS) + 16) +
+    const size_t lds = sizeof(uint16_t) * (RADIX_WAVES * (1 << RADIX_MAX_BITS)) + sizeof(unsigned) * ((1 << RADIX_MAX_BITS) + 16) +
                        sizeof(int64_t) * (1 << RADIX_MAX_BITS) + sizeof(int32_t) * (size_t)tile + vb * (size_t)tile;
     const int32_t* kin = in.col;
     const int32_t* rin = rowidx;
@@ -764,8 +766,10 @@ static void transpose_radix(char vtype, const Csr& in, Csr& out)
             MI_LAUNCH_SMEM((k_radix_scatter<W, IPT>), dim3((unsigned)ntiles), dim3(RADIX_THREADS), lds, c.stream, kin, rin,
                            (const W*)vin, n, shift, pbits, ntiles, (const int64_t*)offs, kout, rout, (W*)vout);
         };
-        if (vb == 4) go(uint32_t{}, std::integral_constant<int, 8>{});
-        else if (vb == 8) go(uint64_t{}, std::integral_constant<int, 8>{});
+        if (vb == 4 && ipt == 8) go(uint32_t{}, std::integral_constant<int, 8>{});
+        else if (vb == 4) go(uint32_t{}, std::integral_constant<int, 4>{});
+        else if (vb == 8 && ipt == 8) go(uint64_t{}, std::integral_constant<int, 8>{});
+        else if (vb == 8) go(uint64_t{}, std::integral_constant<int, 4>{});
         else go(Word16{}, std::integral_constant<int, 4>{});
         kin = kout;
         rin = rout;

@@ -822,6 +822,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.spgemm_rank = value;
         } else if (!strcmp(name, "transpose_radix")) {
             o.transpose_radix = value;
+        } else if (!strcmp(name, "transpose_radix_bits")) {
+            o.transpose_radix_bits = value;
         } else if (!strcmp(name, "transpose_lds_hist")) {
             o.transpose_lds_hist = value;
         } else if (!strcmp(name, "spgemm_narrow_ptr")) {

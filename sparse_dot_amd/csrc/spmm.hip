@@ -1613,6 +1613,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
                           (o.spmm_kpart == 2 || (N * (int64_t)sizeof(T) >= 256 && m.nnz >= ((int64_t)1 << 22) &&
                                                  (double)m.cols * (double)N * (double)sizeof(T) >= 64.0 * 1048576.0));
     bool hold_hot = false;
+    std::shared_ptr<SpmmKpart> kp_keep;  // this call's reference: another host thread may drop the plan (set_values) meanwhile
     if (kp_shape) {
         std::lock_guard<std::mutex> lk(h->mtx);
         if (p.kpart_state == 2 && (p.kpart->P != (int)o.spmm_kpart_parts || p.kpart->min_row != o.spmm_kpart_min_row))
@@ -1620,9 +1621,16 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         if (p.kpart_state == 2) p.kpart->tslices = (int)o.spmm_kpart_tslices;
         if (p.kpart_state == 0 && (p.uses >= 2 || o.spmm_plan_sync || o.spmm_kpart == 2)) build_kpart(p, m, h->vtype);
         hold_hot = p.kpart_state != 1;
+        if (p.kpart_state == 2) {
+            // the partial rows (one per long row and partition) live in the scratch arena: not for operands so wide that
+            // they would take a real share of the device
+            size_t free_b = 0, total_b = 0;
+            MI_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            if ((double)p.kpart->cat.rows * (double)N * (double)sizeof(T) <= (double)total_b / 8.0) kp_keep = p.kpart;
+        }
     }
-    if (kp_shape && p.kpart_state == 2) {
-        SpmmKpart& kp = *p.kpart;
+    if (kp_keep) {
+        SpmmKpart& kp = *kp_keep;
         counters().spmm_last_kpart = (double)kp.P;
         counters().spmm_kpart_long_share = m.nnz ? (double)kp.nnz_long / (double)m.nnz : 0.0;
         // short rows, row-owned, straight into C (the long rows are empty there: they get beta * C)
