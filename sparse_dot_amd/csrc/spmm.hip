@@ -2,7 +2,7 @@
 // Replaces mkl_sparse_?_mm / mkl_sparse_?_mv (reference sparse_dot_mkl/_sparse_dense.py:111-123,
 // _sparse_vector.py:87-95).
 //
-// Kernel design (gfx950, 64-lane waves)
+// Kernel design (gfx950, 64-lane waves) -- DESIGN.md section 3.1
 // -------------------------------------
 // Work decomposition is nnz+row balanced ("merge path"): the sequence of all nonzeros with one
 // extra "row end" item after every row has nnz + rows items; wave w takes items
@@ -10,16 +10,18 @@
 // output row exactly once with plain stores (no atomics, no pre-zeroing of C: empty rows are
 // just row-end items).  A row cut by a chunk boundary leaves a partial sum ("carry") in a small
 // workspace (one N-vector per wave at most); a second tiny kernel adds the carries of a row, in
-// chunk order, to the owner's output -> results are deterministic run to run.  Skewed (R-MAT)
-// rows of 64 k nonzeros therefore spread over ~250 waves instead of one.
+// chunk order, to the owner's output -> results are deterministic run to run.
 //
 // Inside a wave the lanes span the DENSE dimension: LPN lanes x V values (16 bytes per lane when
-// the layout allows: one global_load_dwordx4) cover one row of B, so every B-row read is a
-// fully coalesced 16*LPN-byte segment; the 64/LPN lane groups of the wave work on different
-// nonzeros of the same output row and are combined with xor-shuffles at the row end.  The wave's
-// slice of A (column indices, values, row ends) is staged once in LDS with coalesced loads and
-// then broadcast-read; B rows go straight from L2/HBM to registers (there is no intra-workgroup
-// reuse of a B row to stage for -- see DESIGN.md), U independent loads in flight per lane.
+// the layout allows) cover one row of B, so every B-row read is a fully coalesced 16*LPN-byte
+// segment; the 64/LPN lane groups take consecutive nonzeros.  The wave's slice of A is staged once
+// in LDS and then streamed NG x U nonzeros at a time across row ends (k_spmm_flat, round 5; k_spmm
+// walks row by row).  B rows go straight from L2/HBM to registers: a B row is used by exactly one
+// nonzero of a workgroup, there is nothing to stage.
+//
+// Which rows of B an XCD's private 4 MB L2 holds is the lever (round 5): rows of A with many
+// entries are split by part(column) into 8 sub-rows, partition p is multiplied on XCD p only
+// (SpmmKpart / SpmmParts), the partial rows are combined in a fixed order (k_kp_combine).
 #include <algorithm>
 
 #include "common.hpp"
