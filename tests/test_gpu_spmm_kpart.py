@@ -171,3 +171,50 @@ def test_flat_walk_equals_row_walk_within_tolerance(gpu, oracle, dtype, n, flat)
     assert rel_err(got, want) <= tol(dtype)
     np.testing.assert_allclose(got2, want + 0.5, rtol=10 * tol(dtype), atol=10 * tol(dtype))
     assert not got[8:40].any()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_spmm_randomised_shapes_both_walks_and_partitions(gpu, oracle, seed):
+    """Seeded random sweep over what the SpMM kernels branch on: rows / columns / widths (vector and scalar paths, every
+    lane-group width), row-length mixes (empty runs, rows of exactly the cut length 128 / 129, hub rows over many chunks),
+    chunk size, alpha / beta, dtype -- the streaming walk, the row-by-row walk and the column-partitioned form must all
+    equal the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    dtype = [np.float32, np.float64, np.complex64, np.complex128][seed % 4]
+    m = int(rng.integers(1, 3000))
+    k = int(rng.integers(1, 5000))
+    n = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 24, 32, 48, 64, 100, 128, 192, 256, 320, 512]))
+    lens = rng.integers(0, min(k, 40) + 1, m)
+    for _ in range(int(rng.integers(0, 6))):
+        lens[int(rng.integers(0, m))] = min(k, int(rng.choice([127, 128, 129, 255, 256, 257, 1000, 4000])))
+    if m > 50:
+        s = int(rng.integers(0, m - 40))
+        lens[s:s + 40] = 0
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens] + [np.empty(0, np.int64)]).astype(np.int32)
+    data = rng.uniform(0.5, 1.5, indices.size)
+    if np.dtype(dtype).kind == "c":
+        data = data + 1j * rng.uniform(0.5, 1.5, indices.size)
+    a = sps.csr_matrix((data.astype(dtype), indices, indptr), shape=(m, k))
+    b = dense((k, n), dtype, 2000 + seed)
+    want = oracle.spmm(a.astype(wide(dtype)), b.astype(wide(dtype)))
+    chunk = int(rng.choice([128, 256, 512, 1024]))
+    beta = float(rng.choice([0.0, 0.5, -1.25]))
+    c0 = dense((m, n), dtype, 3000 + seed)
+    for opts in (dict(spmm_flat=1), dict(spmm_flat=0), dict(spmm_flat=1, spmm_kpart=2, spmm_kpart_min_row=int(rng.choice([2, 8, 32, 128])),
+                                                            spmm_kpart_parts=int(rng.choice([8, 4, 2])))):
+        gpu.mi_set_option("spmm_chunk", chunk)
+        for name, value in opts.items():
+            gpu.mi_set_option(name, value)
+        try:
+            got = gpu.dot_product_mkl(a, b)
+            out = c0.copy()
+            got2 = gpu.dot_product_mkl(a, b, out=out, out_scalar=beta) if beta else None
+        finally:
+            for name, value in dict(spmm_chunk=256, spmm_flat=1, spmm_kpart=1, spmm_kpart_min_row=128, spmm_kpart_parts=8).items():
+                gpu.mi_set_option(name, value)
+        if n == 1:
+            got = got.reshape(m, 1)
+        assert got.shape == (m, n) and rel_err(got, want) <= tol(dtype), (opts, rel_err(got, want))
+        if got2 is not None:
+            np.testing.assert_allclose(got2, want + beta * c0.astype(wide(dtype)), rtol=20 * tol(dtype), atol=20 * tol(dtype))
