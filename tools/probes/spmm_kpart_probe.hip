@@ -22,7 +22,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int CH = 256;
 
-struct Parts { long cs[9]; };  // chunk range of partition p: [cs[p], cs[p + 1])
+struct Parts { long cs[33]; long nblk; };  // chunk range of partition p: [cs[p], cs[p + 1]); PART = 2: workgroups per XCD and phase
 
 // PART = 0: k_spmm's mapping (S column slices, every XCD sees every chunk of its slice set)
 // PART = 1: P = 8 / slices partitions; XCD x = b & 7 -> partition x % P, slice x / P; chunk = cs[p] + (b >> 3) * 4 + wave
@@ -35,7 +35,12 @@ __global__ void __launch_bounds__(256, 8) k_gather(const float* __restrict__ B, 
     long w;
     int jlo = 0;
     const int xcd = (int)(blockIdx.x & 7u);
-    if (PART) {
+    if (PART == 2) {  // 8 * phases partitions: XCD x takes partitions x, x + 8, ... one after the other (blocks are dispatched in order)
+        const long bi = (long)(blockIdx.x >> 3);
+        const int p = xcd + 8 * (int)(bi / parts.nblk);
+        w = parts.cs[p] + (bi % parts.nblk) * 4 + wib;
+        if (w >= parts.cs[p + 1]) return;
+    } else if (PART) {
         const int P = 8 / slices, p = xcd % P;
         jlo = (xcd / P) * (128 / slices);
         w = parts.cs[p] + (long)(blockIdx.x >> 3) * 4 + wib;
@@ -80,6 +85,46 @@ __global__ void __launch_bounds__(256, 8) k_gather(const float* __restrict__ B, 
     if (acc.x == 12345.678f) out[w * 64 + lane] = acc;
 }
 
+// Persistent 1024-thread workgroups (one per CU), the H most referenced rows of B of the workgroup's partition copied into LDS
+// once: an index with bit 30 set is (bit 30 | slot) and is served from that copy -- it never reaches the L2.
+template <int U>
+__global__ void __launch_bounds__(1024) k_gather_lds(const float* __restrict__ B, const int* __restrict__ idx, Parts parts, long nidx,
+                                                     const int* __restrict__ hot_list, int H, f4* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f4* cache = reinterpret_cast<f4*>(smem);  // [H][32] pieces of 16 bytes
+    const int xcd = (int)(blockIdx.x & 7u), p = xcd;
+    const int tid = threadIdx.x, lane = tid % 64, wave = tid / 64;
+    for (int i = tid; i < H * 32; i += 1024) {
+        const int row = hot_list[p * H + i / 32];
+        cache[i] = *reinterpret_cast<const f4*>(B + (long)row * 128 + (i % 32) * 4);
+    }
+    __syncthreads();
+    const int g = lane / 32, li = lane % 32;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0xffffffff, 0x00020000);
+    const long wgx = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long w = parts.cs[p] + wgx * 16 + wave; w < parts.cs[p + 1]; w += nwg * 16) {
+        const int* my = idx + w * CH;
+        const long left = nidx - w * CH;
+        const int len = left < CH ? (int)left : CH;
+        for (int q = g; q < len; q += 2 * U) {
+            int t[U];
+            f4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) t[u] = my[q + 2 * u < len ? q + 2 * u : len - 1];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t[u] & 0x40000000) v[u] = cache[(t[u] & 0xffff) * 32 + li];
+                else v[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)t[u] * 128u + (unsigned)li * 4u) * 4u, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        }
+    }
+    if (acc.x == 12345.678f) out[blockIdx.x * 1024 + tid] = acc;
+}
+
 static std::vector<int> g_cols;
 static std::vector<long> g_ptr;
 static std::vector<unsigned> g_cnt;
@@ -115,11 +160,14 @@ static void make_rmat(int scale, int per_row)
 }
 
 template <int LPN, int U, int PART>
-static void launch(int aux, const float* B, const int* idx, long nidx, int slices, const Parts& parts, f4* out)
+static void launch(int aux, const float* B, const int* idx, long nidx, int slices, const Parts& parts, f4* out)  // (slices by value below)
 {
     const long nchunks = (nidx + CH - 1) / CH;
     unsigned grid;
-    if (PART) {
+    if (PART == 2) {
+        grid = (unsigned)(parts.nblk * (long)slices) * 8u;  // `slices` carries the number of phases here
+        slices = 1;
+    } else if (PART) {
         long mx = 0;
         for (int p = 0; p < 8 / slices; ++p) mx = std::max(mx, parts.cs[p + 1] - parts.cs[p]);
         grid = (unsigned)((mx + 3) / 4) * 8u;
@@ -264,6 +312,80 @@ int main(int argc, char** argv)
                     }
                 }
             }
+        }
+    }
+    // ---- LDS copy of the hottest rows of each partition (persistent workgroups) ----
+    {
+        const int T = 128, P = 8;
+        std::vector<std::vector<int>> part(P);
+        auto pf = [&](int c) { return (int)(((unsigned)c * 0x9E3779B1u) >> 16) % P; };
+        for (long r = 0; r < n; ++r) {
+            const long b = g_ptr[r], e = g_ptr[r + 1];
+            if (e - b >= T)
+                for (long i = b; i < e; ++i) part[pf(g_cols[i])].push_back(g_cols[i]);
+        }
+        int* d_hot;
+        CK(hipMalloc(&d_hot, 8 * 256 * 4));
+        for (int H : {0, 64, 128, 192, 240}) {
+            for (int U : {4, 8}) {
+                // the H most referenced columns of every partition (by the global count) -> slots
+                std::vector<int> hot(8 * 256, 0), slot(n, -1);
+                int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (long k = 0; k < n; ++k) {
+                    const int c = order[k], q = pf(c);
+                    if (cnt[q] < H) { slot[c] = cnt[q]; hot[q * H + cnt[q]] = c; ++cnt[q]; }
+                }
+                std::vector<int> cat;
+                Parts ps{};
+                long served = 0, all = 0;
+                for (int q = 0; q < P; ++q) {
+                    ps.cs[q] = (long)cat.size() / CH;
+                    for (int c : part[q]) { cat.push_back(slot[c] >= 0 ? (0x40000000 | slot[c]) : c); served += slot[c] >= 0; ++all; }
+                    while (cat.size() % CH) cat.push_back(cat.back());
+                }
+                ps.cs[P] = (long)cat.size() / CH;
+                CK(hipMemcpy(d_a, cat.data(), cat.size() * 4, hipMemcpyHostToDevice));
+                CK(hipMemcpy(d_hot, hot.data(), hot.size() * 4, hipMemcpyHostToDevice));
+                const long ncat = (long)cat.size();
+                snprintf(nm, sizeof nm, "T=128 P=8 persistent 1024-thread workgroups, LDS copy of %d rows per partition, U=%d", H, U);
+                const float tl = timed(nm, [&] {
+                    if (U == 4) hipLaunchKernelGGL((k_gather_lds<4>), dim3(256), dim3(1024), (size_t)H * 512, 0, B, d_a, ps, ncat, d_hot, H, out);
+                    else hipLaunchKernelGGL((k_gather_lds<8>), dim3(256), dim3(1024), (size_t)H * 512, 0, B, d_a, ps, ncat, d_hot, H, out);
+                }, 1);
+                printf("    => long %.3f ms; %.1f %% of the long-row references served from LDS\n", tl, 100.0 * served / all);
+            }
+        }
+    }
+    // ---- more partitions than XCDs: 8 * phases partitions, XCD x takes x, x + 8, ... in time ----
+    for (int T : {128, 256, 512}) {
+        for (int phases : {1, 2, 4}) {
+            const int P = 8 * phases;
+            std::vector<std::vector<int>> part(P);
+            long n_long = 0;
+            auto pf = [&](int c) { return (int)(((unsigned)c * 0x9E3779B1u) >> 16) % P; };
+            for (long r = 0; r < n; ++r) {
+                const long b = g_ptr[r], e = g_ptr[r + 1];
+                if (e - b >= T) {
+                    ++n_long;
+                    for (long i = b; i < e; ++i) part[pf(g_cols[i])].push_back(g_cols[i]);
+                }
+            }
+            std::vector<int> cat;
+            Parts ps{};
+            long mx = 0;
+            for (int p = 0; p < P; ++p) {
+                ps.cs[p] = (long)cat.size() / CH;
+                for (int c : part[p]) cat.push_back(c);
+                while (cat.size() % CH) cat.push_back(cat.back());
+                mx = std::max(mx, (long)cat.size() / CH - ps.cs[p]);
+            }
+            ps.cs[P] = (long)cat.size() / CH;
+            ps.nblk = (mx + 3) / 4;
+            CK(hipMemcpy(d_a, cat.data(), cat.size() * 4, hipMemcpyHostToDevice));
+            const long ncat = (long)cat.size();
+            snprintf(nm, sizeof nm, "T=%d %d partitions (%d phases per XCD) long pass S=1", T, P, phases);
+            const float tl = timed(nm, [&] { launch<32, 4, 2>(0, B, d_a, ncat, phases, ps, out); }, 1);
+            printf("    => long %.3f ms, %ld long rows, partial rows %.0f MB written + read\n", tl, n_long, 2.0 * n_long * P * 512.0 / 1e6);
         }
     }
     return 0;
