@@ -527,6 +527,7 @@ struct SpmmKpart {
     int P = 0;            // column partitions (8, 4 or 2); the dense operand is cut into 8 / P column slices on top
     int tslices = 1;      // ... times this many passes in time, one column slice each (SpmmParts, spmm.hip)
     int64_t min_row = 0;  // rows of at least this many entries are partitioned
+    int64_t chunk = 0;    // spmm_chunk the chunk ranges cs[] were computed for
     int64_t n_long = 0, nnz_long = 0;
     Csr cat;              // rows = P * n_long (block p = partition p, rows in the order of rowid), cols = A's
     Csr shrt;             // rows = A's, entries of the short rows only

@@ -1364,6 +1364,7 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
     const int64_t n_long = exclusive_scan_i64(flag, lidx, m.rows);
     auto kp = std::make_shared<SpmmKpart>();
     kp->P = P;
+    kp->chunk = o.spmm_chunk;
     kp->tslices = (int)o.spmm_kpart_tslices;
     kp->min_row = min_row;
     kp->n_long = n_long;
@@ -1618,8 +1619,9 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     std::shared_ptr<SpmmKpart> kp_keep;  // this call's reference: another host thread may drop the plan (set_values) meanwhile
     if (kp_shape) {
         std::lock_guard<std::mutex> lk(h->mtx);
-        if (p.kpart_state == 2 && (p.kpart->P != (int)o.spmm_kpart_parts || p.kpart->min_row != o.spmm_kpart_min_row))
-            p.kpart_state = 0;  // the options changed (tools): build again
+        if (p.kpart_state == 2 && (p.kpart->P != (int)o.spmm_kpart_parts || p.kpart->min_row != o.spmm_kpart_min_row ||
+                                   p.kpart->chunk != o.spmm_chunk))
+            p.kpart_state = 0;  // the options changed (tools; the partitions' chunk ranges follow spmm_chunk): build again
         if (p.kpart_state == 2) p.kpart->tslices = (int)o.spmm_kpart_tslices;
         if (p.kpart_state == 0 && (p.uses >= 2 || o.spmm_plan_sync || o.spmm_kpart == 2)) build_kpart(p, m, h->vtype);
         hold_hot = p.kpart_state != 1;

@@ -112,12 +112,18 @@ def test_kpart_adopted_on_third_product_and_dropped_by_set_values(gpu, oracle):
         got = gpu.dot_product_mkl(A, b)
         assert rel_err(got, 1.25 * want) <= F32_TOL
         assert gpu.mi_get_counter("spmm_last_kpart") == 8.0
+        # another chunk size on a handle that already holds the partitioned plan: its chunk ranges are rebuilt
+        for chunk in (128, 1024, 256):
+            gpu.mi_set_option("spmm_chunk", chunk)
+            got = gpu.dot_product_mkl(A, b)
+            assert gpu.mi_get_counter("spmm_last_kpart") == 8.0 and rel_err(got, 1.25 * want) <= F32_TOL, chunk
         gpu.mi_set_option("deterministic", 1)
         got = gpu.dot_product_mkl(A, b)
         assert gpu.mi_get_counter("spmm_last_kpart") == 0.0 and rel_err(got, 1.25 * want) <= F32_TOL
         A.free()
     finally:
         gpu.mi_set_option("deterministic", 0)
+        gpu.mi_set_option("spmm_chunk", 256)
         gpu.mi_set_option("spmm_kpart", 1)
         gpu.mi_set_option("spmm_kpart_min_row", 128)
 
