@@ -362,6 +362,9 @@ def measure_traffic_child(child_args, calls, include, exclude=("k_spmv", "k_spmm
         if not need_free_bytes:
             return
         import torch
+        import sparse_dot_amd as sda
+        sda.mi_set_option("pool_trim", 1)  # this process's cached device blocks and scratch arena back to the driver: the child needs them
+        torch.cuda.empty_cache()
         for _ in range(80):
             if torch.cuda.mem_get_info()[0] >= need_free_bytes:
                 return
@@ -595,7 +598,9 @@ def secondary_gram(torch, abi, dev, with_cpu):
            "first_call_note": "mi_sparse_s_syrkd on a FRESH handle -- what the public gram_matrix_mkl pays on every call, as it "
                               "creates its handle per call like the reference (_gram_matrix.py:121-127): the transpose of X "
                               "(round 5: a stable radix sort of the entries, 2 passes here), the tile tables and the packed "
-                              "records, then the product; `ms` is the product alone on the same handle",
+                              "records, then the product; `ms` is the product alone on the same handle.  Device kernels of the first call: ~68 ms "
+                              "(profiles/r05_gram_first_call_kernel_stats.log); the rest is hipMalloc of ~16 GB of transpose scratch and "
+                              "tables, whose cost depends on whether the driver hands out recycled pages (NOTEBOOK 3.2, alloc probe)",
            "roofline": {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes,
                         "note": "nnz * 8 + (M + 1) * 8 + n (n + 1) / 2 * 4 (the triangle written once) over the "

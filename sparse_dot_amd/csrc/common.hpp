@@ -368,6 +368,8 @@ struct Context {
     std::vector<DevBuf> retired;  // old arenas kept alive until the next synchronise
     void ensure();                // lazy HIP init for this host thread
     void* scratch_alloc(size_t bytes);  // 256-B aligned slice, valid until scratch_reset()
+    void scratch_reserve(size_t bytes);  // room for `bytes` more, grown once and exactly
+    void scratch_release();              // synchronise and give the arena back
     void scratch_reset() { scratch_used = 0; }
     void sync();
 };

@@ -734,6 +734,9 @@ static void transpose_radix(char vtype, const Csr& in, Csr& out)
     int32_t* row_t[2] = {nullptr, nullptr};
     void* val_t[2] = {nullptr, nullptr};
     const int ntmp = passes > 2 ? 2 : passes - 1;
+    const int64_t hist_len = ((int64_t)1 << bits) * ntiles;
+    c.scratch_reserve(sizeof(int32_t) * (size_t)n * 3 + (sizeof(int32_t) + vb) * (size_t)n * (size_t)ntmp +
+                      sizeof(int64_t) * 2 * (size_t)(hist_len + 1) + sizeof(int64_t) * (size_t)(hist_len / 1024 + 64) + 16 * 256);
     for (int k = 0; k < 2; ++k) {
         key_t[k] = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)n));  // the final keys too (row pointer)
         if (k < ntmp) {

@@ -291,6 +291,28 @@ void* Context::scratch_alloc(size_t bytes)
     return static_cast<char*>(scratch.p) + off;
 }
 
+// make room for `bytes` more in ONE step and at their exact size (a caller that knows its total: the doubling above would
+// retire 1 + 2 + 4 + ... GB arenas on the way to 8 -- and keep them until the next synchronise)
+void Context::scratch_reserve(size_t bytes)
+{
+    ensure();
+    const size_t off = (scratch_used + 255) & ~size_t(255);
+    const size_t need = off + bytes + 4096;
+    if (need <= scratch.bytes) return;
+    retired.push_back(std::move(scratch));
+    scratch.alloc(need);
+    scratch_used = 0;
+}
+
+// give the arena back (option pool_trim): the next call starts a new one
+void Context::scratch_release()
+{
+    if (!initialised) return;
+    sync();
+    scratch.release();
+    scratch_used = 0;
+}
+
 void Context::sync()
 {
     ensure();
@@ -838,6 +860,7 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             mi::pool_trim();
             mi::pool_reset_cap();
         } else if (!strcmp(name, "pool_trim")) {
+            mi::ctx().scratch_release();  // this thread's scratch arena too (it only ever grows otherwise)
             mi::pool_trim();
         } else if (!strcmp(name, "trace_phases")) {
             o.trace_phases = value;

@@ -4,6 +4,7 @@
 #   tests[:<pytest -k expression>]   pytest -m gpu (the whole suite, or the selected tests) with durations
 #   bench                            python bench.py --steps 20 --warmup 5   (what the driver runs; secondaries + live counter traffic)
 #   stats                            rocprofv3 --kernel-trace --stats of bench.py (headline only / secondaries only)
+#   kpart-shapes | gram-first         round 5: SpMM partitioned vs row-owned across shapes; kernels of a first dense gram call
 #   pmc-kpart[:variant]              the same for tools/gpu_kpart.py (column-partitioned SpMM; variant e.g. 128:8 or off)
 #   pmc-spmm | pmc-gram | pmc-spgemm separate rocprofv3 --pmc passes for the headline SpMM kernel / the dense gram kernel / every SpGEMM kernel of the
 #                                    literal and the uniform configs[2] (tools/pmc_kernels.py)
@@ -43,6 +44,10 @@ PY
       cp $(find $O/st2 -name "*kernel_stats.csv" | head -1) $O/secondary_kernel_stats.csv; rm -rf $O/st2; head -8 $O/secondary_kernel_stats.csv | cut -c1-160 ;;
     pmc-spmm) pmc pmc_spmm python $R/tools/spmm_sweep.py --launches 5 --variants 0:8192:256 --adopt-tags ;;
     pmc-kpart*) v=${step#pmc-kpart}; v=${v#:}; pmc pmc_kpart python $R/tools/gpu_kpart.py --variants ${v:-128:8} --launches 5 --warm 6 ;;
+    kpart-shapes)  # the column-partitioned SpMM against the row-owned kernel across widths, dtypes and sizes
+      { for a in "--ncols 128" "--ncols 256" "--ncols 64" "--dtype f64 --ncols 128" "--scale 22 --launches 5" "--workload uniform"; do echo "## $a"; timeout 500 python tools/gpu_kpart.py $a --variants "off,default" 2>&1 | grep "variant\|workload" | cut -c1-330; done; } > $O/spmm_kpart_shapes.log; cat $O/spmm_kpart_shapes.log | cut -c1-140 ;;
+    gram-first)  # kernels of the FIRST dense gram on a fresh handle (transpose, tables) at the literal configs[3]
+      ( cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gf -o s -- python $R/tools/bench_ops.py gram --dense --cols 262144 --rows-log2 22 --reps 1 > $O/gf.log 2>&1 ); python tools/kstats.py $O/gf > $O/gram_first_call_kernel_stats.log; rm -rf $O/gf; head -12 $O/gram_first_call_kernel_stats.log ;;
     pmc-gram) pmc pmc_gram python $R/tools/bench_ops.py gram --dense --cols 262144 --rows-log2 22 --reps 1 ;;
     pmc-spgemm) pmc pmc_spgemm_literal python $R/tools/bench_ops.py spgemm --kind rmat --scale 20 --per-row 16 --no-order --reps 1
                 pmc pmc_spgemm_uniform python $R/tools/bench_ops.py spgemm --no-order --reps 2 ;;
