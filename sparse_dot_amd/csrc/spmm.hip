@@ -1613,7 +1613,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
                           (N / kp_slices) * (int64_t)sizeof(T) >= 64 && (ldb * (int64_t)sizeof(T)) % 16 == 0 &&
                           (ldc * (int64_t)sizeof(T)) % 16 == 0 && (reinterpret_cast<uintptr_t>(B) % 16) == 0 &&
                           (reinterpret_cast<uintptr_t>(C) % 16) == 0 &&
-                          (o.spmm_kpart == 2 || (N * (int64_t)sizeof(T) >= 256 && m.nnz >= ((int64_t)1 << 22) &&
+                          (o.spmm_kpart == 2 || (N * (int64_t)sizeof(T) >= 256 && m.nnz >= ((int64_t)1 << 21) &&
                                                  (double)m.cols * (double)N * (double)sizeof(T) >= 64.0 * 1048576.0));
     bool hold_hot = false;
     std::shared_ptr<SpmmKpart> kp_keep;  // this call's reference: another host thread may drop the plan (set_values) meanwhile

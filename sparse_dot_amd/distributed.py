@@ -34,18 +34,34 @@ import numpy as _np
 from scipy import sparse as _sps
 
 
-def partition_rows(indptr, nparts):
-    """Contiguous row blocks balanced by (nnz + rows) work items, the unit the SpMM kernel balances
-    on.  Returns nparts + 1 boundaries b with b[0] = 0, b[-1] = nrows, non-decreasing."""
+# cost of one row of the left matrix in the SpMM, in units of one entry of a long row -- fitted to the kernels' times on the
+# eight row blocks of the headline R-MAT (tools/gpu_kpart_blocks.py, round 5): a row costs 3.3 units whatever it holds (its
+# output row is written, its row-end is walked), an entry of a short row 1.6 (row-owned gather, L2 hit ~0.48), an entry of a
+# row of >= 128 entries 1.0 (gathered by column partition, L2 hit ~0.66)
+_ROW_COST, _SHORT_ENTRY_COST, _LONG_ROW = 3.3, 1.6, 128
+
+
+def partition_rows(indptr, nparts, model="kernel"):
+    """Contiguous row blocks of (nearly) equal COST.  model "kernel" (default): the SpMM cost model above -- what makes the
+    ranks' local products take the same time; model "items": nnz + rows, the kernel's raw work items (the rule of rounds
+    1-4, under which the rank holding the many short rows of a power-law matrix finished last).  Returns nparts + 1
+    boundaries b with b[0] = 0, b[-1] = nrows, non-decreasing."""
     indptr = _np.asarray(indptr, dtype=_np.int64)
     nrows = indptr.shape[0] - 1
     if nparts < 1:
         raise ValueError("nparts must be positive")
-    work = indptr[1:] - indptr[0] + _np.arange(1, nrows + 1, dtype=_np.int64)  # items up to and incl. row i
-    total = int(work[-1]) if nrows else 0
+    if model not in ("kernel", "items"):
+        raise ValueError("model must be 'kernel' or 'items'")
+    lens = _np.diff(indptr)
+    if model == "items":
+        cost = lens + 1
+    else:
+        cost = _ROW_COST + lens * _np.where(lens >= _LONG_ROW, 1.0, _SHORT_ENTRY_COST)
+    work = _np.cumsum(cost)  # cost up to and incl. row i
+    total = float(work[-1]) if nrows else 0.0
     bounds = [0]
     for p in range(1, nparts):
-        target = total * p // nparts
+        target = total * p / nparts
         bounds.append(int(_np.searchsorted(work, target, side="left")) if nrows else 0)
     bounds.append(nrows)
     for i in range(1, len(bounds)):  # monotone even for degenerate inputs

@@ -227,11 +227,19 @@ def test_partition_rows_balances_work():
     lens[17] = 20000  # hub row
     indptr = np.concatenate([[0], np.cumsum(lens)])
     for parts in (1, 2, 3, 8):
-        b = partition_rows(indptr, parts)
+        b = partition_rows(indptr, parts, model="items")
         assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b) >= 0) and len(b) == parts + 1
         work = [(indptr[b[i + 1]] - indptr[b[i]]) + (b[i + 1] - b[i]) for i in range(parts)]
         # no block exceeds the ideal share by more than the largest single row
         assert max(work) <= (indptr[-1] + 1000) / parts + 20001
+        # the default: equal COST under the SpMM model (a row 3.3, a short-row entry 1.6, a long-row entry 1.0)
+        b = partition_rows(indptr, parts)
+        assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b) >= 0) and len(b) == parts + 1
+        row_cost = 3.3 + lens * np.where(lens >= 128, 1.0, 1.6)
+        cost = [row_cost[b[i]:b[i + 1]].sum() for i in range(parts)]
+        assert max(cost) <= row_cost.sum() / parts + row_cost.max() + 1e-6
+    with pytest.raises(ValueError):
+        partition_rows(indptr, 2, model="nope")
     assert partition_rows(np.array([0]), 4).tolist() == [0, 0, 0, 0, 0]
     a = sps.random(50, 20, density=0.3, format="csr", random_state=0)
     blk = row_block(a, 10, 35)
