@@ -1438,6 +1438,7 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     counters().spmm_kpart_build_ms += ms;
+    kp->plan_short.uses = 1;  // the handle has proven its reuse: the short rows' hot / cold analysis follows their FIRST product
     p.kpart = std::move(kp);
     p.kpart_state = 2;
 }
