@@ -850,6 +850,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.transpose_lds_hist = value;
         } else if (!strcmp(name, "spgemm_narrow_ptr")) {
             o.spgemm_narrow_ptr = value;
+        } else if (!strcmp(name, "spgemm_sort_ingest")) {
+            o.spgemm_sort_ingest = value;
         } else if (!strcmp(name, "spgemm_onepass")) {
             o.spgemm_onepass = value;
         } else if (!strcmp(name, "pool_enable")) {

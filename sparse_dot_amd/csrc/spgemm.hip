@@ -2860,6 +2860,33 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
 {
     SpgemmSymbolic st;
     SpgemmBounds bd = spgemm_bounds<T>(A, B, upper, C, st);
+    // Sort on ingest (round 5): rows too long for the LDS hash tables need B's rows in column order (the bitmap path cuts
+    // them into column ranges by search); with unsorted rows they fell to the global-memory hash -- correct, and several
+    // times slower.  mkl_sparse_spmm takes unsorted input without penalty (reference _sparse_sparse.py:35-40), so: a sorted
+    // COPY of B for this product (B itself may alias caller memory and is never reordered behind the caller's back).
+    if (!st.big.b_sorted && bd.max_ub > 4096 && options().spgemm_sort_ingest && B.nnz > 0) {
+        Context& c = ctx();
+        Csr Bs;
+        Bs.rows = B.rows;
+        Bs.cols = B.cols;
+        Bs.nnz = B.nnz;
+        Bs.ptr = B.ptr;  // rows keep their extents
+        Bs.col_own.alloc(sizeof(int32_t) * (size_t)B.nnz);
+        Bs.val_own.alloc(sizeof(T) * (size_t)B.nnz);
+        Bs.col = Bs.col_own.as<int32_t>();
+        Bs.val = Bs.val_own.p;
+        MI_HIP_CHECK(hipMemcpyAsync(Bs.col, B.col, sizeof(int32_t) * (size_t)B.nnz, hipMemcpyDeviceToDevice, c.stream));
+        MI_HIP_CHECK(hipMemcpyAsync(Bs.val, B.val, sizeof(T) * (size_t)B.nnz, hipMemcpyDeviceToDevice, c.stream));
+        Bs.valid = true;
+        sort_csr(type_char<T>::value, Bs);
+        SpgemmSymbolic st2;
+        SpgemmBounds bd2 = spgemm_bounds<T>(A, Bs, upper, C, st2);
+        if (spgemm_onepass<T>(A, Bs, C, st2, bd2)) return;
+        spgemm_symbolic<T>(A, Bs, C, st2, bd2);
+        spgemm_numeric<T>(A, Bs, C, st2, &bd2);
+        c.sync();  // Bs is released on return
+        return;
+    }
     if (spgemm_onepass<T>(A, B, C, st, bd)) return;
     spgemm_symbolic<T>(A, B, C, st, bd);
     spgemm_numeric<T>(A, B, C, st, &bd);

@@ -1013,6 +1013,39 @@ def _hub_case(kind):
     raise KeyError(kind)
 
 
+def test_spgemm_unsorted_b_is_sorted_on_ingest(gpu):
+    """B with shuffled rows and hub rows in the product: the library multiplies by a sorted COPY of B (round 5; the global-memory
+    hash before) -- same structure as with the sorted B, values to 1e-12, B's own arrays untouched; option spgemm_sort_ingest = 0
+    is the old path.  mkl_sparse_spmm takes unsorted input without penalty (reference _sparse_sparse.py:35-40)."""
+    rng = np.random.default_rng(77)
+    n = 1 << 14
+    deg = np.minimum((n / (np.arange(n) + 1.0) ** 0.8).astype(np.int64) + 2, n // 2)  # power-law rows: the first ones are hubs
+    def mat(seed):
+        r = np.random.default_rng(seed)
+        ptr = np.concatenate([[0], np.cumsum(deg)])
+        ind = np.concatenate([np.sort(r.choice(n, d, replace=False)) for d in deg]).astype(np.int32)
+        return sps.csr_matrix((r.uniform(0.5, 1.5, ind.size), ind, ptr), shape=(n, n))
+    a, b = mat(1), mat(2)
+    ind, dat = b.indices.copy(), b.data.copy()
+    for i in range(n):
+        lo, hi = b.indptr[i], b.indptr[i + 1]
+        o = rng.permutation(hi - lo)
+        ind[lo:hi], dat[lo:hi] = ind[lo:hi][o], dat[lo:hi][o]
+    bs = sps.csr_matrix((dat, ind, b.indptr.copy()), shape=b.shape)
+    assert not bs.has_sorted_indices
+    keep_ind, keep_dat = bs.indices.copy(), bs.data.copy()
+    want = gpu.dot_product_mkl(a, b, reorder_output=True)
+    for opt in (1, 0):
+        gpu.mi_set_option("spgemm_sort_ingest", opt)
+        try:
+            got = gpu.dot_product_mkl(a, bs, reorder_output=True)
+        finally:
+            gpu.mi_set_option("spgemm_sort_ingest", 1)
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        assert rel_err(got.data, want.data) <= 1e-12
+    assert np.array_equal(bs.indices, keep_ind) and np.array_equal(bs.data, keep_dat)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.complex64])
 @pytest.mark.parametrize("kind", ["exact_range_multiples", "wide_bitmap_limit", "too_wide_for_bitmap", "duplicates_in_b",
                                   "unsorted_b"])
