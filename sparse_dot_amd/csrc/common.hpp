@@ -425,6 +425,9 @@ struct Csr {
     // generation of the ENTRY ORDER inside the rows: a fresh value (next_order_gen) whenever the entries are (re)laid out --
     // built, transposed into, re-sorted.  Anything that indexes per-entry tables by position (the staged product's B-row
     // extents, spgemm.hip) records it and checks it again before trusting those tables.
+    // SpGEMM results (spgemm.hip): rows of more than range_min_len entries consist of consecutive runs of range_cap entries with
+    // disjoint, ascending column sets (only the inside of a run is unordered) -- mi_sparse_order sorts run by run.  0: no such layout.
+    int64_t range_cap = 0, range_min_len = 0;
     uint64_t order_gen = 0;
     // dense gram (gram.hip): ABSOLUTE position of the first entry of every row at or right of each tile boundary, int32[rows * (cols / w + 2)], built on first
     // use for tile width gram_off_w (structure only: unaffected by set_values)
@@ -610,6 +613,7 @@ struct Options {
     int64_t spgemm_global_mode = 0;  // 0: one workgroup per row, L2-local atomics; 1: cooperative, agent-scope atomics
     int64_t spgemm_group = 1;        // short rows of B (<= 32 entries): one 16-lane group per selected row of B instead of the flat product list (a third of the instructions)
     int64_t spgemm_rank = 0;         // 1: big rows (sorted B, real or complex-float values): the symbolic phase keeps the row bitmaps, the numeric phase accumulates by rank (k_spgemm_rank) and the rows of C come out sorted; 0: range-partitioned LDS hash (k_spgemm_part) -- same kernel time on the literal configs[2] (round 4), without the 128 KiB per big row of stored bitmap
+    int64_t sort_ranges = 1;         // mi_sparse_order on SpGEMM results: rows written range by range are sorted range by range (0: as any other long row)
     int64_t transpose_radix = 1;     // transposes of 2^21 entries and more: stable radix sort of the entries by column (no atomics, no per-row sort afterwards); 2: the same with tiles of 8192 entries; 0: histogram + atomic scatter + row sort
     int64_t transpose_radix_bits = 7;  // ... most bits of the column index per pass (4 .. 9): 2^18 columns = 3 passes of 6 bits (8.7 ms for 2.7e8 entries; 2 passes of 9 bits scatter 64-byte runs: 10.8 ms)
     int64_t transpose_lds_hist = 1;  // column histogram of a transpose through LDS ranges (>= 2^22 entries, <= 2^20 columns); 0: one global atomic per entry

@@ -503,14 +503,198 @@ __global__ void __launch_bounds__(1024)
     }
 }
 
+// rows of a SpGEMM result that were written range by range (Csr::range_cap): consecutive runs of `cap` entries with disjoint,
+// ascending column sets -- only the inside of a run is unordered, so a row is sorted run by run, and a run of <= cap distinct
+// columns spans few columns (cap / density of the row): a counting sort through an LDS bitmap over just that span -- rank of an
+// entry = set bits before its column -- instead of k_sort_bitmap's pass machinery over the whole row (round 5: 132 ms on the
+// literal configs[2] result: a 128 KiB bitmap, eight barrier-separated passes and ONE workgroup per CU for every row).  Runs
+// whose span exceeds the bitmap (very sparse rows) or that hold a repeated column take a bitonic sort of (column, position)
+// keys in the same LDS.  Workgroups of 256 threads pull (row, group of SORT_RANGE_GROUP runs) items from a counter.
+constexpr int SORT_RANGE_GROUP = 16;
+constexpr int SORT_RANGE_WORDS = 4096;  // bitmap words: spans of up to 131 072 columns
+template <typename V, int IPT>
+__global__ void __launch_bounds__(256)
+    k_sort_ranges(const int64_t* __restrict__ ptr, int32_t* col, const int64_t* __restrict__ rows, const int64_t* __restrict__ item_off,
+                  int64_t n_rows, int64_t n_items, int64_t cap, int64_t npad, const V* __restrict__ vin, V* __restrict__ vout,
+                  unsigned long long* work_counter)
+{
+    MI_DYN_SMEM(smem);
+    // counting sort: bits[SORT_RANGE_WORDS] | gpre[SORT_RANGE_WORDS / 8];   bitonic fallback: keys[npad] over the same bytes
+    unsigned* bits = reinterpret_cast<unsigned*>(smem);
+    int* gpre = reinterpret_cast<int*>(bits + SORT_RANGE_WORDS);
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    __shared__ long long next_item;
+    __shared__ int s_lo, s_hi, s_scan[256];
+    const int tid = threadIdx.x;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) next_item = (long long)atomicAdd(work_counter, 1ull);
+        __syncthreads();
+        const int64_t item = next_item;
+        if (item >= n_items) break;
+        int64_t lo_t = 0, hi_t = n_rows;  // largest t with item_off[t] <= item
+        while (hi_t - lo_t > 1) {
+            const int64_t mid = (lo_t + hi_t) >> 1;
+            if (item_off[mid] <= item) lo_t = mid; else hi_t = mid;
+        }
+        const int64_t row = rows[lo_t];
+        const int64_t p_row = ptr[row], len = ptr[row + 1] - p_row;
+        const int64_t run0 = (item - item_off[lo_t]) * SORT_RANGE_GROUP;
+        // a run's columns and values live in registers (IPT per thread, cap <= 256 IPT) and are requested ONE RUN AHEAD: the
+        // passes of a run are separated by barriers, and with one run per workgroup in flight every load was an exposed round trip
+        int32_t cn[IPT];
+        V vn[IPT];
+        auto fetch = [&](int64_t run) {
+            const int64_t q0 = p_row + run * cap;
+            const int64_t mm = len - run * cap < cap ? len - run * cap : cap;  // <= 0 beyond the row: nothing is loaded
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const int k = tid + u * 256;
+                if (k < mm) {
+                    cn[u] = col[q0 + k];
+                    vn[u] = vin[q0 + k];
+                }
+            }
+        };
+        fetch(run0);
+        for (int64_t run = run0; run < run0 + SORT_RANGE_GROUP && run * cap < len; ++run) {
+            const int64_t p0 = p_row + run * cap;
+            const int m = (int)(len - run * cap < cap ? len - run * cap : cap);
+            int32_t cc[IPT];
+            V vv[IPT];
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                cc[u] = cn[u];
+                vv[u] = vn[u];
+            }
+            if (run + 1 < run0 + SORT_RANGE_GROUP) fetch(run + 1);
+            if (tid == 0) {
+                s_lo = 0x7fffffff;
+                s_hi = -1;
+            }
+            __syncthreads();
+            int mn = 0x7fffffff, mx = -1;
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                if (tid + u * 256 < m) {
+                    mn = cc[u] < mn ? cc[u] : mn;
+                    mx = cc[u] > mx ? cc[u] : mx;
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const int a2 = __shfl_xor(mn, d), b2 = __shfl_xor(mx, d);
+                mn = a2 < mn ? a2 : mn;
+                mx = b2 > mx ? b2 : mx;
+            }
+            if ((tid & 63) == 0) {
+                atomicMin(&s_lo, mn);
+                atomicMax(&s_hi, mx);
+            }
+            __syncthreads();
+            const int lo = s_lo & ~31;  // word aligned
+            const int words = ((s_hi - lo) >> 5) + 1;
+            bool counted = false;
+            if (words <= SORT_RANGE_WORDS) {
+                const int groups = (words + SORT_BITMAP_GROUP - 1) / SORT_BITMAP_GROUP;
+                for (int k = tid; k < groups * SORT_BITMAP_GROUP; k += 256) bits[k] = 0u;
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < IPT; ++u) {
+                    if (tid + u * 256 < m) {
+                        const int o = cc[u] - lo;
+                        atomicOr(&bits[o >> 5], 1u << (o & 31));
+                    }
+                }
+                __syncthreads();
+                // set bits per group of 8 words, exclusive scan over the groups (<= 512 of them: two per thread)
+                const int per = (groups + 255) / 256;
+                int local = 0;
+                for (int g2 = tid * per; g2 < (tid + 1) * per && g2 < groups; ++g2) {
+                    int sum = 0;
+#pragma unroll
+                    for (int w = 0; w < SORT_BITMAP_GROUP; ++w) sum += __popc(bits[g2 * SORT_BITMAP_GROUP + w]);
+                    gpre[g2] = sum;
+                    local += sum;
+                }
+                // block scan of the 256 partial sums: inside the waves by shuffles, across the four waves through LDS
+                int incl = local;
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const int v = __shfl_up(incl, d);
+                    if ((tid & 63) >= d) incl += v;
+                }
+                if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
+                __syncthreads();
+                int wave_base = 0;
+                for (int w = 0; w < (tid >> 6); ++w) wave_base += s_scan[w];
+                const int total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+                counted = total == m;  // else: a repeated column (uniform over the workgroup)
+                if (counted) {
+                    int runsum = wave_base + incl - local;
+                    for (int g2 = tid * per; g2 < (tid + 1) * per && g2 < groups; ++g2) {
+                        const int cnt = gpre[g2];
+                        gpre[g2] = runsum;
+                        runsum += cnt;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < IPT; ++u) {
+                        if (tid + u * 256 < m) {
+                            const int o = cc[u] - lo, w = o >> 5, g2 = w / SORT_BITMAP_GROUP;
+                            int r = gpre[g2] + __popc(bits[w] & ((1u << (o & 31)) - 1u));
+                            for (int ww = g2 * SORT_BITMAP_GROUP; ww < w; ++ww) r += __popc(bits[ww]);
+                            vout[p0 + r] = vv[u];
+                            col[p0 + r] = cc[u];  // (every entry of the run is in registers: nothing of it is read again)
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (!counted) {  // wide span or a repeated column: comparison sort of (column, position); values from the registers
+                int64_t n = 2;
+                while (n < m) n <<= 1;
+                for (int64_t k = tid; k < n; k += 256) keys[k] = ~0ull;
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < IPT; ++u)
+                    if (tid + u * 256 < m) keys[tid + u * 256] = ((uint64_t)(uint32_t)cc[u] << 32) | (uint64_t)(tid + u * 256);
+                __syncthreads();
+                MI_BITONIC(keys, n, (int64_t)tid, 256, __syncthreads())
+                for (int64_t k = tid; k < m; k += 256) {
+                    const uint64_t key = keys[k];
+                    col[p0 + k] = (int32_t)(key >> 32);
+                    vout[p0 + k] = vin[p0 + (int64_t)(key & 0xffffffffull)];
+                }
+                __syncthreads();
+            }
+        }
+    }
+    (void)npad;
+}
+
+__global__ void k_sort_range_items(const int64_t* __restrict__ ptr, const int64_t* __restrict__ rows, int64_t n_rows, int64_t cap,
+                                   int64_t* __restrict__ items)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows) return;
+    const int64_t len = ptr[rows[t] + 1] - ptr[rows[t]];
+    const int64_t runs = (len + cap - 1) / cap;
+    items[t] = (runs + SORT_RANGE_GROUP - 1) / SORT_RANGE_GROUP;
+}
+
 // classify rows for the sort tiers: writes row ids of medium / large rows through atomic cursors
+// (rows of more than `ranged_min` entries, when that is positive, were written range by range: their own list, n_med[2] / ranged_rows)
 __global__ void k_sort_classify(const int64_t* ptr, int64_t rows, int64_t big_thr, int64_t* n_med, int64_t* med_rows,
-                                int64_t* n_big, int64_t* big_rows)
+                                int64_t* n_big, int64_t* big_rows, int64_t ranged_min, int64_t* ranged_rows)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     const int64_t len = ptr[i + 1] - ptr[i];
-    if (len > big_thr) {
+    if (ranged_min > 0 && len > ranged_min) {
+        const int64_t d = (int64_t)atomicAdd((unsigned long long*)(n_med + 2), 1ull);
+        if (ranged_rows) ranged_rows[d] = i;
+    } else if (len > big_thr) {
         const int64_t d = (int64_t)atomicAdd((unsigned long long*)n_big, 1ull);
         if (big_rows) big_rows[d] = i;
     } else if (len > SORT_SMALL_MAX) {
@@ -639,8 +823,10 @@ void sort_csr(char vtype, Csr& a)
     } else {
         vout_raw = c.scratch_alloc(vb * (size_t)a.nnz);
     }
-    int64_t* counters = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * 2));
-    MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 2, c.stream));
+    int64_t* counters = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * 4));
+    MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 4, c.stream));
+    // SpGEMM results: rows written range by range are sorted range by range (k_sort_ranges)
+    const int64_t ranged_min = (a.range_cap > 0 && a.range_cap <= 4096 && options().sort_ranges) ? a.range_min_len : 0;
     // rows too long for one wave: counting sort through an LDS column bitmap when the matrix is narrow enough
     // for one (then the block-wide comparison sort is not used at all), else comparison sorts in LDS / HBM
     const int64_t words = (a.cols + 31) / 32;
@@ -648,20 +834,32 @@ void sort_csr(char vtype, Csr& a)
     const bool use_bitmap = bitmap_bytes <= (size_t)144 * 1024;
     const int64_t big_thr = use_bitmap ? SORT_SMALL_MAX : SORT_BLOCK_MAX;
     MI_LAUNCH(k_sort_classify, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, big_thr,
-              counters, (int64_t*)nullptr, counters + 1, (int64_t*)nullptr);
-    int64_t hc[2] = {0, 0};
+              counters, (int64_t*)nullptr, counters + 1, (int64_t*)nullptr, ranged_min, (int64_t*)nullptr);
+    int64_t hc[3] = {0, 0, 0};
     MI_HIP_CHECK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, c.stream));
     MI_HIP_CHECK(hipStreamSynchronize(c.stream));
     const int64_t n_med = hc[0];
     int64_t n_big = hc[1];
+    const int64_t n_ranged = hc[2];
     int64_t* med_rows = nullptr;
     int64_t* big_rows = nullptr;
-    if (n_med || n_big) {
+    int64_t* ranged_rows = nullptr;
+    if (n_med || n_big || n_ranged) {
         med_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_med + 1)));
         big_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
-        MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 2, c.stream));
+        ranged_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_ranged + 1)));
+        MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 4, c.stream));
         MI_LAUNCH(k_sort_classify, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, big_thr,
-                  counters, med_rows, counters + 1, big_rows);
+                  counters, med_rows, counters + 1, big_rows, ranged_min, ranged_rows);
+    }
+    int64_t* range_item_off = nullptr;
+    int64_t n_range_items = 0;
+    if (n_ranged) {
+        int64_t* items = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_ranged + 1)));
+        range_item_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_ranged + 1)));
+        MI_LAUNCH(k_sort_range_items, grid1d(n_ranged, 256), dim3(256), c.stream, (const int64_t*)a.ptr, (const int64_t*)ranged_rows,
+                  n_ranged, a.range_cap, items);
+        n_range_items = exclusive_scan_i64(items, range_item_off, n_ranged);
     }
     auto run = [&](auto word) {
         using V = decltype(word);
@@ -676,6 +874,24 @@ void sort_csr(char vtype, Csr& a)
         if (n_med)
             MI_LAUNCH((k_sort_block<V>), dim3((unsigned)n_med), dim3(256), c.stream, (const int64_t*)a.ptr, a.col,
                       (const int64_t*)med_rows, vin, vout);
+        if (n_range_items) {
+            int64_t npad = 2;
+            while (npad < a.range_cap) npad <<= 1;
+            unsigned long long* cnt3 = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long)));
+            MI_HIP_CHECK(hipMemsetAsync(cnt3, 0, sizeof(unsigned long long), c.stream));
+            const int64_t wgs = std::min<int64_t>(n_range_items, (int64_t)8 * std::max(c.cus, 1));
+            const size_t lds_count = sizeof(unsigned) * SORT_RANGE_WORDS + sizeof(int) * (SORT_RANGE_WORDS / SORT_BITMAP_GROUP);
+            const size_t lds = std::max(lds_count, sizeof(uint64_t) * (size_t)npad);
+            auto go = [&](auto ipt_tag) {
+                constexpr int IPT = decltype(ipt_tag)::value;
+                MI_LAUNCH_SMEM((k_sort_ranges<V, IPT>), dim3((unsigned)wgs), dim3(256), lds, c.stream, (const int64_t*)a.ptr, a.col,
+                               (const int64_t*)ranged_rows, (const int64_t*)range_item_off, n_ranged, n_range_items, a.range_cap,
+                               npad, vin, vout, cnt3);
+            };
+            if (a.range_cap <= 768) go(std::integral_constant<int, 3>{});
+            else if (a.range_cap <= 1280) go(std::integral_constant<int, 5>{});
+            else go(std::integral_constant<int, 16>{});
+        }
         if (n_big && use_bitmap) {  // rows the counting sort refuses (repeated column) go to the HBM comparison sort
             unsigned long long* cnt2 = static_cast<unsigned long long*>(c.scratch_alloc(sizeof(unsigned long long) * 2));
             int64_t* fallback = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_big + 1)));
@@ -712,6 +928,7 @@ void sort_csr(char vtype, Csr& a)
         MI_HIP_CHECK(hipMemcpyAsync(a.val, vout_raw, vb * (size_t)a.nnz, hipMemcpyDeviceToDevice, c.stream));
     }
     a.sorted = true;
+    a.range_cap = 0;
 }
 
 // out := in^T by the stable radix sort above (out's arrays are allocated by the caller)

@@ -842,6 +842,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.spgemm_group = value;
         } else if (!strcmp(name, "spgemm_rank")) {
             o.spgemm_rank = value;
+        } else if (!strcmp(name, "sort_ranges")) {
+            o.sort_ranges = value;
         } else if (!strcmp(name, "transpose_radix")) {
             o.transpose_radix = value;
         } else if (!strcmp(name, "transpose_radix_bits")) {

@@ -2203,6 +2203,7 @@ struct BigRows {
     bool grp = false;          // every row of B has <= 32 entries: the LDS bins up to 512 products run k_spgemm_grp
     // round 4, accumulate-by-rank path (k_spgemm_rank): the symbolic phase's bitmaps and what the numeric phase needs with them
     bool have_rank = false;
+    int64_t out_range_cap = 0;  // numeric phase, range-partitioned hash: the big rows of C were written as consecutive column ranges of this many entries
     int nblk = 0;              // blocks of RANK_G columns
     int64_t wpr = 0;           // bitmap words per stored row
     DevBuf bm_store;           // unsigned[nbig * wpr]
@@ -2465,6 +2466,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                     });
                 };
                 if (n_groups) {
+                    big.out_range_cap = CAP;
                     constexpr int LO = sizeof(T) >= 16 ? 10 : 11, HI = LO + 1;
                     using lo_t = std::integral_constant<int, LO>;
                     using hi_t = std::integral_constant<int, HI>;
@@ -2851,7 +2853,14 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     C.valid = true;
     C.order_gen = next_order_gen();
     C.sorted = false;
-    if (options().deterministic && C.nnz > 0) spgemm_values_deterministic<T>(A, B, C, st.upper_mode);
+    // what mi_sparse_order may rely on (handle.hip, k_sort_ranges): rows longer than the LDS classes were written range by
+    // range -- consecutive runs of `cap` entries whose column sets are disjoint and ascending from run to run
+    C.range_cap = st.big.out_range_cap;
+    C.range_min_len = bin_limit((sizeof(T) >= 16 ? 7 : 8) - 1);
+    if (options().deterministic && C.nnz > 0) {
+        spgemm_values_deterministic<T>(A, B, C, st.upper_mode);
+        C.range_cap = 0;  // (that pass orders the rows itself)
+    }
 }
 
 // C := A * B (or its upper triangle).  C's storage is allocated here.
