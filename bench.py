@@ -645,7 +645,7 @@ def secondary_config5(torch, dist, dev, abi, rank, world, allreduce_max, steps=3
     nnz = int(indices.numel())
     ip64 = indptr.to(torch.int64)
     del indptr
-    bounds = D.partition_rows(ip64.cpu().numpy(), world)
+    bounds = D.partition_rows(ip64.cpu().numpy(), world, dense_bytes=n * N * 4)
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     lo, hi = int(ip64[r0]), int(ip64[r1])
     blk_ptr = (ip64[r0:r1 + 1] - lo).to(torch.int32).contiguous()
@@ -746,7 +746,7 @@ def run_partitioned(torch, dist, dev, indptr, indices, vals, n, B, steps, warmup
     world = dist.get_world_size(group) if dist else 1
     sync = sync or (lambda: None)
     ip64 = indptr.to(torch.int64)
-    bounds = D.partition_rows(ip64.cpu().numpy(), world)
+    bounds = D.partition_rows(ip64.cpu().numpy(), world, dense_bytes=int(B.numel()) * B.element_size())
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     lo, hi = int(ip64[r0]), int(ip64[r1])
     blk_ptr = (ip64[r0:r1 + 1] - lo).to(torch.int32).contiguous()

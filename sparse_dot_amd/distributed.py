@@ -41,11 +41,15 @@ from scipy import sparse as _sps
 _ROW_COST, _SHORT_ENTRY_COST, _LONG_ROW = 3.3, 1.6, 128
 
 
-def partition_rows(indptr, nparts, model="kernel"):
+def partition_rows(indptr, nparts, model="kernel", dense_bytes=None):
     """Contiguous row blocks of (nearly) equal COST.  model "kernel" (default): the SpMM cost model above -- what makes the
     ranks' local products take the same time; model "items": nnz + rows, the kernel's raw work items (the rule of rounds
-    1-4, under which the rank holding the many short rows of a power-law matrix finished last).  Returns nparts + 1
-    boundaries b with b[0] = 0, b[-1] = nrows, non-decreasing."""
+    1-4, under which the rank holding the many short rows of a power-law matrix finished last).  `dense_bytes` = size of the
+    dense operand B when known: from 4 GiB on (BASELINE configs[4]: 17 GB) hardly any row of B is found in a cache whatever
+    the row of A, an entry costs the same everywhere and a row about one entry (measured on its eight blocks: long 1.0, short
+    1.08, row 1.0) -- the "items" rule is used.  Returns nparts + 1 boundaries b with b[0] = 0, b[-1] = nrows, non-decreasing."""
+    if dense_bytes is not None and dense_bytes >= (1 << 32) and model == "kernel":
+        model = "items"
     indptr = _np.asarray(indptr, dtype=_np.int64)
     nrows = indptr.shape[0] - 1
     if nparts < 1:

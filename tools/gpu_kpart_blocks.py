@@ -29,7 +29,7 @@ def main():
     N = args.ncols
     B = torch.rand((n, N), device=dev, dtype=torch.float32)
     ip64 = indptr.to(torch.int64)
-    bounds = D.partition_rows(ip64.cpu().numpy(), args.world)
+    bounds = D.partition_rows(ip64.cpu().numpy(), args.world, dense_bytes=n * N * 4)
     tot = {"off": 0.0, "kpart": 0.0, "default": 0.0}
     for r in range(args.world):
         r0, r1 = int(bounds[r]), int(bounds[r + 1])
