@@ -530,7 +530,6 @@ struct SpmmPlan {  // nnz+row balanced partition for the SpMM kernel (see spmm.h
 // row-owned as before.
 struct SpmmKpart {
     int P = 0;            // column partitions (8, 4 or 2); the dense operand is cut into 8 / P column slices on top
-    int tslices = 1;      // ... times this many passes in time, one column slice each (SpmmParts, spmm.hip)
     int64_t min_row = 0;  // rows of at least this many entries are partitioned
     int64_t chunk = 0;    // spmm_chunk the chunk ranges cs[] were computed for
     int64_t n_long = 0, nnz_long = 0;
@@ -600,10 +599,8 @@ struct Options {
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_slices = 0;       // XCD-affine column slices of the dense operand: 0 = by row width (256-byte slices), else 1, 2, 4, 8
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
-    int64_t spmm_flat = 1;         // SpMM walk inside a wave: 1 = the wave streams the chunk's nonzeros across row ends (k_spmm_flat); 0 = row by row (k_spmm)
     int64_t spmm_kpart = 1;        // column-partitioned long rows (SpmmKpart) from the third product of a handle on: 0 never, 1 when it pays, 2 always (tests)
     int64_t spmm_kpart_min_row = 128;  // ... rows of at least this many entries
-    int64_t spmm_kpart_tslices = 1;  // ... passes in time over the partitioned rows, one column slice of the dense operand each: 1, 2 or 4
     int64_t spmm_kpart_parts = 8;  // ... column partitions: 8, 4 or 2 (x 1, 2, 4 column slices of the dense operand)
     int64_t spgemm_force_global = 0;
     int64_t spgemm_lds_parts = 1;    // big rows: LDS bitmap (symbolic) / hash-partitioned LDS classes (numeric)

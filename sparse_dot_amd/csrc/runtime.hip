@@ -788,17 +788,12 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
         } else if (!strcmp(name, "spmm_hot_kb")) {
             if (value < 0) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_hot_kb must be >= 0");
             o.spmm_hot_kb = value;
-        } else if (!strcmp(name, "spmm_flat")) {
-            o.spmm_flat = value ? 1 : 0;
         } else if (!strcmp(name, "spmm_kpart")) {
             if (value < 0 || value > 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart must be 0, 1 or 2");
             o.spmm_kpart = value;
         } else if (!strcmp(name, "spmm_kpart_min_row")) {
             if (value < 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_min_row must be >= 2");
             o.spmm_kpart_min_row = value;
-        } else if (!strcmp(name, "spmm_kpart_tslices")) {
-            if (value != 1 && value != 2 && value != 4) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_tslices must be 1, 2 or 4");
-            o.spmm_kpart_tslices = value;
         } else if (!strcmp(name, "spmm_kpart_parts")) {
             if (value != 8 && value != 4 && value != 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_parts must be 8, 4 or 2");
             o.spmm_kpart_parts = value;

@@ -15,8 +15,7 @@
 // Inside a wave the lanes span the DENSE dimension: LPN lanes x V values (16 bytes per lane when
 // the layout allows) cover one row of B, so every B-row read is a fully coalesced 16*LPN-byte
 // segment; the 64/LPN lane groups take consecutive nonzeros.  The wave's slice of A is staged once
-// in LDS and then streamed NG x U nonzeros at a time across row ends (k_spmm_flat, round 5; k_spmm
-// walks row by row).  B rows go straight from L2/HBM to registers: a B row is used by exactly one
+// in LDS and then streamed NG x U nonzeros at a time across row ends (round 5; rows one after the other before).  B rows go straight from L2/HBM to registers: a B row is used by exactly one
 // nonzero of a workgroup, there is nothing to stage.
 //
 // Which rows of B an XCD's private 4 MB L2 holds is the lever (round 5): rows of A with many
@@ -196,31 +195,44 @@ constexpr int SPMM_TAG_NONE = 0, SPMM_TAG_BUFFER = 1;
 // Column-partitioned launch (SpmmKpart, common.hpp): the matrix is the concatenation of P sub-matrices, the chunks
 // [cs[p], cs[p + 1]) of its plan belong to sub-matrix p, and sub-matrix p is processed by the XCDs x with x % P == p only
 // (x / P picks one of the 8 / P column slices of the dense operand).  P == 0: the plain mapping.
-// On top, the partitioned launch may walk its chunks T times, once per column slice IN TIME (blocks are dispatched in
-// order: pass t + 1 starts when pass t drains): during a pass an XCD's L2 sees 1 / T of every row of B only, so T times
-// more rows of its partition stay resident, at the price of streaming the sub-matrix T times.
+// (Column slices IN TIME on top -- the chunks walked T times, one slice each -- were measured and removed in round 5:
+// 1.44 -> 1.51 / 1.73 ms for T = 2 / 4, narrower requests cost more than the resident rows gain.)
 struct SpmmParts {
     int64_t cs[9];
     int P;
-    int T;         // passes in time (>= 1)
-    int64_t nblk;  // workgroups per XCD and pass
 };
+
+// k_spmm -- the SpMM kernel.  Partition, ownership rules and carries as described at the top of the file; lane layout: LPN
+// lanes x V values across the (slice of a) row of B, 64 / LPN lane groups on consecutive nonzeros.  The walk inside the wave
+// (round 5; rounds 1-4 took the rows of a chunk one after the other -- a row of 7 nonzeros was one mostly empty batch of
+// loads and one full memory round trip, a chunk of 30 short rows 30 dependent round trips where its 220 nonzeros fill 14
+// batches: the short-row half of the column-partitioned product ran at 0.58 ms for a 0.32 ms gather): the wave streams
+// through the chunk's staged nonzeros NG x U at a time WHATEVER the row structure: lane group g takes the nonzeros p + g,
+// p + g + NG, ... of the stream, the row state (current row, its end) is wave-uniform -- scalar registers, scalar branches
+// -- and a row end inside a batch combines the groups' accumulators (xor shuffles), writes the row (or the cut row's carry)
+// and clears them.  The summation order is a function of the chunk alone: the same bits on every call.
+template <typename T, int V>
+__device__ __forceinline__ vec<T, V> spmm_tagged_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, bool cold)
+{
+    constexpr int BYTES = V * (int)sizeof(T);
+    static_assert(BYTES == 16, "tagged gather: 16-byte pieces");
+    u32x4 r;
+    if (cold) r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2);  // nt
+    else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return __builtin_bit_cast(vec<T, V>, r);
+}
 
 template <typename T, int V, int LPN, int U, int TAG>
 __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ? 8 : 1)
     k_spmm(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
-           const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
-           const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
-           int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices, SpmmParts parts)
+                const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
+                const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
+                int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices, SpmmParts parts)
 {
     MI_DYN_SMEM(smem);
-    constexpr int NG = WAVE / LPN;  // lane groups per wave, each on its own nonzero
-    const int wave_in_block = threadIdx.x / WAVE;
+    constexpr int NG = WAVE / LPN;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const int lane = threadIdx.x % WAVE;
-    // XCD-affine column slicing: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed
-    // only -- any placement is correct).  With S slices the XCDs are split into S sets, set s only ever
-    // touches dense columns [s * N / S, (s + 1) * N / S): its L2 holds N / S values per row of B instead of
-    // N, i.e. S times more hot rows.  Each chunk of A is then processed once per slice.
     int64_t cb = blockIdx.x;
     int64_t jlo = 0, jhi = N;
     int64_t w;
@@ -228,17 +240,19 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
     if (parts.P > 0) {  // column partitions: XCD x works on sub-matrix x % P, column slice x / P (slices == 8 / P)
         const int xcd = (int)(blockIdx.x & 7u);
         const int pp = xcd % parts.P;
-        const int64_t ns = N / slices;  // slices = (8 / P) in space x T in time
-        const int64_t bi = (int64_t)(blockIdx.x >> 3);
-        const int64_t tt = bi / parts.nblk, lb = bi - tt * parts.nblk;
-        jlo = ((xcd / parts.P) * parts.T + tt) * ns;
+        const int64_t ns = N / slices;
+        jlo = (xcd / parts.P) * ns;
         jhi = jlo + ns;
-        w = parts.cs[pp] + lb * SPMM_WAVES + wave_in_block;
+        w = parts.cs[pp] + (int64_t)(blockIdx.x >> 3) * SPMM_WAVES + wave_in_block;
         active = w < parts.cs[pp + 1];
     } else {
+        // XCD-affine column slicing: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only -- any
+        // placement is correct).  With S slices the XCDs are split into S sets, set s only ever touches dense columns
+        // [s * N / S, (s + 1) * N / S): its L2 holds N / S values per row of B instead of N, i.e. S times more hot rows.
+        // Each chunk of A is then processed once per slice.
         if (slices > 1) {  // slices in {2, 4, 8}
             const int xcd = (int)(blockIdx.x & 7u);
-            const int per = 8 / slices;  // XCDs per slice
+            const int per = 8 / slices;
             cb = (int64_t)(blockIdx.x >> 3) * per + (xcd % per);
             const int64_t ns = N / slices;
             jlo = (xcd / per) * ns;
@@ -247,23 +261,20 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
         w = cb * SPMM_WAVES + wave_in_block;
         active = w < nchunks;
     }
-
-    // carve this wave's LDS: staged nonzeros first (largest alignment), then the row ends
     const size_t per_wave = (spmm_wave_lds<T>(ch) + 15) & ~size_t(15);
     char* base = smem + per_wave * wave_in_block;
     SpEntry<T>* s_nz = reinterpret_cast<SpEntry<T>*>(base);
     int32_t* s_end = reinterpret_cast<int32_t*>(base + sizeof(SpEntry<T>) * (size_t)(ch + SPMM_SPLIT));
 
     int64_t r0 = 0, P0 = 0;
-    int n_owned = 0, has_trail = 0;
+    int n_owned = 0, has_trail = 0, len = 0;
     if (active) {
         const int64_t total = nnz + rows;
         const int64_t s = w * ch;
         const int64_t e = (s + ch < total) ? s + ch : total;
         const int64_t ra = chunk_row[w];      // row holding item s
         const int64_t rb = chunk_row[w + 1];  // row holding item e (== rows after the last item)
-        // first row: a short row that began in the previous chunk was finished there; a long one
-        // is continued from item s
+        // first row: a short row that began in the previous chunk was finished there; a long one is continued from item s
         {
             const int64_t pa = ptr[ra], pa1 = ptr[ra + 1];
             const bool before = (pa + ra) < s;
@@ -276,8 +287,7 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
                 P0 = before ? s - ra : pa;
             }
         }
-        // last row: the row holding item e, if it starts inside this chunk, is finished here when
-        // short and cut (-> carry) when long
+        // last row: the row holding item e, if it starts inside this chunk, is finished here when short and cut (-> carry) when long
         int64_t r_stop, P1;
         if (rb < rows && (ptr[rb] + rb) < e) {
             const int64_t pb = ptr[rb], pb1 = ptr[rb + 1];
@@ -298,227 +308,6 @@ __global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ?
         for (int k = lane; k < nproc; k += WAVE) {
             int64_t en = ptr[r0 + k + 1];
             if (k == nproc - 1) en = P1;  // a cut row ends at the chunk end
-            s_end[k] = (int32_t)(en - P0);
-        }
-        const int len = (int)(P1 - P0);
-        // (A and C with the non-temporal policy -- each is touched once per slice -- measured 2 % SLOWER on the headline
-        // matrix at every hot budget, profiles/r03_spmm_stream_nt_ab.log: plain loads / stores)
-        for (int k = lane; k < len; k += WAVE) {
-            const T a = val[P0 + k];
-            SpEntry<T> en;
-            en.c = col[P0 + k];
-            en.v = conj_a ? vt<T>::conj(a) : a;
-            s_nz[k] = en;
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-
-    const int g = lane / LPN;
-    const int li = lane % LPN;
-    const int nproc = n_owned + has_trail;
-    __amdgpu_buffer_rsrc_t b_rsrc;
-    if constexpr (TAG == SPMM_TAG_BUFFER) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0xffffffff, 0x00020000);
-
-    for (int64_t j0 = jlo; j0 < jhi; j0 += (int64_t)LPN * V) {
-        const int64_t jc = j0 + (int64_t)li * V;  // first column of this lane
-        const bool col_ok = jc < jhi;             // V divides N on the vector path
-        // idle lanes (jc >= N) still issue loads, from column 0: keeps the loop free of divergence
-        const T* bcol = B + (col_ok ? jc : jlo) * b_cs;
-        int begin = 0;
-        for (int k = 0; k < nproc; ++k) {
-            const int end = s_end[k];
-            T acc[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) acc[v] = vt<T>::zero();
-            for (int p = begin + g; p < end; p += NG * U) {
-                SpEntry<T> nz[U];
-                vec<T, V> b[U];
-                bool ok[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int pp = p + u * NG;
-                    ok[u] = pp < end;
-                    nz[u] = s_nz[ok[u] ? pp : end - 1];  // clamp: re-read a valid entry of this row
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    // narrow rows of B (many lane groups): idle groups issue no load at all; wide rows: the
-                    // clamped entry is re-read (an L1 hit) and the loop stays free of divergence
-                    if (NG >= 8 && !ok[u]) continue;
-                    if constexpr (TAG == SPMM_TAG_BUFFER) {
-                        const int32_t cidx = nz[u].c & 0x7fffffff;
-                        const unsigned voff = (unsigned)(((int64_t)cidx * b_rs + (col_ok ? jc : jlo)) * (int64_t)sizeof(T));
-                        u32x4 r;
-                        if (nz[u].c < 0) r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 2);  // nt
-                        else r = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff, 0, 0);
-                        b[u] = __builtin_bit_cast(vec<T, V>, r);
-                    } else {
-                        const T* src = bcol + (int64_t)nz[u].c * b_rs;
-                        if (V > 1) {
-                            b[u] = *reinterpret_cast<const vec<T, V>*>(src);
-                        } else {
-                            b[u].v[0] = src[0];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (ok[u]) {
-#pragma unroll
-                        for (int v = 0; v < V; ++v) acc[v] = vt<T>::fma(nz[u].v, b[u].v[v], acc[v]);
-                    }
-                }
-            }
-            begin = end;
-            // combine the lane groups
-#pragma unroll
-            for (int off = LPN; off < WAVE; off <<= 1) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) acc[v] = vt<T>::add(acc[v], shfl_xor_val(acc[v], off));
-            }
-            if (g == 0 && col_ok) {
-                if (k < n_owned) {
-                    T* crow = C + (r0 + k) * c_rs + jc * c_cs;
-                    vec<T, V> out;
-                    if (beta_zero) {
-#pragma unroll
-                        for (int v = 0; v < V; ++v) out.v[v] = vt<T>::mul(alpha, acc[v]);
-                    } else {
-                        vec<T, V> old;
-                        if (V > 1) {
-                            old = *reinterpret_cast<const vec<T, V>*>(crow);
-                        } else {
-                            old.v[0] = crow[0];
-                        }
-#pragma unroll
-                        for (int v = 0; v < V; ++v)
-                            out.v[v] = vt<T>::fma(alpha, acc[v], vt<T>::mul(beta, old.v[v]));
-                    }
-                    if (V > 1) {
-                        *reinterpret_cast<vec<T, V>*>(crow) = out;
-                    } else {
-                        crow[0] = out.v[0];
-                    }
-                } else {
-                    // trailing partial row -> carry (raw partial sum; alpha applied by the fix-up)
-                    T* cv = carry_val + w * N + jc;
-                    if (V > 1) {
-                        vec<T, V> out;
-#pragma unroll
-                        for (int v = 0; v < V; ++v) out.v[v] = acc[v];
-                        *reinterpret_cast<vec<T, V>*>(cv) = out;
-                    } else {
-                        cv[0] = acc[0];
-                    }
-                }
-            }
-        }
-    }
-}
-
-// k_spmm_flat (round 5) -- the same partition, ownership rules, staging, lane layout (LPN lanes x V values across the
-// row of B, 64 / LPN lane groups on consecutive nonzeros) and carries as k_spmm, another walk inside the wave.  k_spmm takes
-// the rows of a chunk one after the other: a row of 7 nonzeros is one (mostly empty) batch of loads and one full memory round
-// trip, so a chunk of 30 short rows is 30 dependent round trips where its 220 nonzeros would fill 14 batches (the short-row
-// half of the column-partitioned product ran at 0.58 ms for a 0.32 ms gather).  Here the wave streams through the chunk's
-// staged nonzeros NG x U at a time WHATEVER the row structure: lane group g takes the nonzeros p + g, p + g + NG, ... of the
-// stream, the row state (current row, its end) is wave-uniform -- scalar registers, scalar branches -- and a row end inside a
-// batch combines the groups' accumulators (xor shuffles), writes the row (or the cut row's carry) and clears them.  The
-// summation order is a function of the chunk alone: the same bits on every call.
-template <typename T, int V>
-__device__ __forceinline__ vec<T, V> spmm_tagged_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, bool cold)
-{
-    constexpr int BYTES = V * (int)sizeof(T);
-    static_assert(BYTES == 16, "tagged gather: 16-byte pieces");
-    u32x4 r;
-    if (cold) r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2);  // nt
-    else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
-    return __builtin_bit_cast(vec<T, V>, r);
-}
-
-template <typename T, int V, int LPN, int U, int TAG>
-__global__ void __launch_bounds__(SPMM_WAVES* WAVE, (U == 4 && sizeof(T) <= 8) ? 8 : 1)
-    k_spmm_flat(int64_t rows, int64_t nnz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
-                const T* __restrict__ val, const int32_t* __restrict__ chunk_row, int64_t nchunks, int ch, int conj_a,
-                const T* __restrict__ B, int64_t b_rs, int64_t b_cs, T* __restrict__ C, int64_t c_rs, int64_t c_cs,
-                int64_t N, T alpha, T beta, int beta_zero, T* __restrict__ carry_val, int slices, SpmmParts parts)
-{
-    MI_DYN_SMEM(smem);
-    constexpr int NG = WAVE / LPN;
-    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const int lane = threadIdx.x % WAVE;
-    int64_t cb = blockIdx.x;
-    int64_t jlo = 0, jhi = N;
-    int64_t w;
-    bool active;
-    if (parts.P > 0) {
-        const int xcd = (int)(blockIdx.x & 7u);
-        const int pp = xcd % parts.P;
-        const int64_t ns = N / slices;  // slices = (8 / P) in space x T in time
-        const int64_t bi = (int64_t)(blockIdx.x >> 3);
-        const int64_t tt = bi / parts.nblk, lb = bi - tt * parts.nblk;
-        jlo = ((xcd / parts.P) * parts.T + tt) * ns;
-        jhi = jlo + ns;
-        w = parts.cs[pp] + lb * SPMM_WAVES + wave_in_block;
-        active = w < parts.cs[pp + 1];
-    } else {
-        if (slices > 1) {
-            const int xcd = (int)(blockIdx.x & 7u);
-            const int per = 8 / slices;
-            cb = (int64_t)(blockIdx.x >> 3) * per + (xcd % per);
-            const int64_t ns = N / slices;
-            jlo = (xcd / per) * ns;
-            jhi = jlo + ns;
-        }
-        w = cb * SPMM_WAVES + wave_in_block;
-        active = w < nchunks;
-    }
-    const size_t per_wave = (spmm_wave_lds<T>(ch) + 15) & ~size_t(15);
-    char* base = smem + per_wave * wave_in_block;
-    SpEntry<T>* s_nz = reinterpret_cast<SpEntry<T>*>(base);
-    int32_t* s_end = reinterpret_cast<int32_t*>(base + sizeof(SpEntry<T>) * (size_t)(ch + SPMM_SPLIT));
-
-    int64_t r0 = 0, P0 = 0;
-    int n_owned = 0, has_trail = 0, len = 0;
-    if (active) {  // identical to k_spmm's prologue
-        const int64_t total = nnz + rows;
-        const int64_t s = w * ch;
-        const int64_t e = (s + ch < total) ? s + ch : total;
-        const int64_t ra = chunk_row[w];
-        const int64_t rb = chunk_row[w + 1];
-        {
-            const int64_t pa = ptr[ra], pa1 = ptr[ra + 1];
-            const bool before = (pa + ra) < s;
-            const bool is_long = (pa1 - pa + 1) > SPMM_SPLIT;
-            if (before && !is_long) {
-                r0 = ra + 1;
-                P0 = pa1;
-            } else {
-                r0 = ra;
-                P0 = before ? s - ra : pa;
-            }
-        }
-        int64_t r_stop, P1;
-        if (rb < rows && (ptr[rb] + rb) < e) {
-            const int64_t pb = ptr[rb], pb1 = ptr[rb + 1];
-            r_stop = rb + 1;
-            if ((pb1 - pb + 1) > SPMM_SPLIT) {
-                P1 = (e - rb < pb1) ? e - rb : pb1;
-                has_trail = 1;
-            } else {
-                P1 = pb1;
-            }
-        } else {
-            r_stop = rb;
-            P1 = (rb < rows) ? ptr[rb] : nnz;
-        }
-        if (r_stop < r0) r_stop = r0;
-        const int nproc = (int)(r_stop - r0);
-        n_owned = nproc - has_trail;
-        for (int k = lane; k < nproc; k += WAVE) {
-            int64_t en = ptr[r0 + k + 1];
-            if (k == nproc - 1) en = P1;
             s_end[k] = (int32_t)(en - P0);
         }
         len = (int)(P1 - P0);
@@ -1131,8 +920,6 @@ static void plan_after_product(SpmmPlan& p, std::mutex& mtx, const Csr& m, int64
     if (p.uses >= 2 && !hold_hot && p.hot_state == 0 && p.hot_rows_budget < 0) enqueue_hot_analysis(p, m, hot_rows);
 }
 
-static inline const char* flat_name() { return options().spmm_flat ? "_flat" : ""; }
-
 template <typename T, int V, int LPN, int U>
 static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* B, int64_t b_rs, int64_t b_cs, T* C,
                           int64_t c_rs, int64_t c_cs, int64_t N, T alpha, T beta, T* carry_val,
@@ -1142,28 +929,21 @@ static void launch_spmm_u(const Csr& m, const SpmmPlan& p, int conj_a, const T* 
     const size_t per_wave = (spmm_wave_lds<T>(p.chunk) + 15) & ~size_t(15);
     const size_t lds = per_wave * SPMM_WAVES;
     unsigned grid = (unsigned)ceil_div(p.nchunks, SPMM_WAVES);
-    if (parts.P > 0) {  // eight interleaved block lists, each as long as the longest partition's, once per pass in time
-        grid = (unsigned)(parts.nblk * parts.T) * 8u;
+    if (parts.P > 0) {  // eight interleaved block lists, each as long as the longest partition's
+        int64_t mx = 0;
+        for (int q = 0; q < parts.P; ++q) mx = std::max(mx, parts.cs[q + 1] - parts.cs[q]);
+        grid = (unsigned)ceil_div(mx, SPMM_WAVES) * 8u;
         if (grid == 0) return;
     } else if (slices > 1) grid = (unsigned)ceil_div((int64_t)grid, 8 / slices) * 8u;  // see the block mapping in k_spmm
     const int beta_zero = vt<T>::is_zero(beta) ? 1 : 0;
-    note_kernel("mi::k_spmm%s<%s, V=%d, LPN=%d, U=%d, TAG=%d> x %d column slice%s%s", flat_name(), type_name<T>(), V, LPN, U,
+    note_kernel("mi::k_spmm<%s, V=%d, LPN=%d, U=%d, TAG=%d> x %d column slice%s%s", type_name<T>(), V, LPN, U,
                 (V * sizeof(T) == 16) ? tag_mode : 0, slices, slices > 1 ? "s" : "",
                 parts.P > 0 ? " (long rows by column partition + short rows row-owned)" : "");
-    const bool flat = options().spmm_flat != 0;
 #define MI_SPMM_LAUNCH(TAGMODE, COLS)                                                                                  \
-    do {                                                                                                               \
-        if (flat)                                                                                                      \
-            MI_LAUNCH_SMEM((k_spmm_flat<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream,   \
-                           m.rows, m.nnz, (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,              \
-                           (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C,    \
-                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_val, slices, parts);                           \
-        else                                                                                                           \
-            MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream,        \
-                           m.rows, m.nnz, (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,              \
-                           (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C,    \
-                           c_rs, c_cs, N, alpha, beta, beta_zero, carry_val, slices, parts);                           \
-    } while (0)
+    MI_LAUNCH_SMEM((k_spmm<T, V, LPN, U, TAGMODE>), dim3(grid), dim3(SPMM_WAVES * WAVE), lds, c.stream, m.rows, m.nnz, \
+                   (const int64_t*)m.ptr, (const int32_t*)(COLS), (const T*)m.val,                                      \
+                   (const int32_t*)p.chunk_row.as<int32_t>(), p.nchunks, p.chunk, conj_a, B, b_rs, b_cs, C, c_rs,      \
+                   c_cs, N, alpha, beta, beta_zero, carry_val, slices, parts)
     if constexpr (V * sizeof(T) == 16) {
         if (tag_mode == SPMM_TAG_BUFFER) {
             MI_SPMM_LAUNCH(SPMM_TAG_BUFFER, p.col_tagged.as<int32_t>());
@@ -1365,7 +1145,6 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
     auto kp = std::make_shared<SpmmKpart>();
     kp->P = P;
     kp->chunk = o.spmm_chunk;
-    kp->tslices = (int)o.spmm_kpart_tslices;
     kp->min_row = min_row;
     kp->n_long = n_long;
     Csr& sh = kp->shrt;
@@ -1455,7 +1234,7 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
     int slices = 1;
     {
         int64_t want = options().spmm_slices;
-        if (parts) want = 8 / parts->P * parts->tslices;
+        if (parts) want = 8 / parts->P;
         else if (want == 0) {
             // by row width only (never by the matrix: the column split fixes the summation order, so a handle
             // returns the same bits on every call): 256-byte slices, 128-byte ones for 256-byte rows.  Measured on
@@ -1464,7 +1243,7 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
             const int64_t row_bytes = N * (int64_t)sizeof(T);
             want = row_bytes >= 2048 ? 8 : row_bytes >= 1024 ? 4 : row_bytes >= 256 ? 2 : 1;
         }
-        if (layout == MI_SPARSE_LAYOUT_ROW_MAJOR && (want == 2 || want == 4 || want == 8 || (parts && want == 16)) && N % want == 0 &&
+        if (layout == MI_SPARSE_LAYOUT_ROW_MAJOR && (want == 2 || want == 4 || want == 8) && N % want == 0 &&
             (N / want) % V16 == 0 && (N / want) * (int64_t)sizeof(T) >= 64)
             slices = (int)want;
     }
@@ -1513,15 +1292,11 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
     counters().spmm_last_tagged = (double)tag_mode;
     counters().spmm_hot_coverage = pl.hot_coverage;
     if (!vec_ok) slices = 1;
-    if (parts && slices != 8 / parts->P * parts->tslices) fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "column-partitioned launch on an unaligned operand");
+    if (parts && slices != 8 / parts->P) fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "column-partitioned launch on an unaligned operand");
     counters().spmm_last_slices = (double)slices;
     SpmmParts kparts;
     kparts.P = parts ? parts->P : 0;
-    kparts.T = parts ? parts->tslices : 1;
-    kparts.nblk = 0;
     for (int q = 0; q < 9; ++q) kparts.cs[q] = parts ? parts->cs[q] : 0;
-    if (parts)
-        for (int q = 0; q < parts->P; ++q) kparts.nblk = std::max(kparts.nblk, ceil_div(parts->cs[q + 1] - parts->cs[q], SPMM_WAVES));
 #define MI_SPMM_ARGS m, pl, conj_a, B, b_rs, b_cs, C, c_rs, c_cs, N, alpha, beta, carry_val, tag_mode, slices, kparts
     if (vec_ok) {
         const int64_t lanes = N / slices / V16;  // 16-byte lanes needed for one (slice of a) row of B
@@ -1608,7 +1383,7 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     // row-owned kernel for good.
     constexpr int V16 = 16 / (int)sizeof(T);
     const Options& o = options();
-    const int kp_slices = 8 / (int)o.spmm_kpart_parts * (int)o.spmm_kpart_tslices;
+    const int kp_slices = 8 / (int)o.spmm_kpart_parts;
     const bool kp_shape = o.spmm_kpart != 0 && !o.deterministic && !o.spmm_force_generic && N > 1 &&
                           layout == MI_SPARSE_LAYOUT_ROW_MAJOR && N % (V16 * kp_slices) == 0 &&
                           (N / kp_slices) * (int64_t)sizeof(T) >= 64 && (ldb * (int64_t)sizeof(T)) % 16 == 0 &&
@@ -1623,7 +1398,6 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         if (p.kpart_state == 2 && (p.kpart->P != (int)o.spmm_kpart_parts || p.kpart->min_row != o.spmm_kpart_min_row ||
                                    p.kpart->chunk != o.spmm_chunk))
             p.kpart_state = 0;  // the options changed (tools; the partitions' chunk ranges follow spmm_chunk): build again
-        if (p.kpart_state == 2) p.kpart->tslices = (int)o.spmm_kpart_tslices;
         if (p.kpart_state == 0 && (p.uses >= 2 || o.spmm_plan_sync || o.spmm_kpart == 2)) build_kpart(p, m, h->vtype);
         hold_hot = p.kpart_state != 1;
         if (p.kpart_state == 2) {

@@ -1,5 +1,5 @@
 """GPU: the column-partitioned SpMM (SpmmKpart, csrc/spmm.hip: long rows split by part(column) and gathered by one set of
-XCDs per partition, partial rows summed in a fixed order) and the streaming walk (k_spmm_flat) against the CPU oracle --
+XCDs per partition, partial rows summed in a fixed order) and the streaming walk of k_spmm against the CPU oracle --
 forced on for test-sized matrices.  Replaces one mkl_sparse_?_mm (reference sparse_dot_mkl/_sparse_dense.py:111-123)."""
 import numpy as np
 import pytest
@@ -38,7 +38,7 @@ def wide(dtype):
 class kpart_forced:
     def __init__(self, gpu, min_row=16, parts=8, **extra):
         self.gpu, self.opts = gpu, dict(spmm_kpart=2, spmm_kpart_min_row=min_row, spmm_kpart_parts=parts, **extra)
-        self.defaults = dict(spmm_kpart=1, spmm_kpart_min_row=128, spmm_kpart_parts=8, spmm_flat=1, spmm_chunk=256,
+        self.defaults = dict(spmm_kpart=1, spmm_kpart_min_row=128, spmm_kpart_parts=8, spmm_chunk=256,
                              spmm_slices=0, deterministic=0)
 
     def __enter__(self):
@@ -70,15 +70,13 @@ def test_kpart_matches_oracle(gpu, oracle, dtype, n, parts):
     np.testing.assert_allclose(got2, want - 3.0, rtol=10 * tol(dtype), atol=10 * tol(dtype))
 
 
-@pytest.mark.parametrize("flat", [0, 1])
 @pytest.mark.parametrize("chunk", [128, 256, 1024])
-def test_kpart_chunks_and_walks(gpu, oracle, chunk, flat):
-    """Partition boundaries against chunk boundaries (a chunk straddling two partitions), hub sub-rows cut into carries,
-    both walks inside the wave."""
+def test_kpart_chunks(gpu, oracle, chunk):
+    """Partition boundaries against chunk boundaries (a chunk straddling two partitions), hub sub-rows cut into carries."""
     a = skewed_csr(2200, 9000, np.float32, 5, hubs=((0, 9000), (1, 8000), (2, 17), (2100, 6000)))
     b = dense((9000, 128), np.float32, 6)
     want = oracle.spmm(a.astype(np.float64), b.astype(np.float64))
-    with kpart_forced(gpu, 24, 8, spmm_chunk=chunk, spmm_flat=flat):
+    with kpart_forced(gpu, 24, 8, spmm_chunk=chunk):
         got = gpu.dot_product_mkl(a, b)
         assert gpu.mi_get_counter("spmm_last_kpart") == 8.0
         again = gpu.dot_product_mkl(a, b)
@@ -161,29 +159,25 @@ def test_kpart_all_rows_long_and_no_rows_long(gpu, oracle):
 
 @pytest.mark.parametrize("dtype,n", [(np.float32, 128), (np.float32, 96), (np.float32, 20), (np.float64, 64), (np.float64, 7),
                                      (np.complex64, 32), (np.complex128, 16)])
-@pytest.mark.parametrize("flat", [0, 1])
-def test_flat_walk_equals_row_walk_within_tolerance(gpu, oracle, dtype, n, flat):
-    """k_spmm_flat (batches across row ends) and k_spmm (row by row): every lane-group width, scalar path included."""
+def test_streaming_walk_every_lane_group_width(gpu, oracle, dtype, n):
+    """k_spmm's walk (batches of loads across row ends, wave-uniform row state): every lane-group width, scalar path included;
+    rows of exactly the cut length, hub rows, empty rows; alpha / beta."""
     a = skewed_csr(1800, 5000, dtype, 21, hubs=((5, 3000), (6, 129), (7, 128), (900, 257)))
     b = dense((5000, n), dtype, 22)
     want = oracle.spmm(a.astype(wide(dtype)), b.astype(wide(dtype)))
-    gpu.mi_set_option("spmm_flat", flat)
-    try:
-        got = gpu.dot_product_mkl(a, b)
-        out = np.full_like(got, 1.0)
-        got2 = gpu.dot_product_mkl(a, b, out=out, out_scalar=0.5)
-    finally:
-        gpu.mi_set_option("spmm_flat", 1)
+    got = gpu.dot_product_mkl(a, b)
+    out = np.full_like(got, 1.0)
+    got2 = gpu.dot_product_mkl(a, b, out=out, out_scalar=0.5)
     assert rel_err(got, want) <= tol(dtype)
     np.testing.assert_allclose(got2, want + 0.5, rtol=10 * tol(dtype), atol=10 * tol(dtype))
     assert not got[8:40].any()
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
-def test_spmm_randomised_shapes_both_walks_and_partitions(gpu, oracle, seed):
+def test_spmm_randomised_shapes_row_owned_and_partitioned(gpu, oracle, seed):
     """Seeded random sweep over what the SpMM kernels branch on: rows / columns / widths (vector and scalar paths, every
     lane-group width), row-length mixes (empty runs, rows of exactly the cut length 128 / 129, hub rows over many chunks),
-    chunk size, alpha / beta, dtype -- the streaming walk, the row-by-row walk and the column-partitioned form must all
+    chunk size, alpha / beta, dtype -- the row-owned and the column-partitioned form must both
     equal the oracle."""
     rng = np.random.default_rng(1000 + seed)
     dtype = [np.float32, np.float64, np.complex64, np.complex128][seed % 4]
@@ -207,7 +201,7 @@ def test_spmm_randomised_shapes_both_walks_and_partitions(gpu, oracle, seed):
     chunk = int(rng.choice([128, 256, 512, 1024]))
     beta = float(rng.choice([0.0, 0.5, -1.25]))
     c0 = dense((m, n), dtype, 3000 + seed)
-    for opts in (dict(spmm_flat=1), dict(spmm_flat=0), dict(spmm_flat=1, spmm_kpart=2, spmm_kpart_min_row=int(rng.choice([2, 8, 32, 128])),
+    for opts in (dict(spmm_kpart=0), dict(spmm_kpart=2, spmm_kpart_min_row=int(rng.choice([2, 8, 32, 128])),
                                                             spmm_kpart_parts=int(rng.choice([8, 4, 2])))):
         gpu.mi_set_option("spmm_chunk", chunk)
         for name, value in opts.items():
@@ -217,7 +211,7 @@ def test_spmm_randomised_shapes_both_walks_and_partitions(gpu, oracle, seed):
             out = c0.copy()
             got2 = gpu.dot_product_mkl(a, b, out=out, out_scalar=beta) if beta else None
         finally:
-            for name, value in dict(spmm_chunk=256, spmm_flat=1, spmm_kpart=1, spmm_kpart_min_row=128, spmm_kpart_parts=8).items():
+            for name, value in dict(spmm_chunk=256, spmm_kpart=1, spmm_kpart_min_row=128, spmm_kpart_parts=8).items():
                 gpu.mi_set_option(name, value)
         if n == 1:
             got = got.reshape(m, 1)
