@@ -1217,7 +1217,6 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     counters().spmm_kpart_build_ms += ms;
-    kp->plan_short.uses = 1;  // the handle has proven its reuse: the short rows' hot / cold analysis follows their FIRST product
     p.kpart = std::move(kp);
     p.kpart_state = 2;
 }
@@ -1226,7 +1225,7 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
 // `parts`: column-partitioned launch of a concatenated matrix (slices = 8 / parts->P), else the plain mapping.
 template <typename T>
 static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T alpha, int layout, const T* B, int64_t N,
-                     int64_t ldb, T beta, T* C, int64_t ldc, const SpmmKpart* parts, bool hold_hot)
+                     int64_t ldb, T beta, T* C, int64_t ldc, const SpmmKpart* parts, bool hold_hot, bool allow_hot = true)
 {
     Context& c = ctx();
     // XCD-affine column slices (k_spmm): each set of XCDs works on N / S dense columns only
@@ -1252,7 +1251,7 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
     // untagged (every XCD's reference stream is an eighth of the columns: non-temporal cold loads cost more than the
     // evictions they prevent -- long pass 0.81 ms untagged, 0.94-1.04 ms tagged, profiles/r05_spmm_kpart_probe.log)
     int64_t hot_rows = 0;
-    if (!parts && layout == MI_SPARSE_LAYOUT_ROW_MAJOR && options().spmm_hot_kb > 0 &&
+    if (!parts && allow_hot && layout == MI_SPARSE_LAYOUT_ROW_MAJOR && options().spmm_hot_kb > 0 &&
         (N * (int64_t)sizeof(T) >= 512 || options().spmm_hot_force))
         hot_rows = options().spmm_hot_kb * 1024 / slice_bytes;
     const SpmmPlan& pl = get_plan(p, mtx, m, (int)options().spmm_chunk, hot_rows);
@@ -1412,8 +1411,11 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         SpmmKpart& kp = *kp_keep;
         counters().spmm_last_kpart = (double)kp.P;
         counters().spmm_kpart_long_share = m.nnz ? (double)kp.nnz_long / (double)m.nnz : 0.0;
-        // short rows, row-owned, straight into C (the long rows are empty there: they get beta * C)
-        spmm_run<T>(kp.plan_short, h->mtx, kp.shrt, conj_a, alpha, layout, B, N, ldb, beta, C, ldc, nullptr, false);
+        // short rows, row-owned, straight into C (the long rows are empty there: they get beta * C).  Gathered UNTAGGED: once the
+        // long rows are gone, what is left re-references too little for the slower non-temporal loads of the cold columns to pay
+        // (headline 1.30 -> 1.25 ms, three interleaved rounds; 512-byte rows of B; 1 KiB rows: 2.99 vs 3.02 ms --
+        // profiles/r05_spmm_short_rows_untagged_ab.log); the row-owned product of the WHOLE matrix keeps its tags (1.72 vs 1.88 ms)
+        spmm_run<T>(kp.plan_short, h->mtx, kp.shrt, conj_a, alpha, layout, B, N, ldb, beta, C, ldc, nullptr, true, false);
         // long rows: partial[q * n_long + i] = (sub-row q of long row i) * B, then C[rowid[i]] += alpha * sum over q
         T* partial = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)kp.cat.rows * (size_t)N));
         spmm_run<T>(kp.plan_cat, h->mtx, kp.cat, conj_a, vt<T>::one(), layout, B, N, ldb, vt<T>::zero(), partial, N, &kp, true);
