@@ -615,6 +615,7 @@ struct Options {
     int64_t transpose_radix_bits = 7;  // ... most bits of the column index per pass (4 .. 9): 2^18 columns = 3 passes of 6 bits (8.7 ms for 2.7e8 entries; 2 passes of 9 bits scatter 64-byte runs: 10.8 ms)
     int64_t transpose_lds_hist = 1;  // column histogram of a transpose through LDS ranges (>= 2^22 entries, <= 2^20 columns); 0: one global atomic per entry
     int64_t spgemm_narrow_ptr = 1;   // k_row_ub gathers B's row extents from an int32 copy of its row pointer made per call (nnz(B) < 2^31, >= 2^16 rows): half the table, twice the pointers per line
+    int64_t spgemm_col_panels = 1;   // B wider than the LDS bitmap of the big-row path (~1.1 M columns) and rows of the product too long for the LDS hash: product by panels of 2^20 columns (0: global-memory hash)
     int64_t spgemm_sort_ingest = 1;  // B with unsorted rows and rows of the product too long for the LDS hash: multiply by a sorted copy of B (0: global-memory hash)
     int64_t spgemm_onepass = 1;      // products whose rows all fit the small LDS tables: ONE kernel (no symbolic pass), rows placed by a decoupled look-back; 0: always two phases
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
@@ -641,6 +642,7 @@ struct Counters {
     double spmm_plans_built = 0.0;
     double spmm_last_kpart = 0.0;     // column partitions the last SpMM ran its long rows with (0: row-owned only)
     double spmm_kpart_long_share = 0.0;  // share of the nonzeros in partitioned rows (last SpMM)
+    double spgemm_panels = 0.0;       // column panels multiplied by SpGEMM products of a B wider than the LDS bitmap, accumulated
     double spmm_kpart_build_ms = 0.0; // host wall time spent building column-partitioned plans, accumulated
     double bsr_native_calls = 0.0;    // products served by the BSR block kernel
 };

@@ -847,6 +847,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.transpose_lds_hist = value;
         } else if (!strcmp(name, "spgemm_narrow_ptr")) {
             o.spgemm_narrow_ptr = value;
+        } else if (!strcmp(name, "spgemm_col_panels")) {
+            o.spgemm_col_panels = value;
         } else if (!strcmp(name, "spgemm_sort_ingest")) {
             o.spgemm_sort_ingest = value;
         } else if (!strcmp(name, "spgemm_onepass")) {
@@ -904,6 +906,7 @@ mi_sparse_status_t mi_sparse_get_counter(const char* name, double* value)
         else if (!strcmp(name, "spmm_last_kpart")) *value = k.spmm_last_kpart;
         else if (!strcmp(name, "spmm_kpart_long_share")) *value = k.spmm_kpart_long_share;
         else if (!strcmp(name, "spmm_kpart_build_ms")) *value = k.spmm_kpart_build_ms;
+        else if (!strcmp(name, "spgemm_panels")) *value = k.spgemm_panels;
         else if (!strcmp(name, "bsr_native_calls")) *value = k.bsr_native_calls;
         else mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown counter '%s'", name);
     });

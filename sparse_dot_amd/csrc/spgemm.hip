@@ -2863,12 +2863,10 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     }
 }
 
-// C := A * B (or its upper triangle).  C's storage is allocated here.
+// C := A * B (or its upper triangle) for bounds `bd` / state `st` already computed by spgemm_bounds.
 template <typename T>
-static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
+static void spgemm_core(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st, SpgemmBounds& bd)
 {
-    SpgemmSymbolic st;
-    SpgemmBounds bd = spgemm_bounds<T>(A, B, upper, C, st);
     // Sort on ingest (round 5): rows too long for the LDS hash tables need B's rows in column order (the bitmap path cuts
     // them into column ranges by search); with unsorted rows they fell to the global-memory hash -- correct, and several
     // times slower.  mkl_sparse_spmm takes unsorted input without penalty (reference _sparse_sparse.py:35-40), so: a sorted
@@ -2899,6 +2897,214 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
     if (spgemm_onepass<T>(A, B, C, st, bd)) return;
     spgemm_symbolic<T>(A, B, C, st, bd);
     spgemm_numeric<T>(A, B, C, st, &bd);
+}
+
+// ---- B wider than an LDS bitmap: column panels ---------------------------------------------------------------------------
+// The big-row path (k_spgemm_bitmap / k_spgemm_part) holds one bit per column of B in LDS -- about 1.1 M columns.  A wider B
+// used to send every row of the product beyond the LDS hash classes to the global-memory hash (17 x slower on a power-law
+// product).  mkl_sparse_spmm has no such cliff (reference _sparse_sparse.py:35-40), so: B is cut into PANELS of 2^20 columns
+// (its rows are sorted -- a sorted copy is made when they are not -- so a panel is a contiguous piece of every row), the
+// product of A with every panel runs on the fast path with the panel's columns rebased to 0, and the rows of the result are
+// the concatenation of the panels' rows (ascending panel order; inside a panel's piece the order is the fast path's).
+// The symbolic phases of all panels run first (row lengths of C = their sums), then every panel's numeric phase writes
+// straight into its piece of every row of C.  Costs: A is walked once per panel and phase; B is held twice during the call.
+constexpr int64_t PANEL_COLS = (int64_t)1 << 20;
+
+__global__ void __launch_bounds__(256)
+    k_panel_extent(int64_t rows, const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol, int64_t c_lo, int64_t c_hi,
+                   int64_t* __restrict__ lo, int64_t* __restrict__ len)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= rows) return;
+    const int64_t b = bptr[k], e = bptr[k + 1];
+    auto lower = [&](int64_t from, int64_t key) {  // first position in [from, e) whose column is >= key
+        int64_t l = from, h = e;
+        while (l < h) {
+            const int64_t m = (l + h) >> 1;
+            if ((int64_t)bcol[m] < key) l = m + 1;
+            else h = m;
+        }
+        return l;
+    };
+    const int64_t s = lower(b, c_lo);
+    const int64_t t = lower(s, c_hi);
+    lo[k] = s;
+    len[k] = t - s;
+}
+
+// one wave per row of B: its entries inside the panel, columns rebased
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_panel_fill(int64_t rows, const int64_t* __restrict__ lo, const int64_t* __restrict__ qptr, const int32_t* __restrict__ bcol,
+                 const T* __restrict__ bval, int32_t col_base, int32_t* __restrict__ qcol, T* __restrict__ qval)
+{
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (k >= rows) return;
+    const int64_t d = qptr[k], n = qptr[k + 1] - d, s = lo[k];
+    for (int64_t t = lane; t < n; t += WAVE) {
+        qcol[d + t] = bcol[s + t] - col_base;
+        qval[d + t] = bval[s + t];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    k_panel_add_len(int64_t rows, const int64_t* __restrict__ qptr, int64_t* __restrict__ len)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) len[i] += qptr[i + 1] - qptr[i];
+}
+
+// the columns a panel's numeric phase wrote are the panel's own (rebased): add the panel's first column.  Workgroups over chunks
+// of the panel's entries in PANEL order (qptr = the panel's own row pointer); cursor[i] = where the panel's piece of row i starts in C
+constexpr int PANEL_CHUNK = 4096;
+__global__ void __launch_bounds__(256)
+    k_panel_shift(int64_t chunk0, int64_t rows, int64_t nnz, const int64_t* __restrict__ qptr, const int64_t* __restrict__ cursor,
+                  int32_t col_base, int32_t* __restrict__ ccol)
+{
+    const int64_t e0 = (chunk0 + (int64_t)blockIdx.x) * PANEL_CHUNK;
+    const int64_t e1 = e0 + PANEL_CHUNK < nnz ? e0 + PANEL_CHUNK : nnz;
+    auto owner = [&](int64_t e, int64_t l, int64_t h) {  // last row in [l, h] that starts at or before entry e
+        while (l < h) {
+            const int64_t m = (l + h + 1) >> 1;
+            if (qptr[m] <= e) l = m;
+            else h = m - 1;
+        }
+        return l;
+    };
+    const int64_t r_lo = owner(e0, 0, rows - 1), r_hi = owner(e1 - 1, r_lo, rows - 1);
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int64_t r = owner(e, r_lo, r_hi);
+        ccol[cursor[r] + (e - qptr[r])] += col_base;
+    }
+}
+
+struct SpgemmPanel {
+    Csr B, Cp;  // the panel of B (columns rebased); Cp: the panel's own row pointer / entry count (no arrays)
+    SpgemmSymbolic st;
+};
+
+// false: not done (the panels' copies of B did not fit) -- the caller takes the global-memory path
+template <typename T>
+static bool spgemm_panels(const Csr& A, const Csr& B, Csr& C)
+{
+    Context& c = ctx();
+    auto t_last = std::chrono::steady_clock::now();
+    const int64_t np = ceil_div(B.cols, PANEL_COLS);
+    using Panel = SpgemmPanel;
+    try {
+        // rows of B in column order
+        const Csr* Bp = &B;
+        Csr Bs;
+        if (!rows_sorted(B)) {
+            Bs.rows = B.rows;
+            Bs.cols = B.cols;
+            Bs.nnz = B.nnz;
+            Bs.ptr = B.ptr;
+            Bs.col_own.alloc(sizeof(int32_t) * (size_t)B.nnz);
+            Bs.val_own.alloc(sizeof(T) * (size_t)B.nnz);
+            Bs.col = Bs.col_own.as<int32_t>();
+            Bs.val = Bs.val_own.p;
+            MI_HIP_CHECK(hipMemcpyAsync(Bs.col, B.col, sizeof(int32_t) * (size_t)B.nnz, hipMemcpyDeviceToDevice, c.stream));
+            MI_HIP_CHECK(hipMemcpyAsync(Bs.val, B.val, sizeof(T) * (size_t)B.nnz, hipMemcpyDeviceToDevice, c.stream));
+            Bs.valid = true;
+            sort_csr(type_char<T>::value, Bs);
+            Bp = &Bs;
+        }
+        std::vector<std::unique_ptr<Panel>> panels;
+        DevBuf lo_b, len_b;
+        lo_b.alloc(sizeof(int64_t) * (size_t)(B.rows + 1));
+        len_b.alloc(sizeof(int64_t) * (size_t)(std::max(B.rows, A.rows) + 1));
+        const unsigned rgrid = (unsigned)ceil_div(B.rows, 256);
+        std::vector<int64_t> base_of;
+        // symbolic phase of every panel: the row lengths of C are their sums
+        for (int64_t q = 0; q < np; ++q) {
+            auto pn = std::make_unique<Panel>();
+            Csr& Bq = pn->B;
+            Bq.rows = B.rows;
+            Bq.cols = std::min(PANEL_COLS, B.cols - q * PANEL_COLS);
+            Bq.ptr_own.alloc(sizeof(int64_t) * (size_t)(B.rows + 1));
+            Bq.ptr = Bq.ptr_own.as<int64_t>();
+            MI_LAUNCH(k_panel_extent, dim3(rgrid), dim3(256), c.stream, B.rows, (const int64_t*)Bp->ptr, (const int32_t*)Bp->col,
+                      q * PANEL_COLS, q * PANEL_COLS + Bq.cols, lo_b.as<int64_t>(), len_b.as<int64_t>());
+            Bq.nnz = exclusive_scan_i64(len_b.as<int64_t>(), Bq.ptr, B.rows);
+            if (Bq.nnz == 0) continue;
+            Bq.col_own.alloc(sizeof(int32_t) * (size_t)Bq.nnz);
+            Bq.val_own.alloc(sizeof(T) * (size_t)Bq.nnz);
+            Bq.col = Bq.col_own.as<int32_t>();
+            Bq.val = Bq.val_own.p;
+            MI_LAUNCH((k_panel_fill<T>), dim3((unsigned)ceil_div(B.rows * WAVE, 256)), dim3(256), c.stream, B.rows,
+                      (const int64_t*)lo_b.as<int64_t>(), (const int64_t*)Bq.ptr, (const int32_t*)Bp->col, (const T*)Bp->val,
+                      (int32_t)(q * PANEL_COLS), Bq.col, static_cast<T*>(Bq.val));
+            Bq.valid = true;
+            cache_set(Bq.sorted, true);
+            Bq.order_gen = next_order_gen();
+            SpgemmBounds bdq = spgemm_bounds<T>(A, Bq, false, pn->Cp, pn->st);
+            spgemm_symbolic<T>(A, Bq, pn->Cp, pn->st, bdq);
+            if (pn->Cp.nnz == 0) continue;
+            base_of.push_back(q * PANEL_COLS);
+            panels.push_back(std::move(pn));
+        }
+        trace_mark("panels: symbolic", t_last);
+        int64_t* len = len_b.as<int64_t>();
+        MI_HIP_CHECK(hipMemsetAsync(len, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
+        const unsigned agrid = (unsigned)ceil_div(A.rows, 256);
+        for (auto& pn : panels) MI_LAUNCH(k_panel_add_len, dim3(agrid), dim3(256), c.stream, A.rows, (const int64_t*)pn->Cp.ptr, len);
+        C.rows = A.rows;
+        C.cols = B.cols;
+        C.ptr_own.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
+        C.ptr = C.ptr_own.as<int64_t>();
+        C.nnz = exclusive_scan_i64(len, C.ptr, A.rows);
+        C.col_own.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(C.nnz, 1));
+        C.val_own.alloc(sizeof(T) * (size_t)std::max<int64_t>(C.nnz, 1));
+        C.col = C.col_own.as<int32_t>();
+        C.val = C.val_own.p;
+        // numeric phase of every panel, straight into its pieces of the rows of C: cursor[i] = where row i continues
+        int64_t* cursor = len;
+        MI_HIP_CHECK(hipMemcpyAsync(cursor, C.ptr, sizeof(int64_t) * (size_t)A.rows, hipMemcpyDeviceToDevice, c.stream));
+        for (size_t k = 0; k < panels.size(); ++k) {
+            Panel& pn = *panels[k];
+            const RowStats rs = device_row_stats(pn.st.row_nnz.as<int64_t>(), A.rows);
+            run_phase<T, true>(A, pn.B, pn.st.upper_mode, pn.st.row_nnz.as<int64_t>(), rs, nullptr, cursor, C.col,
+                               static_cast<T*>(C.val), pn.st.big);
+            if (base_of[k] > 0)
+                launch_batched(ceil_div(pn.Cp.nnz, (int64_t)PANEL_CHUNK), 256, [&](int64_t off, int64_t nb) {
+                    MI_LAUNCH(k_panel_shift, dim3((unsigned)nb), dim3(256), c.stream, off, A.rows, pn.Cp.nnz, (const int64_t*)pn.Cp.ptr,
+                              (const int64_t*)cursor, (int32_t)base_of[k], C.col);
+                });
+            MI_LAUNCH(k_panel_add_len, dim3(agrid), dim3(256), c.stream, A.rows, (const int64_t*)pn.Cp.ptr, cursor);
+        }
+        c.sync();  // the panels are released on return
+        trace_mark("panels: numeric", t_last);
+    } catch (const status_error& e) {
+        if (e.status != MI_SPARSE_STATUS_ALLOC_FAILED) throw;
+        clear_error();
+        c.sync();
+        return false;
+    }
+    C.valid = true;
+    C.order_gen = next_order_gen();
+    C.sorted = false;
+    C.range_cap = 0;  // a row is the concatenation of the panels' pieces: not one sequence of full ranges
+    counters().spgemm_panels += (double)np;
+    if (options().deterministic && C.nnz > 0) spgemm_values_deterministic<T>(A, B, C, 0);
+    return true;
+}
+
+// C := A * B (or its upper triangle).  C's storage is allocated here.
+template <typename T>
+static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
+{
+    SpgemmSymbolic st;
+    SpgemmBounds bd = spgemm_bounds<T>(A, B, upper, C, st);
+    // rows beyond the LDS hash classes and a B too wide for the LDS bitmap: column panels (see above)
+    if (!upper && bd.max_ub > 4096 && options().spgemm_col_panels && !options().spgemm_force_global && B.nnz > 0 &&
+        B.nnz < ((int64_t)1 << 31) && bitmap_lds_bytes(B.cols) > (size_t)140 * 1024) {
+        if (spgemm_panels<T>(A, B, C)) return;
+        C = Csr();
+        bd = spgemm_bounds<T>(A, B, upper, C, st);
+    }
+    spgemm_core<T>(A, B, upper, C, st, bd);
 }
 
 void spgemm(char vtype, const Csr& A, const Csr& B, bool upper, Csr& C)

@@ -1046,6 +1046,61 @@ def test_spgemm_unsorted_b_is_sorted_on_ingest(gpu):
     assert np.array_equal(bs.indices, keep_ind) and np.array_equal(bs.data, keep_dat)
 
 
+@pytest.mark.parametrize("shuffled", [False, True])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.complex128])
+def test_spgemm_wide_b_by_column_panels(gpu, dtype, shuffled):
+    """B with 2^22 + 77 columns (five panels of 2^20, the last one 77 wide) and hub rows in the product: the big-row path's LDS
+    bitmap does not reach that far, so the product runs panel by panel on the fast path and the rows of the result are the
+    panels' rows one after the other (round 5; the global-memory hash before -- option spgemm_col_panels = 0).  Hub columns on
+    both sides of every panel boundary, rows of A with and without hub status, empty panels inside a row, rows of B shuffled.
+    mkl_sparse_spmm takes any width / order (reference _sparse_sparse.py:35-40).  Oracle: scipy in the wide type."""
+    rng = np.random.default_rng(5)
+    n, k, W = (1 << 22) + 77, 2500, 1 << 20
+    cols = []
+    for r in range(k):
+        c = rng.integers(0, n, 24)
+        if r % 3 == 0:
+            c = np.concatenate([c, [W - 1, W, 2 * W - 1, 2 * W, 3 * W, 4 * W - 1, 4 * W, n - 1]])  # the boundaries, shared: collisions
+        if r % 7 == 0:
+            c = c[c < W]  # rows of B that live in the first panel only
+        cols.append(np.unique(c))
+    ptr = np.concatenate([[0], np.cumsum([c.size for c in cols])])
+    ind = np.concatenate(cols).astype(np.int32)
+    dat = rng.uniform(0.5, 1.5, ind.size)
+    if shuffled:
+        for r in range(k):
+            o = rng.permutation(ptr[r + 1] - ptr[r])
+            ind[ptr[r]:ptr[r + 1]], dat[ptr[r]:ptr[r + 1]] = ind[ptr[r]:ptr[r + 1]][o], dat[ptr[r]:ptr[r + 1]][o]
+    b = sps.csr_matrix((dat, ind, ptr), shape=(k, n))
+    a = sps.random(60, k, density=0.004, format="lil", random_state=3, dtype=np.float64)
+    a[4, rng.choice(k, 1200, replace=False)] = 0.75   # hub rows of A: ~30 000 products each
+    a[31, rng.choice(k, 2000, replace=False)] = 1.5
+    a[50, :] = 0
+    a = a.tocsr()
+    a.data[:] = rng.uniform(0.5, 1.5, a.nnz)
+    a, b = a.astype(dtype), b.astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        a.data = a.data * (1 + 0.5j)
+        b.data = b.data * (0.5 - 1j)
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    want = (a.astype(wide) @ b.astype(wide)).tocsr()
+    want.sort_indices()
+    keep = b.indices.copy()
+    for opt in (1, 0):
+        gpu.mi_set_option("spgemm_col_panels", opt)
+        gpu.mi_get_counter("reset")
+        try:
+            got = gpu.dot_product_mkl(a, b)
+            panels = gpu.mi_get_counter("spgemm_panels")
+            srt = gpu.dot_product_mkl(a, b, reorder_output=True)
+        finally:
+            gpu.mi_set_option("spgemm_col_panels", 1)
+        assert panels == (5 if opt else 0)
+        _check_spgemm(got, want, dtype)
+        assert np.array_equal(srt.indices, want.indices) and np.array_equal(srt.indptr, want.indptr)
+    assert np.array_equal(b.indices, keep)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.complex64])
 @pytest.mark.parametrize("kind", ["exact_range_multiples", "wide_bitmap_limit", "too_wide_for_bitmap", "duplicates_in_b",
                                   "unsorted_b"])
