@@ -794,6 +794,10 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
         } else if (!strcmp(name, "spmm_kpart_min_row")) {
             if (value < 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_min_row must be >= 2");
             o.spmm_kpart_min_row = value;
+        } else if (!strcmp(name, "spmm_kpart_chunk")) {
+            if (value != 128 && value != 256 && value != 512 && value != 1024)
+                mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_chunk must be 128, 256, 512 or 1024");
+            o.spmm_kpart_chunk = value;
         } else if (!strcmp(name, "spmm_kpart_parts")) {
             if (value != 8 && value != 4 && value != 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart_parts must be 8, 4 or 2");
             o.spmm_kpart_parts = value;

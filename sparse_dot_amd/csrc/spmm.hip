@@ -1144,7 +1144,7 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
     const int64_t n_long = exclusive_scan_i64(flag, lidx, m.rows);
     auto kp = std::make_shared<SpmmKpart>();
     kp->P = P;
-    kp->chunk = o.spmm_chunk;
+    kp->chunk = o.spmm_kpart_chunk;
     kp->min_row = min_row;
     kp->n_long = n_long;
     Csr& sh = kp->shrt;
@@ -1206,7 +1206,7 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
                                         c.stream));
         MI_HIP_CHECK(hipEventRecord(e1, c.stream));
         MI_HIP_CHECK(hipStreamSynchronize(c.stream));
-        const int64_t chunk = o.spmm_chunk;
+        const int64_t chunk = kp->chunk;
         const int64_t nchunks = ceil_div(cat.nnz + cat.rows, chunk);
         kp->cs[0] = 0;
         for (int q = 1; q < P; ++q) kp->cs[q] = (starts[(size_t)q] + (int64_t)q * n_long) / chunk;
@@ -1225,7 +1225,8 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
 // `parts`: column-partitioned launch of a concatenated matrix (slices = 8 / parts->P), else the plain mapping.
 template <typename T>
 static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T alpha, int layout, const T* B, int64_t N,
-                     int64_t ldb, T beta, T* C, int64_t ldc, const SpmmKpart* parts, bool hold_hot, bool allow_hot = true)
+                     int64_t ldb, T beta, T* C, int64_t ldc, const SpmmKpart* parts, bool hold_hot, bool allow_hot = true,
+                     int chunk = 0)
 {
     Context& c = ctx();
     // XCD-affine column slices (k_spmm): each set of XCDs works on N / S dense columns only
@@ -1254,7 +1255,7 @@ static void spmm_run(SpmmPlan& p, std::mutex& mtx, const Csr& m, int conj_a, T a
     if (!parts && allow_hot && layout == MI_SPARSE_LAYOUT_ROW_MAJOR && options().spmm_hot_kb > 0 &&
         (N * (int64_t)sizeof(T) >= 512 || options().spmm_hot_force))
         hot_rows = options().spmm_hot_kb * 1024 / slice_bytes;
-    const SpmmPlan& pl = get_plan(p, mtx, m, (int)options().spmm_chunk, hot_rows);
+    const SpmmPlan& pl = get_plan(p, mtx, m, chunk > 0 ? chunk : (int)options().spmm_chunk, hot_rows);
     // fix-up grid: the exact task count once it has reached the host, else its upper bound
     const int64_t fix_tasks = pl.n_tasks >= 0 ? ceil_div(pl.n_tasks, 8) + pl.n_tasks_long : pl.nchunks;  // workgroups of the fix-up
     // one workgroup per task, grid-stride beyond the grid.  While the exact count is still on its way to the host the bound is
@@ -1395,8 +1396,8 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
     if (kp_shape) {
         std::lock_guard<std::mutex> lk(h->mtx);
         if (p.kpart_state == 2 && (p.kpart->P != (int)o.spmm_kpart_parts || p.kpart->min_row != o.spmm_kpart_min_row ||
-                                   p.kpart->chunk != o.spmm_chunk))
-            p.kpart_state = 0;  // the options changed (tools; the partitions' chunk ranges follow spmm_chunk): build again
+                                   p.kpart->chunk != o.spmm_kpart_chunk))
+            p.kpart_state = 0;  // the options changed (tools; the partitions' chunk ranges follow spmm_kpart_chunk): build again
         if (p.kpart_state == 0 && (p.uses >= 2 || o.spmm_plan_sync || o.spmm_kpart == 2)) build_kpart(p, m, h->vtype);
         hold_hot = p.kpart_state != 1;
         if (p.kpart_state == 2) {
@@ -1415,10 +1416,12 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         // long rows are gone, what is left re-references too little for the slower non-temporal loads of the cold columns to pay
         // (headline 1.30 -> 1.25 ms, three interleaved rounds; 512-byte rows of B; 1 KiB rows: 2.99 vs 3.02 ms --
         // profiles/r05_spmm_short_rows_untagged_ab.log); the row-owned product of the WHOLE matrix keeps its tags (1.72 vs 1.88 ms)
-        spmm_run<T>(kp.plan_short, h->mtx, kp.shrt, conj_a, alpha, layout, B, N, ldb, beta, C, ldc, nullptr, true, false);
+        spmm_run<T>(kp.plan_short, h->mtx, kp.shrt, conj_a, alpha, layout, B, N, ldb, beta, C, ldc, nullptr, true, false,
+                    (int)kp.chunk);
         // long rows: partial[q * n_long + i] = (sub-row q of long row i) * B, then C[rowid[i]] += alpha * sum over q
         T* partial = static_cast<T*>(c.scratch_alloc(sizeof(T) * (size_t)kp.cat.rows * (size_t)N));
-        spmm_run<T>(kp.plan_cat, h->mtx, kp.cat, conj_a, vt<T>::one(), layout, B, N, ldb, vt<T>::zero(), partial, N, &kp, true);
+        spmm_run<T>(kp.plan_cat, h->mtx, kp.cat, conj_a, vt<T>::one(), layout, B, N, ldb, vt<T>::zero(), partial, N, &kp, true,
+                    true, (int)kp.chunk);
         const int64_t lanes = N / V16;
         if (lanes > 16)
             MI_LAUNCH((k_kp_combine<T, V16, 32>), dim3((unsigned)ceil_div(kp.n_long * 32, 256)), dim3(256), c.stream,

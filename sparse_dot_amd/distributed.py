@@ -37,8 +37,8 @@ from scipy import sparse as _sps
 # cost of one row of the left matrix in the SpMM, in units of one entry of a long row -- fitted to the kernels' times on the
 # eight row blocks of the headline R-MAT (tools/gpu_kpart_blocks.py, round 5): a row costs 3.3 units whatever it holds (its
 # output row is written, its row-end is walked), an entry of a short row 1.6 (row-owned gather, L2 hit ~0.48), an entry of a
-# row of >= 128 entries 1.0 (gathered by column partition, L2 hit ~0.66)
-_ROW_COST, _SHORT_ENTRY_COST, _LONG_ROW = 3.3, 1.6, 128
+# row of >= 64 entries (the library's spmm_kpart_min_row) 1.0 (gathered by column partition, L2 hit ~0.66)
+_ROW_COST, _SHORT_ENTRY_COST, _LONG_ROW = 3.3, 1.6, 64
 
 
 def partition_rows(indptr, nparts, model="kernel", dense_bytes=None):

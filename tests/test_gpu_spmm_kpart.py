@@ -38,7 +38,7 @@ def wide(dtype):
 class kpart_forced:
     def __init__(self, gpu, min_row=16, parts=8, **extra):
         self.gpu, self.opts = gpu, dict(spmm_kpart=2, spmm_kpart_min_row=min_row, spmm_kpart_parts=parts, **extra)
-        self.defaults = dict(spmm_kpart=1, spmm_kpart_min_row=128, spmm_kpart_parts=8, spmm_chunk=256,
+        self.defaults = dict(spmm_kpart=1, spmm_kpart_min_row=64, spmm_kpart_parts=8, spmm_chunk=256, spmm_kpart_chunk=128,
                              spmm_slices=0, deterministic=0)
 
     def __enter__(self):
@@ -76,7 +76,7 @@ def test_kpart_chunks(gpu, oracle, chunk):
     a = skewed_csr(2200, 9000, np.float32, 5, hubs=((0, 9000), (1, 8000), (2, 17), (2100, 6000)))
     b = dense((9000, 128), np.float32, 6)
     want = oracle.spmm(a.astype(np.float64), b.astype(np.float64))
-    with kpart_forced(gpu, 24, 8, spmm_chunk=chunk):
+    with kpart_forced(gpu, 24, 8, spmm_chunk=chunk, spmm_kpart_chunk=chunk):  # (the partitioned kernels have their own chunk option)
         got = gpu.dot_product_mkl(a, b)
         assert gpu.mi_get_counter("spmm_last_kpart") == 8.0
         again = gpu.dot_product_mkl(a, b)
@@ -113,6 +113,7 @@ def test_kpart_adopted_on_third_product_and_dropped_by_set_values(gpu, oracle):
         # another chunk size on a handle that already holds the partitioned plan: its chunk ranges are rebuilt
         for chunk in (128, 1024, 256):
             gpu.mi_set_option("spmm_chunk", chunk)
+            gpu.mi_set_option("spmm_kpart_chunk", chunk)
             got = gpu.dot_product_mkl(A, b)
             assert gpu.mi_get_counter("spmm_last_kpart") == 8.0 and rel_err(got, 1.25 * want) <= F32_TOL, chunk
         gpu.mi_set_option("deterministic", 1)
@@ -122,8 +123,9 @@ def test_kpart_adopted_on_third_product_and_dropped_by_set_values(gpu, oracle):
     finally:
         gpu.mi_set_option("deterministic", 0)
         gpu.mi_set_option("spmm_chunk", 256)
+        gpu.mi_set_option("spmm_kpart_chunk", 128)
         gpu.mi_set_option("spmm_kpart", 1)
-        gpu.mi_set_option("spmm_kpart_min_row", 128)
+        gpu.mi_set_option("spmm_kpart_min_row", 64)
 
 
 def test_kpart_transposed_and_column_major(gpu, oracle):
@@ -204,6 +206,7 @@ def test_spmm_randomised_shapes_row_owned_and_partitioned(gpu, oracle, seed):
     for opts in (dict(spmm_kpart=0), dict(spmm_kpart=2, spmm_kpart_min_row=int(rng.choice([2, 8, 32, 128])),
                                                             spmm_kpart_parts=int(rng.choice([8, 4, 2])))):
         gpu.mi_set_option("spmm_chunk", chunk)
+        gpu.mi_set_option("spmm_kpart_chunk", chunk)
         for name, value in opts.items():
             gpu.mi_set_option(name, value)
         try:
@@ -211,7 +214,7 @@ def test_spmm_randomised_shapes_row_owned_and_partitioned(gpu, oracle, seed):
             out = c0.copy()
             got2 = gpu.dot_product_mkl(a, b, out=out, out_scalar=beta) if beta else None
         finally:
-            for name, value in dict(spmm_chunk=256, spmm_kpart=1, spmm_kpart_min_row=128, spmm_kpart_parts=8).items():
+            for name, value in dict(spmm_chunk=256, spmm_kpart_chunk=128, spmm_kpart=1, spmm_kpart_min_row=64, spmm_kpart_parts=8).items():
                 gpu.mi_set_option(name, value)
         if n == 1:
             got = got.reshape(m, 1)

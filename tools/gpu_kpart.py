@@ -63,7 +63,7 @@ def main():
             want[k] = (vals[b:e].double()[:, None] * B[indices[b:e].long()].double()).sum(0)
     ref = None
     marker = torch.zeros(1, device=dev)
-    defaults = {"spmm_chunk": 256, "spmm_slices": 0, "spmm_hot_kb": 8192, "spmm_unroll": 4}
+    defaults = {"spmm_chunk": 256, "spmm_kpart_chunk": 128, "spmm_slices": 0, "spmm_hot_kb": 8192, "spmm_unroll": 4}
     for full in args.variants.split(","):
         var, *extra = full.split("+")
         for name, value in defaults.items():
@@ -74,7 +74,7 @@ def main():
             sda.mi_set_option("spmm_kpart", 0)
         elif var == "default":  # the library's own choice (what bench.py times)
             sda.mi_set_option("spmm_kpart", 1)
-            sda.mi_set_option("spmm_kpart_min_row", 128)
+            sda.mi_set_option("spmm_kpart_min_row", 64)
             sda.mi_set_option("spmm_kpart_parts", 8)
         else:
             t, p = var.split(":")
