@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(THREADS)
                  const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
                  const int32_t* __restrict__ bcol, const T* __restrict__ bval, int gw, int upper,
                  int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
-                 T* __restrict__ cval)
+                 T* __restrict__ cval, int32_t col_base)
 {
     constexpr int S = 1 << LOG2S;
     __shared__ int32_t keys[S];
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(THREADS)
             const int32_t key = keys[k];
             if (key != HASH_EMPTY) {
                 const int pos = atomicAdd(&counter, 1);
-                ccol[out0 + pos] = key;
+                ccol[out0 + pos] = key + col_base;
                 cval[out0 + pos] = vals[k];
             }
         }
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(64)
                  const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
                  const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
                  int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
-                 T* __restrict__ cval)
+                 T* __restrict__ cval, int32_t col_base)
 {
     constexpr int S = 1 << LOG2S, GW = 16, NG = 64 / GW, U = 4;
     __shared__ __attribute__((aligned(16))) int32_t keys[S];
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(64)
             int cnt;
             const int pos = wave_rank(key != HASH_EMPTY, cnt);
             if (key != HASH_EMPTY) {
-                ccol[out0 + written + pos] = key;
+                ccol[out0 + written + pos] = key + col_base;
                 cval[out0 + written + pos] = vals[k0 + lane];
             }
             written += cnt;
@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(1024)
                     const T* __restrict__ aval, const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol,
                     const T* __restrict__ bval, int gw, int upper, int32_t* slab_keys, T* slab_vals, int64_t slab,
                     int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
-                    T* __restrict__ cval, unsigned long long* work_counter)
+                    T* __restrict__ cval, unsigned long long* work_counter, int32_t col_base)
 {
     __shared__ int counter;
     __shared__ long long next_idx;
@@ -787,7 +787,7 @@ __global__ void __launch_bounds__(1024)
                 const int32_t key = load_l2(&keys[k]);
                 if (key != HASH_EMPTY) {
                     const int pos = atomicAdd(&counter, 1);
-                    ccol[base + pos] = key;
+                    ccol[base + pos] = key + col_base;
                     T v;
                     if (vt<T>::is_complex) {
                         using R = typename vt<T>::real;
@@ -890,7 +890,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
     k_spgemm_gcompact(const int32_t* __restrict__ row_list, const int32_t* keys_all, const T* vals_all, int log2s,
                       unsigned long long* __restrict__ cursor, const int64_t* __restrict__ cptr,
-                      int32_t* __restrict__ ccol, T* __restrict__ cval)
+                      int32_t* __restrict__ ccol, T* __restrict__ cval, int32_t col_base)
 {
     __shared__ int count;
     __shared__ long long base;
@@ -923,7 +923,7 @@ __global__ void __launch_bounds__(256)
     for (int u = 0; u < PER; ++u) {
         if (pos[u] >= 0) {
             const int64_t k = k0 + tid + (int64_t)u * 256;
-            ccol[out0 + pos[u]] = key[u];
+            ccol[out0 + pos[u]] = key[u] + col_base;
             cval[out0 + pos[u]] = vals[k];
         }
     }
@@ -1333,7 +1333,7 @@ __global__ void __launch_bounds__(PART_THREADS)
                   const int32_t* __restrict__ bounds, int64_t ncols, int64_t cap,
                   const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
-                  const int32_t* __restrict__ bnd, int32_t* __restrict__ ccol, T* __restrict__ cval)
+                  const int32_t* __restrict__ bnd, int32_t* __restrict__ ccol, T* __restrict__ cval, int32_t col_base)
 {
     constexpr int S = 1 << LOG2S;
     constexpr int NT = PART_THREADS;
@@ -1475,7 +1475,7 @@ __global__ void __launch_bounds__(PART_THREADS)
                 const int pos = atomicAdd(&n_out, 1);
                 // non-temporal: 117 GB of C on the literal configs[2], written once -- as plain stores they evict the slices of
                 // B that neighbouring ranges share (profiles/r04_spgemm_nt_stores_ab.log: 158.2 -> 153.5 ms)
-                __builtin_nontemporal_store(key, &ccol[out0 + pos]);
+                __builtin_nontemporal_store(key + col_base, &ccol[out0 + pos]);
                 if constexpr (!vt<T>::is_complex) __builtin_nontemporal_store(vals[k], &cval[out0 + pos]);
                 else cval[out0 + pos] = vals[k];
                 keys[k] = HASH_EMPTY;
@@ -1712,7 +1712,7 @@ __global__ void __launch_bounds__(NT, (sizeof(T) <= 8 ? 2 : 1) * NT / 256)  // t
                   const unsigned* __restrict__ bm, int64_t wpr, const int32_t* __restrict__ acol, const T* __restrict__ aval,
                   const int64_t* __restrict__ ext0, const int32_t* __restrict__ blkptr, int nblk1,
                   const int32_t* __restrict__ bcol, const T* __restrict__ bval, int32_t* __restrict__ ccol,
-                  T* __restrict__ cval)
+                  T* __restrict__ cval, int32_t col_base)
 {
     constexpr int CAP = rank_cap<T>();
     constexpr int WPT = RANK_SPANW / NT;  // bitmap words per thread
@@ -1839,7 +1839,7 @@ __global__ void __launch_bounds__(NT, (sizeof(T) <= 8 ? 2 : 1) * NT / 256)  // t
                 if (need >= c) { pos += 2; need -= c; }
                 c = (int)((x >> pos) & 1u);
                 if (need >= c) pos += 1;
-                ccol[d.out0 + k] = c0 + wi[u] * 32 + pos;
+                ccol[d.out0 + k] = c0 + wi[u] * 32 + pos + col_base;
             }
         }
 #pragma unroll
@@ -2201,6 +2201,7 @@ struct BigRows {
     DevBuf bounds;             // int32: range starts, P_max = ceil(min(ub, cols) / cap) slots per big row
     DevBuf ext0, extlen;       // per nonzero of A: first counted entry of B's row (int64) and their number (int32) -- k_row_ub
     bool grp = false;          // every row of B has <= 32 entries: the LDS bins up to 512 products run k_spgemm_grp
+    int32_t col_base = 0;      // numeric phase: added to every column index written (B is a column panel of a wider matrix, spgemm_panels)
     // round 4, accumulate-by-rank path (k_spgemm_rank): the symbolic phase's bitmaps and what the numeric phase needs with them
     bool have_rank = false;
     int64_t out_range_cap = 0;  // numeric phase, range-partitioned hash: the big rows of C were written as consecutive column ranges of this many entries
@@ -2246,7 +2247,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
     if (b.n[k]) {                                                                                                  \
         launch_batched(b.n[k], THREADS, [&](int64_t off, int64_t nb) {                                             \
             MI_LAUNCH((k_spgemm_lds<T, LOG2S, THREADS, NUMERIC>), dim3((unsigned)nb), dim3(THREADS), c.stream,       \
-                      MI_SPGEMM_LDS_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval);               \
+                      MI_SPGEMM_LDS_ARGS(b.list[k] + off), GW, (int)upper, row_nnz, cptr, ccol, cval, big.col_base); \
         });                                                                                                        \
         b.n[k] = 0;                                                                                                \
     }
@@ -2254,7 +2255,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
     if (big.grp && b.n[k]) {                                                                                       \
         launch_batched(b.n[k], 64, [&](int64_t off, int64_t nb) {                                                  \
             MI_LAUNCH((k_spgemm_grp<T, LOG2S, NUMERIC>), dim3((unsigned)nb), dim3(64), c.stream,                     \
-                      MI_SPGEMM_LDS_ARGS(b.list[k] + off), (int)upper, row_nnz, cptr, ccol, cval);                   \
+                      MI_SPGEMM_LDS_ARGS(b.list[k] + off), (int)upper, row_nnz, cptr, ccol, cval, big.col_base);     \
         });                                                                                                        \
         b.n[k] = 0;                                                                                                \
     }
@@ -2398,7 +2399,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                                   off, n_groups, (const RankGroup*)rgroups, (const RankItem*)ritems,
                                   (const unsigned*)big.bm_store.as<unsigned>(), big.wpr, (const int32_t*)A.col, (const T*)A.val,
                                   (const int64_t*)big.ext0.as<int64_t>(), (const int32_t*)big.blkptr.as<int32_t>(), big.nblk + 1,
-                                  (const int32_t*)B.col, (const T*)B.val, ccol, cval);
+                                  (const int32_t*)B.col, (const T*)B.val, ccol, cval, big.col_base);
                     });
                     note_kernel("k_spgemm_rank<%s,%d,%d>", type_name<T>(), RANK_THREADS, RANK_UNROLL);
                 }
@@ -2462,7 +2463,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                         MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)nblk), dim3(PART_THREADS), c.stream, off, n_groups,
                                   (const int32_t*)item_t, (const PartDesc*)desc, bounds, B.cols, CAP, (const int32_t*)A.col,
                                   (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val, upper,
-                                  (const int32_t*)bnd, ccol, cval);
+                                  (const int32_t*)bnd, ccol, cval, big.col_base);
                     });
                 };
                 if (n_groups) {
@@ -2511,7 +2512,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                           (const int32_t*)b.list[k], cnt, B.cols, (const int64_t*)A.ptr, (const int32_t*)A.col,
                           (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val,
                           gw > threads ? threads : gw, (int)upper, kbuf.as<int32_t>(), vbuf.as<T>(), slab, row_nnz, cptr,
-                          ccol, cval, work);
+                          ccol, cval, work, big.col_base);
                 MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // slabs are freed on scope exit
             }
         }
@@ -2563,7 +2564,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                     if (NUMERIC)
                         MI_LAUNCH((k_spgemm_gcompact<T>), dim3((unsigned)ceil_div(S, GCOMP_SLOTS), (unsigned)nb), dim3(256),
                                   c.stream, (const int32_t*)(b.list[k] + r0), (const int32_t*)kbuf.as<int32_t>(),
-                                  (const T*)vbuf.as<T>(), log2s, cur.as<unsigned long long>(), cptr, ccol, cval);
+                                  (const T*)vbuf.as<T>(), log2s, cur.as<unsigned long long>(), cptr, ccol, cval, big.col_base);
                 }
                 MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // workspaces are freed on scope exit
             }
@@ -2907,7 +2908,7 @@ static void spgemm_core(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSy
 // product of A with every panel runs on the fast path with the panel's columns rebased to 0, and the rows of the result are
 // the concatenation of the panels' rows (ascending panel order; inside a panel's piece the order is the fast path's).
 // The symbolic phases of all panels run first (row lengths of C = their sums), then every panel's numeric phase writes
-// straight into its piece of every row of C.  Costs: A is walked once per panel and phase; B is held twice during the call.
+// straight into its piece of every row of C, adding the panel's first column to the indices it writes (BigRows::col_base).  Costs: A is walked once per panel and phase; B is held twice during the call.
 constexpr int64_t PANEL_COLS = (int64_t)1 << 20;
 
 __global__ void __launch_bounds__(256)
@@ -2953,30 +2954,6 @@ __global__ void __launch_bounds__(256)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < rows) len[i] += qptr[i + 1] - qptr[i];
-}
-
-// the columns a panel's numeric phase wrote are the panel's own (rebased): add the panel's first column.  Workgroups over chunks
-// of the panel's entries in PANEL order (qptr = the panel's own row pointer); cursor[i] = where the panel's piece of row i starts in C
-constexpr int PANEL_CHUNK = 4096;
-__global__ void __launch_bounds__(256)
-    k_panel_shift(int64_t chunk0, int64_t rows, int64_t nnz, const int64_t* __restrict__ qptr, const int64_t* __restrict__ cursor,
-                  int32_t col_base, int32_t* __restrict__ ccol)
-{
-    const int64_t e0 = (chunk0 + (int64_t)blockIdx.x) * PANEL_CHUNK;
-    const int64_t e1 = e0 + PANEL_CHUNK < nnz ? e0 + PANEL_CHUNK : nnz;
-    auto owner = [&](int64_t e, int64_t l, int64_t h) {  // last row in [l, h] that starts at or before entry e
-        while (l < h) {
-            const int64_t m = (l + h + 1) >> 1;
-            if (qptr[m] <= e) l = m;
-            else h = m - 1;
-        }
-        return l;
-    };
-    const int64_t r_lo = owner(e0, 0, rows - 1), r_hi = owner(e1 - 1, r_lo, rows - 1);
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
-        const int64_t r = owner(e, r_lo, r_hi);
-        ccol[cursor[r] + (e - qptr[r])] += col_base;
-    }
 }
 
 struct SpgemmPanel {
@@ -3065,13 +3042,9 @@ static bool spgemm_panels(const Csr& A, const Csr& B, Csr& C)
         for (size_t k = 0; k < panels.size(); ++k) {
             Panel& pn = *panels[k];
             const RowStats rs = device_row_stats(pn.st.row_nnz.as<int64_t>(), A.rows);
+            pn.st.big.col_base = (int32_t)base_of[k];  // the numeric kernels write the panel's columns at their place in B
             run_phase<T, true>(A, pn.B, pn.st.upper_mode, pn.st.row_nnz.as<int64_t>(), rs, nullptr, cursor, C.col,
                                static_cast<T*>(C.val), pn.st.big);
-            if (base_of[k] > 0)
-                launch_batched(ceil_div(pn.Cp.nnz, (int64_t)PANEL_CHUNK), 256, [&](int64_t off, int64_t nb) {
-                    MI_LAUNCH(k_panel_shift, dim3((unsigned)nb), dim3(256), c.stream, off, A.rows, pn.Cp.nnz, (const int64_t*)pn.Cp.ptr,
-                              (const int64_t*)cursor, (int32_t)base_of[k], C.col);
-                });
             MI_LAUNCH(k_panel_add_len, dim3(agrid), dim3(256), c.stream, A.rows, (const int64_t*)pn.Cp.ptr, cursor);
         }
         c.sync();  // the panels are released on return

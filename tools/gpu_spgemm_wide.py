@@ -32,6 +32,9 @@ ha = mk(n, n, a[0], a[1], av)
 cases = [("narrow B (2^%d columns)" % scale, mk(n, n, b[0], b[1], bv), 1),
          ("wide B, stride 16 (2^%d columns), panels" % (scale + 4), mk(n, n * 16, b[0], col_stride, bv), 1),
          ("wide B, random spread (2^%d columns), panels" % (scale + 4), mk(n, n * 16, b[0], col_rand, bv), 1)]
+only = [a.split("=")[1] for a in sys.argv if a.startswith("only=")]
+if only:
+    cases = [c for c in cases if only[0] in c[0]]
 if with_global:
     cases += [("wide B, stride 16, global hash", mk(n, n * 16, b[0], col_stride, bv), 0)]
 for name, hb, opt in cases:
