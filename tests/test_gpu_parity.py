@@ -1101,6 +1101,46 @@ def test_spgemm_wide_b_by_column_panels(gpu, dtype, shuffled):
     assert np.array_equal(b.indices, keep)
 
 
+def test_spgemm_wide_b_panels_with_gaps_int64_and_deterministic(gpu):
+    """Column panels again: B 3 x 2^20 + 5 columns with NOTHING in the second panel and a single column in the last one, rows
+    of A that are big in one panel and small in another, int64 index arrays, and option deterministic (values re-formed in a
+    fixed order on the final pattern): same structure as scipy, values to 1e-12, three deterministic runs bit-identical."""
+    rng = np.random.default_rng(11)
+    W = 1 << 20
+    n, k = 3 * W + 5, 1800
+    cols = []
+    for r in range(k):
+        c = rng.integers(0, W, 30)                      # panel 0
+        if r % 2:
+            c = np.concatenate([c, 2 * W + rng.integers(0, W, 4)])  # panel 2, thin
+        if r % 5 == 0:
+            c = np.concatenate([c, [n - 1]])            # panel 3: one column
+        cols.append(np.unique(c))
+    ptr = np.concatenate([[0], np.cumsum([c.size for c in cols])]).astype(np.int64)
+    ind = np.concatenate(cols).astype(np.int64)
+    b = sps.csr_matrix((rng.uniform(0.5, 1.5, ind.size), ind, ptr), shape=(k, n))
+    a = sps.random(40, k, density=0.003, format="lil", random_state=8, dtype=np.float64)
+    a[7, rng.choice(k, 900, replace=False)] = 1.0
+    a[8, rng.choice(k, 1500, replace=False)] = 1.0
+    a = a.tocsr()
+    a.data[:] = rng.uniform(0.5, 1.5, a.nnz)
+    a.indices, a.indptr = a.indices.astype(np.int64), a.indptr.astype(np.int64)
+    want = (a @ b).tocsr()
+    want.sort_indices()
+    gpu.mi_get_counter("reset")
+    got = gpu.dot_product_mkl(a, b)
+    assert gpu.mi_get_counter("spgemm_panels") == 4
+    _check_spgemm(got, want, np.float64)
+    gpu.mi_set_option("deterministic", 1)
+    try:
+        runs = [gpu.dot_product_mkl(a, b) for _ in range(3)]
+    finally:
+        gpu.mi_set_option("deterministic", 0)
+    for r in runs:
+        _check_spgemm(r, want, np.float64)
+        assert np.array_equal(r.indices, runs[0].indices) and np.array_equal(r.data, runs[0].data)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.complex64])
 @pytest.mark.parametrize("kind", ["exact_range_multiples", "wide_bitmap_limit", "too_wide_for_bitmap", "duplicates_in_b",
                                   "unsorted_b"])
