@@ -359,6 +359,14 @@ mi_sparse_status_t mi_sparse_z_mv(int op, mi_complex16 alpha, mi_sparse_matrix_t
  * op must be 10 (the only value the reference passes). */
 mi_sparse_status_t mi_sparse_spmm(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, mi_sparse_matrix_t *C);
 
+/* The same product with the column indices of every row in INCREASING order: what the reference's
+ * `reorder_output=True` obtains with mkl_sparse_spmm followed by mkl_sparse_order
+ * (_sparse_sparse.py:226-230, _common.py:683-692) in one call.  Knowing that the rows will be ordered,
+ * the library accumulates the long rows by the rank of their column (they come out in order: nothing
+ * left to sort but the short rows) whenever the row bitmaps that takes fit in 8 GiB; otherwise it is
+ * mi_sparse_spmm + mi_sparse_order.  Same pattern, same values (to tolerance) either way. */
+mi_sparse_status_t mi_sparse_spmm_ordered(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, mi_sparse_matrix_t *C);
+
 /* mkl_sparse_sp2m (the two-stage API; MKL signature
  *   mkl_sparse_sp2m(opA, descrA, A, opB, descrB, B, request, *C)):   C := op(A) * op(B)   with the symbolic and the
  * numeric phase of the two-phase hash SpGEMM callable separately, so that a pattern is analysed once and reused:

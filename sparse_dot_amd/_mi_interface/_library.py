@@ -136,6 +136,7 @@ def _bind(lib):
     add("mi_sparse_order", [H])
     add("mi_sparse_convert_csr", [H, _int, HP])
     add("mi_sparse_spmm", [_int, H, H, HP])
+    add("mi_sparse_spmm_ordered", [_int, H, H, HP])
     add("mi_sparse_syrk", [_int, H, HP])
     add("mi_sparse_sp2m", [_int, matrix_descr, H, _int, matrix_descr, H, _int, HP])
     add("mi_sparse_sypr", [_int, H, H, matrix_descr, HP, _int])

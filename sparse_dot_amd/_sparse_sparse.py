@@ -14,13 +14,16 @@ from ._mi_interface import (MI, SparseHandle, _check_return_value, _empty_output
                             is_bsr, sparse_matrix_t, sparse_output_type)
 
 
-def _matmul_mi(handle_a, handle_b):
-    """Sparse handle of A @ B (library-owned; the caller destroys it)."""
+def _matmul_mi(handle_a, handle_b, ordered=False):
+    """Sparse handle of A @ B (library-owned; the caller destroys it).  `ordered`: the rows come back with their column
+    indices in increasing order (mi_sparse_spmm_ordered: the reference's mkl_sparse_spmm + mkl_sparse_order,
+    _sparse_sparse.py:226-230, as one call -- the library then accumulates the long rows in order to begin with)."""
     if handle_a is None or handle_b is None:
         raise ValueError("mi_sparse_spmm returned 1 (SPARSE_STATUS_NOT_INITIALIZED)")
     out = sparse_matrix_t()
-    ret = MI.call("mi_sparse_spmm", 10, handle_a.ptr, handle_b.ptr, _ct.byref(out))
-    _check_return_value(ret, "mi_sparse_spmm")
+    name = "mi_sparse_spmm_ordered" if ordered else "mi_sparse_spmm"
+    ret = MI.call(name, 10, handle_a.ptr, handle_b.ptr, _ct.byref(out))
+    _check_return_value(ret, name)
     return SparseHandle(out, handle_a.letter)
 
 
@@ -57,11 +60,8 @@ def _sparse_dot_sparse(matrix_a, matrix_b, cast=False, reorder_output=False, den
             result = _matmul_mi_dense(ha, hb, out_shape, dbl, out=out, complex_type=cplx)
             debug_timer("Multiplied matrices", t)
             return result
-        with _matmul_mi(ha, hb) as hc:
-            t = debug_timer("Multiplied matrices", t)
-            if reorder_output:
-                hc.order()
-                t = debug_timer("Reordered output indices", t)
+        with _matmul_mi(ha, hb, ordered=reorder_output) as hc:
+            t = debug_timer("Multiplied matrices" + (" (rows ordered)" if reorder_output else ""), t)
             if is_bsr(matrix_a):
                 if is_bsr(matrix_b) and matrix_a.blocksize == matrix_b.blocksize:
                     result = hc.export_bsr(output_type)  # re-blocked on the device (mi_sparse_?_export_bsr)

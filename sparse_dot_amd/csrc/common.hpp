@@ -428,6 +428,9 @@ struct Csr {
     // SpGEMM results (spgemm.hip): rows of more than range_min_len entries consist of consecutive runs of range_cap entries with
     // disjoint, ascending column sets (only the inside of a run is unordered) -- mi_sparse_order sorts run by run.  0: no such layout.
     int64_t range_cap = 0, range_min_len = 0;
+    // SpGEMM results accumulated by rank (k_spgemm_rank): rows of more than sorted_min_len entries already have their columns
+    // in increasing order -- mi_sparse_order leaves them alone.  0: nothing known.
+    int64_t sorted_min_len = 0;
     uint64_t order_gen = 0;
     // dense gram (gram.hip): ABSOLUTE position of the first entry of every row at or right of each tile boundary, int32[rows * (cols / w + 2)], built on first
     // use for tile width gram_off_w (structure only: unaffected by set_values)

@@ -686,11 +686,12 @@ __global__ void k_sort_range_items(const int64_t* __restrict__ ptr, const int64_
 // classify rows for the sort tiers: writes row ids of medium / large rows through atomic cursors
 // (rows of more than `ranged_min` entries, when that is positive, were written range by range: their own list, n_med[2] / ranged_rows)
 __global__ void k_sort_classify(const int64_t* ptr, int64_t rows, int64_t big_thr, int64_t* n_med, int64_t* med_rows,
-                                int64_t* n_big, int64_t* big_rows, int64_t ranged_min, int64_t* ranged_rows)
+                                int64_t* n_big, int64_t* big_rows, int64_t ranged_min, int64_t* ranged_rows, int64_t sorted_min)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     const int64_t len = ptr[i + 1] - ptr[i];
+    if (sorted_min > 0 && len > sorted_min) return;  // in column order already (Csr::sorted_min_len): no list takes it
     if (ranged_min > 0 && len > ranged_min) {
         const int64_t d = (int64_t)atomicAdd((unsigned long long*)(n_med + 2), 1ull);
         if (ranged_rows) ranged_rows[d] = i;
@@ -701,6 +702,19 @@ __global__ void k_sort_classify(const int64_t* ptr, int64_t rows, int64_t big_th
         const int64_t d = (int64_t)atomicAdd((unsigned long long*)n_med, 1ull);
         if (med_rows) med_rows[d] = i;
     }
+}
+
+// rows of at most `max_len` entries: their (sorted) values from the sort's output array back into the matrix (16 lanes per row)
+template <typename V>
+__global__ void __launch_bounds__(256)
+    k_sort_copy_back(const int64_t* __restrict__ ptr, int64_t rows, int64_t max_len, const V* __restrict__ src, V* __restrict__ dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t >> 4;
+    if (r >= rows) return;
+    const int64_t b = ptr[r], n = ptr[r + 1] - b;
+    if (n > max_len) return;
+    for (int64_t k = t & 15; k < n; k += 16) dst[b + k] = src[b + k];
 }
 
 __global__ void k_big_row_sizes(const int64_t* ptr, const int64_t* rows_list, int64_t n, int64_t* sizes)
@@ -825,6 +839,9 @@ void sort_csr(char vtype, Csr& a)
     }
     int64_t* counters = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * 4));
     MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 4, c.stream));
+    // SpGEMM results accumulated by rank: the long rows are in column order already -- no kernel visits them, and their values
+    // (most of the matrix) stay where they are: the rows that ARE sorted take their values through `vout` and back (k_sort_copy_back)
+    const int64_t sorted_min = a.sorted_min_len > SORT_SMALL_MAX ? a.sorted_min_len : 0;
     // SpGEMM results: rows written range by range are sorted range by range (k_sort_ranges)
     const int64_t ranged_min = (a.range_cap > 0 && a.range_cap <= 4096 && options().sort_ranges) ? a.range_min_len : 0;
     // rows too long for one wave: counting sort through an LDS column bitmap when the matrix is narrow enough
@@ -834,7 +851,7 @@ void sort_csr(char vtype, Csr& a)
     const bool use_bitmap = bitmap_bytes <= (size_t)144 * 1024;
     const int64_t big_thr = use_bitmap ? SORT_SMALL_MAX : SORT_BLOCK_MAX;
     MI_LAUNCH(k_sort_classify, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, big_thr,
-              counters, (int64_t*)nullptr, counters + 1, (int64_t*)nullptr, ranged_min, (int64_t*)nullptr);
+              counters, (int64_t*)nullptr, counters + 1, (int64_t*)nullptr, ranged_min, (int64_t*)nullptr, sorted_min);
     int64_t hc[3] = {0, 0, 0};
     MI_HIP_CHECK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, c.stream));
     MI_HIP_CHECK(hipStreamSynchronize(c.stream));
@@ -850,7 +867,7 @@ void sort_csr(char vtype, Csr& a)
         ranged_rows = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(n_ranged + 1)));
         MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 4, c.stream));
         MI_LAUNCH(k_sort_classify, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, big_thr,
-                  counters, med_rows, counters + 1, big_rows, ranged_min, ranged_rows);
+                  counters, med_rows, counters + 1, big_rows, ranged_min, ranged_rows, sorted_min);
     }
     int64_t* range_item_off = nullptr;
     int64_t n_range_items = 0;
@@ -920,7 +937,17 @@ void sort_csr(char vtype, Csr& a)
     if (vb == 4) run(uint32_t{});
     else if (vb == 8) run(uint64_t{});
     else run(Word16{});
-    if (owned) {
+    if (sorted_min > 0) {
+        auto back = [&](auto word) {
+            using V = decltype(word);
+            MI_LAUNCH((k_sort_copy_back<V>), grid1d(a.rows * 16, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, sorted_min,
+                      (const V*)vout_raw, static_cast<V*>(a.val));
+        };
+        if (vb == 4) back(uint32_t{});
+        else if (vb == 8) back(uint64_t{});
+        else back(Word16{});
+        if (owned) MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // `fresh` goes back to the cache
+    } else if (owned) {
         MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // the old block goes back to the cache: nothing may still read it
         a.val_own = std::move(fresh);
         a.val = a.val_own.p;
@@ -929,6 +956,7 @@ void sort_csr(char vtype, Csr& a)
     }
     a.sorted = true;
     a.range_cap = 0;
+    a.sorted_min_len = 0;
 }
 
 // out := in^T by the stable radix sort above (out's arrays are allocated by the caller)

@@ -2204,6 +2204,7 @@ struct BigRows {
     int32_t col_base = 0;      // numeric phase: added to every column index written (B is a column panel of a wider matrix, spgemm_panels)
     // round 4, accumulate-by-rank path (k_spgemm_rank): the symbolic phase's bitmaps and what the numeric phase needs with them
     bool have_rank = false;
+    bool want_rank = false;    // the caller will order the result (mi_sparse_spmm_ordered): take the rank path when its bitmaps are affordable
     int64_t out_range_cap = 0;  // numeric phase, range-partitioned hash: the big rows of C were written as consecutive column ranges of this many entries
     int nblk = 0;              // blocks of RANK_G columns
     int64_t wpr = 0;           // bitmap words per stored row
@@ -2317,14 +2318,15 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                 }
                 // round 4: keep the bitmaps for k_spgemm_rank when they (and the block starts of B's rows) are affordable
                 bool rank_path = false;
-                if (big.b_sorted && options().spgemm_rank && sizeof(T) <= 8) {
+                if (big.b_sorted && (options().spgemm_rank || big.want_rank) && sizeof(T) <= 8) {
                     const int nblk = (int)ceil_div(B.cols, (int64_t)RANK_G);
                     const int64_t wpr = (int64_t)nblk * RANK_GW;
                     const size_t need = sizeof(unsigned) * (size_t)wpr * (size_t)nbig + sizeof(uint16_t) * (size_t)nblk * (size_t)nbig +
                                         sizeof(int32_t) * (size_t)(nblk + 1) * (size_t)B.rows + sizeof(int32_t) * (size_t)A.rows;
                     size_t free_b = 0, total_b = 0;
                     MI_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-                    if (need < free_b / 3) {
+                    // (asked for by the caller's ordering only: not when the bitmaps would crowd the result out of the block cache)
+                    if (need < free_b / 3 && (options().spgemm_rank || need <= ((size_t)8 << 30))) {
                         rank_path = true;
                         big.nblk = nblk;
                         big.wpr = wpr;
@@ -2858,16 +2860,19 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     // range -- consecutive runs of `cap` entries whose column sets are disjoint and ascending from run to run
     C.range_cap = st.big.out_range_cap;
     C.range_min_len = bin_limit((sizeof(T) >= 16 ? 7 : 8) - 1);
+    C.sorted_min_len = st.big.have_rank ? C.range_min_len : 0;  // k_spgemm_rank wrote every longer row in column order
     if (options().deterministic && C.nnz > 0) {
         spgemm_values_deterministic<T>(A, B, C, st.upper_mode);
         C.range_cap = 0;  // (that pass orders the rows itself)
+        C.sorted_min_len = 0;
     }
 }
 
 // C := A * B (or its upper triangle) for bounds `bd` / state `st` already computed by spgemm_bounds.
 template <typename T>
-static void spgemm_core(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st, SpgemmBounds& bd)
+static void spgemm_core(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st, SpgemmBounds& bd, bool want_sorted = false)
 {
+    st.big.want_rank = want_sorted;
     // Sort on ingest (round 5): rows too long for the LDS hash tables need B's rows in column order (the bitmap path cuts
     // them into column ranges by search); with unsorted rows they fell to the global-memory hash -- correct, and several
     // times slower.  mkl_sparse_spmm takes unsorted input without penalty (reference _sparse_sparse.py:35-40), so: a sorted
@@ -2889,6 +2894,7 @@ static void spgemm_core(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSy
         sort_csr(type_char<T>::value, Bs);
         SpgemmSymbolic st2;
         SpgemmBounds bd2 = spgemm_bounds<T>(A, Bs, upper, C, st2);
+        st2.big.want_rank = want_sorted;
         if (spgemm_onepass<T>(A, Bs, C, st2, bd2)) return;
         spgemm_symbolic<T>(A, Bs, C, st2, bd2);
         spgemm_numeric<T>(A, Bs, C, st2, &bd2);
@@ -3066,7 +3072,7 @@ static bool spgemm_panels(const Csr& A, const Csr& B, Csr& C)
 
 // C := A * B (or its upper triangle).  C's storage is allocated here.
 template <typename T>
-static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
+static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C, bool want_sorted)
 {
     SpgemmSymbolic st;
     SpgemmBounds bd = spgemm_bounds<T>(A, B, upper, C, st);
@@ -3077,12 +3083,12 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C)
         C = Csr();
         bd = spgemm_bounds<T>(A, B, upper, C, st);
     }
-    spgemm_core<T>(A, B, upper, C, st, bd);
+    spgemm_core<T>(A, B, upper, C, st, bd, want_sorted);
 }
 
-void spgemm(char vtype, const Csr& A, const Csr& B, bool upper, Csr& C)
+void spgemm(char vtype, const Csr& A, const Csr& B, bool upper, Csr& C, bool want_sorted = false)
 {
-    by_type(vtype, [&](auto tag) { spgemm_typed<decltype(tag)>(A, B, upper, C); });
+    by_type(vtype, [&](auto tag) { spgemm_typed<decltype(tag)>(A, B, upper, C, want_sorted); });
 }
 
 // ---- staged product (mkl_sparse_sp2m analogue) -------------------------------------------------------------
@@ -3373,7 +3379,7 @@ using mi::cfloat;
 
 extern "C" {
 
-mi_sparse_status_t mi_sparse_spmm(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, mi_sparse_matrix_t* C)
+static mi_sparse_status_t spmm_entry(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, mi_sparse_matrix_t* C, bool ordered)
 {
     return mi::guarded([&] {
         if (!C) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL output handle pointer");
@@ -3394,7 +3400,11 @@ mi_sparse_status_t mi_sparse_spmm(int op, mi_sparse_matrix_t A, mi_sparse_matrix
         // MKL keeps the operands' format: the product of two BSR handles with one block size is exportable as BSR
         if (ha->bsr.valid && hb->bsr.valid && ha->bsr.bs == hb->bsr.bs) r->result_bs = ha->bsr.bs;
         try {
-            mi::spgemm(ha->vtype, a, b, false, r->csr);
+            mi::spgemm(ha->vtype, a, b, false, r->csr, ordered);
+            if (ordered && !mi::rows_sorted(r->csr)) {
+                mi::ctx().scratch_reset();
+                mi::sort_csr(ha->vtype, r->csr);
+            }
             mi::ctx().sync();
         } catch (...) {
             r->magic = 0;
@@ -3403,6 +3413,16 @@ mi_sparse_status_t mi_sparse_spmm(int op, mi_sparse_matrix_t A, mi_sparse_matrix
         }
         *C = r;
     });
+}
+
+mi_sparse_status_t mi_sparse_spmm(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, mi_sparse_matrix_t* C)
+{
+    return spmm_entry(op, A, B, C, false);
+}
+
+mi_sparse_status_t mi_sparse_spmm_ordered(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, mi_sparse_matrix_t* C)
+{
+    return spmm_entry(op, A, B, C, true);
 }
 
 mi_sparse_status_t mi_sparse_syrk(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t* C)

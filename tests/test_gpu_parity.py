@@ -828,6 +828,52 @@ def test_spgemm_hub_rows_lds_bitmap_and_partitioned_classes(gpu, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
+def test_spmm_ordered_is_spmm_plus_order(gpu, dtype):
+    """mi_sparse_spmm_ordered (what reorder_output=True calls since round 5; reference _sparse_sparse.py:226-230 =
+    mkl_sparse_spmm + mkl_sparse_order): long rows accumulated by rank -- already in order, mi_sparse_order leaves them and
+    their values alone -- short and medium rows sorted as before.  Through the C ABI: the same row pointer and column indices
+    as mi_sparse_spmm followed by mi_sparse_order, values to tolerance; complex double (no rank kernel) takes the two steps."""
+    import ctypes as ct
+    from sparse_dot_amd._mi_interface import MI, SparseHandle, _check_return_value, sparse_matrix_t
+    rng = np.random.default_rng(21)
+    k, n = 5000, 200000
+    a = sps.random(400, k, density=0.003, format="lil", random_state=5, dtype=np.float64)
+    a[1, rng.choice(k, 900, replace=False)] = 1.5     # long rows of C (tens of thousands of entries) ...
+    a[2, rng.choice(k, 2600, replace=False)] = 0.5
+    a[399, rng.choice(k, 60, replace=False)] = 2.0    # ... medium (513 .. 4096) ...
+    a[17, :] = 0                                      # ... and an empty one
+    a = a.tocsr()
+    a.data[:] = rng.uniform(0.5, 1.5, a.nnz)
+    b = sps.random(k, n, density=80 / n, format="csr", random_state=6, dtype=np.float64)
+    b.data[:] = rng.uniform(0.5, 1.5, b.nnz)
+    a, b = a.astype(dtype), b.astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        a.data = a.data * (1 + 0.5j)
+        b.data = b.data * (0.5 - 1j)
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    want = (a.astype(wide) @ b.astype(wide)).tocsr()
+    want.sort_indices()
+    lens = np.diff(want.indptr)
+    assert lens.max() > 40000 and ((lens > 512) & (lens <= 4096)).any() and (lens == 0).any()
+    with SparseHandle.from_scipy(a) as ha, SparseHandle.from_scipy(b) as hb:
+        outs = []
+        for ordered in (False, True):
+            out = sparse_matrix_t()
+            if ordered:
+                _check_return_value(MI.call("mi_sparse_spmm_ordered", 10, ha.ptr, hb.ptr, ct.byref(out)), "spmm_ordered")
+            else:
+                _check_return_value(MI.call("mi_sparse_spmm", 10, ha.ptr, hb.ptr, ct.byref(out)), "spmm")
+                _check_return_value(MI.call("mi_sparse_order", out), "order")
+            with SparseHandle(out, ha.letter) as hc:
+                outs.append(hc.export("csr_matrix"))
+    for got in outs:
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        assert rel_err(got.data, want.data) <= tol(dtype)
+    got = gpu.dot_product_mkl(a, b, reorder_output=True)   # the public path
+    assert np.array_equal(got.indices, want.indices) and rel_err(got.data, want.data) <= tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.complex64, np.complex128])
 def test_spgemm_hub_rows_accumulate_by_rank(gpu, dtype):
     """Option spgemm_rank = 1 (round 4): the symbolic phase keeps the big rows' column bitmaps, the numeric phase adds every
     product at the RANK of its column (k_spgemm_rank).  Same structure and values as scipy, and the big rows come out SORTED
