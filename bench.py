@@ -509,6 +509,29 @@ def secondary_spgemm(torch, abi, dev, kind, with_cpu):
                                 "all phases: upper bounds, binning, symbolic, scan, numeric)" % reps},
            "parity_rowsum_max_rel_err": rel}
     assert rel <= 1e-12, "SpGEMM row-sum parity check failed: %g" % rel
+    # the same product with ordered rows (the reference's reorder_output=True: mkl_sparse_spmm + mkl_sparse_order,
+    # _sparse_sparse.py:226-230): one mi_sparse_spmm_ordered call, median of 2 after 1
+    try:
+        abi.destroy(hc)
+        hc = None
+        ot = []
+        for rep in range(3):
+            ho = abi.handle_t()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            abi.check(abi.MI.call("mi_sparse_spmm_ordered", 10, ha, hb, ct.byref(ho)), "spmm_ordered")
+            torch.cuda.synchronize()
+            if rep:
+                ot.append(time.perf_counter() - t0)
+            if rep < 2:
+                abi.destroy(ho)
+        hc = ho
+        out["ordered_ms"] = round(_median(ot) * 1e3, 3)
+        out["ordered_note"] = ("mi_sparse_spmm_ordered: the product with every row's columns in increasing order, whole call "
+                               "(product + ordering; long rows by rank when their bitmaps fit in 8 GiB, else sorted run by run in place)")
+    except Exception as exc:  # noqa: BLE001
+        out["ordered_ms"] = None
+        out["ordered_note"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
     out["first_call_note"] = ("first_call_ms is the first product in THIS process; first_call_fresh_process the same product as the first "
                               "thing a new process does.  Both contain one hipMalloc of the 117 GB result, and device memory that has been "
                               "used before -- by this process or by one that has exited -- is scrubbed by the driver when it is handed out "

@@ -335,7 +335,8 @@ struct alignas(16) Word16 {
 // compares of the 64-bit form.
 template <typename K, typename V>
 __global__ void __launch_bounds__(64)
-    k_sort_small(const int64_t* ptr, int32_t* col, int64_t rows, const V* __restrict__ vin, V* __restrict__ vout)
+    k_sort_small(const int64_t* ptr, int32_t* col, int64_t rows, const V* __restrict__ vin, V* __restrict__ vout,
+                 const int64_t* __restrict__ voff)
 {
     constexpr int POS_BITS = sizeof(K) == 4 ? 9 : 32;  // SORT_SMALL_MAX == 512 == 2^9
     constexpr K POS_MASK = (K)(((uint64_t)1 << POS_BITS) - 1);
@@ -347,8 +348,9 @@ __global__ void __launch_bounds__(64)
         const int64_t p0 = ptr[row];
         const int64_t len = ptr[row + 1] - p0;
         if (len > SORT_SMALL_MAX) continue;
+        const int64_t q0 = voff ? voff[row] : p0;  // where the row's values go in `vout` (compact output: sort_csr)
         if (len < 2) {
-            if (len == 1 && lane == 0) vout[p0] = vin[p0];
+            if (len == 1 && lane == 0) vout[q0] = vin[p0];
             continue;
         }
         int64_t n = 2;
@@ -360,7 +362,7 @@ __global__ void __launch_bounds__(64)
         for (int64_t k = lane; k < len; k += 64) {
             const K key = keys[k];
             col[p0 + k] = (int32_t)(key >> POS_BITS);
-            vout[p0 + k] = vin[p0 + (int64_t)(key & POS_MASK)];
+            vout[q0 + k] = vin[p0 + (int64_t)(key & POS_MASK)];
         }
         __syncthreads();
     }
@@ -369,11 +371,13 @@ __global__ void __launch_bounds__(64)
 // rows with SORT_SMALL_MAX < len <= SORT_BLOCK_MAX: row list given explicitly
 template <typename V>
 __global__ void __launch_bounds__(256) k_sort_block(const int64_t* ptr, int32_t* col, const int64_t* row_list,
-                                                    const V* __restrict__ vin, V* __restrict__ vout)
+                                                    const V* __restrict__ vin, V* __restrict__ vout,
+                                                    const int64_t* __restrict__ voff)
 {
     __shared__ uint64_t keys[SORT_BLOCK_MAX];
     const int64_t row = row_list[blockIdx.x];
     const int64_t p0 = ptr[row];
+    const int64_t q0 = voff ? voff[row] : p0;
     const int64_t len = ptr[row + 1] - p0;
     int64_t n = 2;
     while (n < len) n <<= 1;
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(256) k_sort_block(const int64_t* ptr, int32_t*
     for (int64_t k = threadIdx.x; k < len; k += 256) {
         const uint64_t key = keys[k];
         col[p0 + k] = (int32_t)(key >> 32);
-        vout[p0 + k] = vin[p0 + (int64_t)(key & 0xffffffffull)];
+        vout[q0 + k] = vin[p0 + (int64_t)(key & 0xffffffffull)];
     }
 }
 
@@ -393,11 +397,13 @@ __global__ void __launch_bounds__(256) k_sort_block(const int64_t* ptr, int32_t*
 template <typename V>
 __global__ void __launch_bounds__(1024) k_sort_global(const int64_t* ptr, int32_t* col, const int64_t* row_list,
                                                       const int64_t* slab_off, uint64_t* slabs,
-                                                      const V* __restrict__ vin, V* __restrict__ vout)
+                                                      const V* __restrict__ vin, V* __restrict__ vout,
+                                                      const int64_t* __restrict__ voff)
 {
     const int64_t row = row_list[blockIdx.x];
     uint64_t* keys = slabs + slab_off[blockIdx.x];
     const int64_t p0 = ptr[row];
+    const int64_t q0 = voff ? voff[row] : p0;
     const int64_t len = ptr[row + 1] - p0;
     int64_t n = 2;
     while (n < len) n <<= 1;
@@ -408,7 +414,7 @@ __global__ void __launch_bounds__(1024) k_sort_global(const int64_t* ptr, int32_
     for (int64_t k = threadIdx.x; k < len; k += 1024) {
         const uint64_t key = keys[k];
         col[p0 + k] = (int32_t)(key >> 32);
-        vout[p0 + k] = vin[p0 + (int64_t)(key & 0xffffffffull)];
+        vout[q0 + k] = vin[p0 + (int64_t)(key & 0xffffffffull)];
     }
 }
 
@@ -423,7 +429,7 @@ template <typename V>
 __global__ void __launch_bounds__(1024)
     k_sort_bitmap(const int64_t* __restrict__ ptr, int32_t* col, const int64_t* __restrict__ big_rows, int64_t n_big,
                   int64_t ncols, const V* __restrict__ vin, V* __restrict__ vout, unsigned long long* n_fallback,
-                  int64_t* fallback_rows, unsigned long long* work_counter)
+                  int64_t* fallback_rows, unsigned long long* work_counter, const int64_t* __restrict__ voff)
 {
     MI_DYN_SMEM(smem);
     const int64_t words = (ncols + 31) / 32;
@@ -441,6 +447,7 @@ __global__ void __launch_bounds__(1024)
         if (idx >= n_big) break;
         const int64_t row = big_rows[idx];
         const int64_t p0 = ptr[row], len = ptr[row + 1] - p0;
+        const int64_t q0 = voff ? voff[row] : p0;
         for (int64_t k = tid; k < words; k += threads) bits[k] = 0u;
         __syncthreads();
         for (int64_t k = tid; k < len; k += threads) {
@@ -486,7 +493,7 @@ __global__ void __launch_bounds__(1024)
             const int64_t w = c >> 5, g = w / SORT_BITMAP_GROUP;
             int r = gpre[g] + __popc(bits[w] & ((1u << (c & 31)) - 1u));
             for (int64_t ww = g * SORT_BITMAP_GROUP; ww < w; ++ww) r += __popc(bits[ww]);
-            vout[p0 + r] = vin[p0 + k];
+            vout[q0 + r] = vin[p0 + k];
         }
         __syncthreads();  // every column has been read: rewrite them in order from the bitmap
         for (int64_t g = tid; g < groups; g += threads) {
@@ -661,10 +668,21 @@ __global__ void __launch_bounds__(256)
                     if (tid + u * 256 < m) keys[tid + u * 256] = ((uint64_t)(uint32_t)cc[u] << 32) | (uint64_t)(tid + u * 256);
                 __syncthreads();
                 MI_BITONIC(keys, n, (int64_t)tid, 256, __syncthreads())
-                for (int64_t k = tid; k < m; k += 256) {
-                    const uint64_t key = keys[k];
-                    col[p0 + k] = (int32_t)(key >> 32);
-                    vout[p0 + k] = vin[p0 + (int64_t)(key & 0xffffffffull)];
+                // (vout may BE vin: every value of the run is read before the first one is written)
+                V tv[IPT];
+#pragma unroll
+                for (int u = 0; u < IPT; ++u) {
+                    const int k = tid + u * 256;
+                    if (k < m) tv[u] = vin[p0 + (int64_t)(keys[k] & 0xffffffffull)];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < IPT; ++u) {
+                    const int k = tid + u * 256;
+                    if (k < m) {
+                        col[p0 + k] = (int32_t)(keys[k] >> 32);
+                        vout[p0 + k] = tv[u];
+                    }
                 }
                 __syncthreads();
             }
@@ -707,14 +725,24 @@ __global__ void k_sort_classify(const int64_t* ptr, int64_t rows, int64_t big_th
 // rows of at most `max_len` entries: their (sorted) values from the sort's output array back into the matrix (16 lanes per row)
 template <typename V>
 __global__ void __launch_bounds__(256)
-    k_sort_copy_back(const int64_t* __restrict__ ptr, int64_t rows, int64_t max_len, const V* __restrict__ src, V* __restrict__ dst)
+    k_sort_copy_back(const int64_t* __restrict__ ptr, int64_t rows, int64_t max_len, const int64_t* __restrict__ voff,
+                     const V* __restrict__ src, V* __restrict__ dst)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t r = t >> 4;
     if (r >= rows) return;
     const int64_t b = ptr[r], n = ptr[r + 1] - b;
     if (n > max_len) return;
-    for (int64_t k = t & 15; k < n; k += 16) dst[b + k] = src[b + k];
+    const int64_t q = voff[r];
+    for (int64_t k = t & 15; k < n; k += 16) dst[b + k] = src[q + k];
+}
+
+__global__ void k_sort_short_len(const int64_t* __restrict__ ptr, int64_t rows, int64_t max_len, int64_t* __restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int64_t n = ptr[r + 1] - ptr[r];
+    out[r] = n <= max_len ? n : 0;
 }
 
 __global__ void k_big_row_sizes(const int64_t* ptr, const int64_t* rows_list, int64_t n, int64_t* sizes)
@@ -829,9 +857,25 @@ void sort_csr(char vtype, Csr& a)
     // transposes), through a temporary and back when they alias caller HBM.
     const size_t vb = value_bytes(vtype);
     const bool owned = a.val_own.p && a.val == a.val_own.p;
+    // SpGEMM results (the big ones): most of the entries sit in rows that need no second value array -- rows accumulated by
+    // rank are in column order already (Csr::sorted_min_len: no kernel visits them), rows written range by range are sorted
+    // run by run with the run in registers, IN PLACE (k_sort_ranges).  Only the shorter rows then take their values through
+    // `vout`, which is COMPACT (voff[row] = where the row's values go) and copied back (k_sort_copy_back): no second
+    // nnz-sized block -- 78 GB next to the 117 GB of the literal configs[2] result, which pushed the block cache over its
+    // limit and made every ordered product pay the driver's allocation of recycled memory (2.2 s per call).
+    const int64_t sorted_min = a.sorted_min_len > SORT_SMALL_MAX ? a.sorted_min_len : 0;
+    const int64_t ranged_thr = (a.range_cap > 0 && a.range_cap <= 4096 && options().sort_ranges && a.range_min_len > SORT_SMALL_MAX) ? a.range_min_len : 0;
+    const int64_t partial_thr = sorted_min > 0 ? sorted_min : ranged_thr;  // rows of more entries keep their values in place
     DevBuf fresh;
     void* vout_raw;
-    if (owned) {
+    int64_t* voff = nullptr;
+    if (partial_thr > 0) {
+        int64_t* slen = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(a.rows + 1)));
+        voff = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(a.rows + 1)));
+        MI_LAUNCH(k_sort_short_len, grid1d(a.rows, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, partial_thr, slen);
+        const int64_t n_short = exclusive_scan_i64(slen, voff, a.rows);
+        vout_raw = c.scratch_alloc(vb * (size_t)(n_short + 1));
+    } else if (owned) {
         fresh.alloc(vb * (size_t)a.nnz);
         vout_raw = fresh.p;
     } else {
@@ -839,11 +883,8 @@ void sort_csr(char vtype, Csr& a)
     }
     int64_t* counters = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * 4));
     MI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int64_t) * 4, c.stream));
-    // SpGEMM results accumulated by rank: the long rows are in column order already -- no kernel visits them, and their values
-    // (most of the matrix) stay where they are: the rows that ARE sorted take their values through `vout` and back (k_sort_copy_back)
-    const int64_t sorted_min = a.sorted_min_len > SORT_SMALL_MAX ? a.sorted_min_len : 0;
     // SpGEMM results: rows written range by range are sorted range by range (k_sort_ranges)
-    const int64_t ranged_min = (a.range_cap > 0 && a.range_cap <= 4096 && options().sort_ranges) ? a.range_min_len : 0;
+    const int64_t ranged_min = ranged_thr;
     // rows too long for one wave: counting sort through an LDS column bitmap when the matrix is narrow enough
     // for one (then the block-wide comparison sort is not used at all), else comparison sorts in LDS / HBM
     const int64_t words = (a.cols + 31) / 32;
@@ -882,15 +923,16 @@ void sort_csr(char vtype, Csr& a)
         using V = decltype(word);
         const V* vin = static_cast<const V*>(a.val);
         V* vout = static_cast<V*>(vout_raw);
+        V* ranged_out = partial_thr > 0 ? static_cast<V*>(a.val) : vout;  // in place when the short rows use the compact array
         if (a.cols < ((int64_t)1 << 23))
             MI_LAUNCH((k_sort_small<uint32_t, V>), grid1d(a.rows, SORT_ROWS_PER_SMALL_BLOCK), dim3(64), c.stream,
-                      (const int64_t*)a.ptr, a.col, a.rows, vin, vout);
+                      (const int64_t*)a.ptr, a.col, a.rows, vin, vout, (const int64_t*)voff);
         else
             MI_LAUNCH((k_sort_small<uint64_t, V>), grid1d(a.rows, SORT_ROWS_PER_SMALL_BLOCK), dim3(64), c.stream,
-                      (const int64_t*)a.ptr, a.col, a.rows, vin, vout);
+                      (const int64_t*)a.ptr, a.col, a.rows, vin, vout, (const int64_t*)voff);
         if (n_med)
             MI_LAUNCH((k_sort_block<V>), dim3((unsigned)n_med), dim3(256), c.stream, (const int64_t*)a.ptr, a.col,
-                      (const int64_t*)med_rows, vin, vout);
+                      (const int64_t*)med_rows, vin, vout, (const int64_t*)voff);
         if (n_range_items) {
             int64_t npad = 2;
             while (npad < a.range_cap) npad <<= 1;
@@ -903,7 +945,7 @@ void sort_csr(char vtype, Csr& a)
                 constexpr int IPT = decltype(ipt_tag)::value;
                 MI_LAUNCH_SMEM((k_sort_ranges<V, IPT>), dim3((unsigned)wgs), dim3(256), lds, c.stream, (const int64_t*)a.ptr, a.col,
                                (const int64_t*)ranged_rows, (const int64_t*)range_item_off, n_ranged, n_range_items, a.range_cap,
-                               npad, vin, vout, cnt3);
+                               npad, vin, ranged_out, cnt3);
             };
             if (a.range_cap <= 768) go(std::integral_constant<int, 3>{});
             else if (a.range_cap <= 1280) go(std::integral_constant<int, 5>{});
@@ -915,7 +957,7 @@ void sort_csr(char vtype, Csr& a)
             MI_HIP_CHECK(hipMemsetAsync(cnt2, 0, sizeof(unsigned long long) * 2, c.stream));
             MI_LAUNCH_SMEM((k_sort_bitmap<V>), dim3((unsigned)(n_big < 512 ? n_big : 512)), dim3(1024), bitmap_bytes, c.stream,
                            (const int64_t*)a.ptr, a.col, (const int64_t*)big_rows, n_big, a.cols, vin, vout, cnt2, fallback,
-                           cnt2 + 1);
+                           cnt2 + 1, (const int64_t*)voff);
             unsigned long long nf = 0;
             MI_HIP_CHECK(hipMemcpyAsync(&nf, cnt2, sizeof(nf), hipMemcpyDeviceToHost, c.stream));
             MI_HIP_CHECK(hipStreamSynchronize(c.stream));
@@ -931,22 +973,21 @@ void sort_csr(char vtype, Csr& a)
             const int64_t total = exclusive_scan_i64(sizes, doff, n_big);
             uint64_t* slabs = static_cast<uint64_t*>(c.scratch_alloc(sizeof(uint64_t) * (size_t)total));
             MI_LAUNCH((k_sort_global<V>), dim3((unsigned)n_big), dim3(1024), c.stream, (const int64_t*)a.ptr, a.col,
-                      (const int64_t*)big_rows, (const int64_t*)doff, slabs, vin, vout);
+                      (const int64_t*)big_rows, (const int64_t*)doff, slabs, vin, vout, (const int64_t*)voff);
         }
     };
     if (vb == 4) run(uint32_t{});
     else if (vb == 8) run(uint64_t{});
     else run(Word16{});
-    if (sorted_min > 0) {
+    if (partial_thr > 0) {
         auto back = [&](auto word) {
             using V = decltype(word);
-            MI_LAUNCH((k_sort_copy_back<V>), grid1d(a.rows * 16, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, sorted_min,
-                      (const V*)vout_raw, static_cast<V*>(a.val));
+            MI_LAUNCH((k_sort_copy_back<V>), grid1d(a.rows * 16, 256), dim3(256), c.stream, (const int64_t*)a.ptr, a.rows, partial_thr,
+                      (const int64_t*)voff, (const V*)vout_raw, static_cast<V*>(a.val));
         };
         if (vb == 4) back(uint32_t{});
         else if (vb == 8) back(uint64_t{});
         else back(Word16{});
-        if (owned) MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // `fresh` goes back to the cache
     } else if (owned) {
         MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // the old block goes back to the cache: nothing may still read it
         a.val_own = std::move(fresh);

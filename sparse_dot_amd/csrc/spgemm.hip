@@ -3401,9 +3401,9 @@ static mi_sparse_status_t spmm_entry(int op, mi_sparse_matrix_t A, mi_sparse_mat
         if (ha->bsr.valid && hb->bsr.valid && ha->bsr.bs == hb->bsr.bs) r->result_bs = ha->bsr.bs;
         try {
             mi::spgemm(ha->vtype, a, b, false, r->csr, ordered);
-            if (ordered && !mi::rows_sorted(r->csr)) {
+            if (ordered) {
                 mi::ctx().scratch_reset();
-                mi::sort_csr(ha->vtype, r->csr);
+                mi::sort_csr(ha->vtype, r->csr);  // (looks at the rows first: a result that is in order already is left alone)
             }
             mi::ctx().sync();
         } catch (...) {
