@@ -570,6 +570,48 @@ def secondary_spgemm(torch, abi, dev, kind, with_cpu):
     return out
 
 
+def secondary_gemm(torch, abi, dev, with_cpu):
+    """SURVEY section 8 a7 / a8 (the dense x dense fallback, the only MFMA consumer): mi_cblas_sgemm / mi_cblas_dgemm on
+    device-resident 4096^3 operands against the dense MFMA peak; numpy's BLAS on the host beside it."""
+    m = n = k = 4096
+    out = {"workload": "dense x dense fallback (cblas_?gemm, reference _dense_dense.py:53-66): 4096 x 4096 x 4096, row-major, device-resident"}
+    for letter, tdt, peak in (("s", torch.float32, 157.3), ("d", torch.float64, 78.6)):
+        A = torch.rand((m, k), device=dev, dtype=tdt)
+        Bm = torch.rand((k, n), device=dev, dtype=tdt)
+        C = torch.empty((m, n), device=dev, dtype=tdt)
+
+        def step():
+            abi.check(abi.MI.call("mi_cblas_%sgemm" % letter, 101, 111, 111, m, n, k, 1.0, A.data_ptr(), k, Bm.data_ptr(), n, 0.0,
+                                  C.data_ptr(), n), "gemm")
+        step()
+        torch.cuda.synchronize()
+        rows = torch.randint(0, m, (16,), device=dev)
+        want = A[rows].double() @ Bm.double()
+        err = float(((C[rows].double() - want).abs() / want.abs().clamp(min=1e-300)).max())
+        ok = err <= (1e-5 if letter == "s" else 1e-12)  # (recorded, not asserted: 4096-term fp32 sums sit within a factor 3 of the bar)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / 5
+        tf = 2.0 * m * n * k / t / 1e12
+        ent = {"ms": round(t * 1e3, 3), "value": round(tf, 2), "unit": "TFLOP/s", "max_rel_err_rows": err, "within_tolerance": bool(ok),
+               "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                            "note": "dense %s MFMA peak (MI355X_MICROARCH.md)" % ("fp32" if letter == "s" else "fp64")}}
+        if with_cpu:
+            import numpy as np
+            ah, bh = A.cpu().numpy(), Bm.cpu().numpy()
+            np.dot(ah[:512], bh)
+            t0 = time.perf_counter()
+            np.dot(ah, bh)
+            tc = time.perf_counter() - t0
+            ent["cpu_baseline"] = {"value": round(2.0 * m * n * k / tc / 1e12, 3), "unit": "TFLOP/s", "cores": _host_cores(), "kind": "port",
+                                   "sample": "numpy.dot of the same operands on the host (its BLAS, all threads), one call after a warm-up"}
+        out["f32" if letter == "s" else "f64"] = ent
+        del A, Bm, C
+    return out
+
+
 def secondary_gram(torch, abi, dev, with_cpu):
     """BASELINE configs[3] as literally stated: A^T A of a uniform CSR 4 M x 262144, 64/row fp32, dense output
     (256 GiB, upper triangle written).  Falls back to half the width if the output cannot be allocated."""
@@ -886,7 +928,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 in this run (use the committed summary)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
-    ap.add_argument("--secondary", default="all", help="comma list of: uniform,spgemm,spgemm_rmat,gram,host_api (default all)")
+    ap.add_argument("--secondary", default="all", help="comma list of: uniform,spgemm,spgemm_rmat,gram,host_api,gemm (default all)")
     ap.add_argument("--gather-mode", default="bcast", choices=["bcast", "padded", "p2p"])
     ap.add_argument("--bcast-mode", default="bcast", choices=["bcast", "scatter_allgather"])
     ap.add_argument("--no-variants", action="store_true", help="N > 1: skip the p2p / pipelined forms and configs[4]")
@@ -1219,7 +1261,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    want_sec = set(args.secondary.split(",")) if args.secondary != "all" else {"uniform", "spgemm", "spgemm_rmat", "gram", "host_api"}
+    want_sec = set(args.secondary.split(",")) if args.secondary != "all" else {"uniform", "spgemm", "spgemm_rmat", "gram", "host_api", "gemm"}
     with_cpu = not args.no_cpu
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "rmat":
         secondary = {}
@@ -1236,6 +1278,13 @@ def main():
             line["cpu_baseline"] = None
         del B, indptr, indices, vals
         torch.cuda.empty_cache()
+        if "gemm" in want_sec:
+            try:
+                secondary["gemm_dense"] = secondary_gemm(torch, abi, dev, with_cpu)
+            except AssertionError:
+                raise
+            except Exception as exc:  # noqa: BLE001
+                secondary["gemm_dense"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         for key, fn in (("spgemm_uniform", lambda: secondary_spgemm(torch, abi, dev, "uniform", with_cpu)),
                         ("spgemm_rmat_literal", lambda: secondary_spgemm(torch, abi, dev, "rmat", with_cpu)),
                         ("gram_dense", lambda: secondary_gram(torch, abi, dev, with_cpu))):

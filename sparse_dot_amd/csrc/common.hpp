@@ -602,6 +602,7 @@ struct Options {
     int64_t spmm_hot_force = 0;    // tests: tag even tiny / unskewed matrices
     int64_t spmm_slices = 0;       // XCD-affine column slices of the dense operand: 0 = by row width (256-byte slices), else 1, 2, 4, 8
     int64_t spmm_hot_kb = 8192;    // bytes of hot B rows to keep L2 resident (0 disables hot/cold tagging)
+    int64_t gemm_big_tiles = -1;   // dense x dense: products of at least this many 128 x 128 output tiles take the pipelined 128-tile kernel (-1: one per CU; 0: never)
     int64_t spmm_kpart = 1;        // column-partitioned long rows (SpmmKpart) from the third product of a handle on: 0 never, 1 when it pays, 2 always (tests)
     int64_t spmm_kpart_min_row = 64;   // ... rows of at least this many entries (the partial rows cost 2 x 8 row widths per long row: break-even ~53 entries; 48 / 64 / 96 / 128 / 160 on the headline matrix: 1.248 / 1.240 / 1.240 / 1.27 / 1.37 ms)
     int64_t spmm_kpart_chunk = 128;    // ... work items per wave of the two partitioned kernels (spmm_chunk for every other product): 128 / 256 = 1.217-1.229 / 1.234-1.240 ms

@@ -106,6 +106,276 @@ __global__ void __launch_bounds__(256)
     (void)wave;
 }
 
+// ---- the same product for operands large enough to fill the chip (round 5): 128 x 128 tile per workgroup ------------------
+// The 64 x 64 kernel above reaches 0.48 of the fp32 MFMA peak at 4096^3 (75.8 of 157.3 TFLOP/s; B stored transposed 0.33;
+// fp64 39 of 78.6); this one 0.59-0.64 in fp32 either way (92-101 TFLOP/s; K steps of 32: the same), tools/gpu_gemm.py:
+// its K step is a scalar gather of 8 elements per thread behind two barriers, with nothing in flight while the MFMAs run.
+// Here: four waves x (64 x 64) = 2 x 2 (fp32, 32x32x2) or 4 x 4 (fp64, 16x16x4) accumulator tiles per wave -- an A / B fragment
+// read from LDS feeds two / four MFMAs --, K stepped by 16 through TWO LDS buffers: the next step's panel of A and B is
+// requested from HBM (16-byte loads along whichever dimension is contiguous, 4 / 8-byte ones otherwise) BEFORE this step's 32 /
+// 64 MFMAs per wave are issued and written to the other buffer after them: one barrier per step, loads under the matrix pipe.
+// LDS images are k-major (As[k][i], Bs[k][j]): a fragment read is 32 (16) consecutive words per k, conflict-free.
+#ifndef MI_GEMM_BK32
+#define MI_GEMM_BK32 16
+#endif
+constexpr int GB = 128;   // output tile
+template <typename T>
+constexpr int gemm_bk() { return sizeof(T) == 4 ? MI_GEMM_BK32 : 16; }   // K step
+// row padding of the LDS images: fp32 fragments are 32 consecutive words of one row (conflict-free with any stride); an fp64
+// fragment read takes 16 doubles from each of two k rows per half-wave: the row stride must be 32 words off a multiple of 64
+template <typename T>
+constexpr int gemm_pad() { return sizeof(T) == 8 ? 16 : 4; }
+
+// how a panel is read from HBM: 0 element by element, 1 vectors along the tile's row / column index, 2 vectors along k
+__host__ __device__ inline int gemm_vec_mode(int64_t s_mn, int64_t s_k, int64_t ld_ok16)
+{
+    if (!ld_ok16) return 0;
+    if (s_mn == 1) return 1;
+    if (s_k == 1) return 2;
+    return 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_gemm_mfma128(int64_t M, int64_t N, int64_t K, T alpha, const T* __restrict__ A, int64_t a_rs, int64_t a_cs, int a_mode,
+                   const T* __restrict__ B, int64_t b_rs, int64_t b_cs, int b_mode, T beta, int beta_zero,
+                   T* __restrict__ C, int64_t c_rs, int64_t c_cs, int tri, int tiles_n)
+{
+    constexpr bool is_f32 = std::is_same<T, float>::value;
+    constexpr int GBK = gemm_bk<T>();
+    constexpr int V = 16 / (int)sizeof(T);            // elements per 16-byte vector
+    constexpr int EPT = GB * GBK / 256;               // elements of each panel per thread (8)
+    constexpr int VPT = EPT / V;                      // vectors of each panel per thread (2 / 4)
+    constexpr int GBP = gemm_pad<T>();
+    __shared__ __attribute__((aligned(16))) T As[2][GBK][GB + GBP];
+    __shared__ __attribute__((aligned(16))) T Bs[2][GBK][GB + GBP];
+    // tile order: groups of 8 tile rows walk the tile columns together (the A panels of a group and the B panel of a column
+    // are shared by workgroups that run at the same time)
+    const int64_t tiles_m = (M + GB - 1) / GB;
+    int64_t bi, bj;
+    {
+        const int64_t b = blockIdx.x, grp = 8, per = grp * tiles_n;
+        const int64_t g0 = (b / per) * grp, rows_here = tiles_m - g0 < grp ? tiles_m - g0 : grp;
+        bi = g0 + (b % per) % rows_here;
+        bj = (b % per) / rows_here;
+    }
+    const int64_t i0 = bi * GB, j0 = bj * GB;
+    if (tri == 1 && j0 + GB - 1 < i0) return;  // tile entirely below the diagonal
+    if (tri == 2 && i0 + GB - 1 < j0) return;
+    const int tid = threadIdx.x, wave = tid / WAVE, lane = tid % WAVE;
+    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+
+    // ---- HBM -> registers -> LDS, one panel of A (GB x GBK) and one of B (GBK x GB) per K step ----
+    T ra[EPT], rb[EPT];
+    auto fetch = [&](int64_t k0) {
+        // A: element (i, k) of the panel
+        if (a_mode == 1) {  // vectors along i (A stored with i contiguous)
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int e = (tid + v * 256) * V, kk = e / GB, ii = e % GB;
+                const int64_t gi = i0 + ii, gk = k0 + kk;
+                if (gi + V <= M && gk < K) {
+                    const vec<T, V> x = *reinterpret_cast<const vec<T, V>*>(A + gi * a_rs + gk * a_cs);
+#pragma unroll
+                    for (int q = 0; q < V; ++q) ra[v * V + q] = x.v[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) ra[v * V + q] = (gi + q < M && gk < K) ? A[(gi + q) * a_rs + gk * a_cs] : T(0);
+                }
+            }
+        } else if (a_mode == 2) {  // vectors along k
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int e = (tid + v * 256) * V, ii = e / GBK, kk = e % GBK;
+                const int64_t gi = i0 + ii, gk = k0 + kk;
+                if (gi < M && gk + V <= K) {
+                    const vec<T, V> x = *reinterpret_cast<const vec<T, V>*>(A + gi * a_rs + gk * a_cs);
+#pragma unroll
+                    for (int q = 0; q < V; ++q) ra[v * V + q] = x.v[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) ra[v * V + q] = (gi < M && gk + q < K) ? A[gi * a_rs + (gk + q) * a_cs] : T(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = tid + u * 256, kk = e / GB, ii = e % GB;
+                const int64_t gi = i0 + ii, gk = k0 + kk;
+                ra[u] = (gi < M && gk < K) ? A[gi * a_rs + gk * a_cs] : T(0);
+            }
+        }
+        // B: element (k, j) of the panel
+        if (b_mode == 1) {  // vectors along j
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int e = (tid + v * 256) * V, kk = e / GB, jj = e % GB;
+                const int64_t gj = j0 + jj, gk = k0 + kk;
+                if (gj + V <= N && gk < K) {
+                    const vec<T, V> x = *reinterpret_cast<const vec<T, V>*>(B + gk * b_rs + gj * b_cs);
+#pragma unroll
+                    for (int q = 0; q < V; ++q) rb[v * V + q] = x.v[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) rb[v * V + q] = (gj + q < N && gk < K) ? B[gk * b_rs + (gj + q) * b_cs] : T(0);
+                }
+            }
+        } else if (b_mode == 2) {  // vectors along k
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int e = (tid + v * 256) * V, jj = e / GBK, kk = e % GBK;
+                const int64_t gj = j0 + jj, gk = k0 + kk;
+                if (gj < N && gk + V <= K) {
+                    const vec<T, V> x = *reinterpret_cast<const vec<T, V>*>(B + gk * b_rs + gj * b_cs);
+#pragma unroll
+                    for (int q = 0; q < V; ++q) rb[v * V + q] = x.v[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) rb[v * V + q] = (gj < N && gk + q < K) ? B[(gk + q) * b_rs + gj * b_cs] : T(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = tid + u * 256, kk = e / GB, jj = e % GB;
+                const int64_t gj = j0 + jj, gk = k0 + kk;
+                rb[u] = (gj < N && gk < K) ? B[gk * b_rs + gj * b_cs] : T(0);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+        if (a_mode == 1) {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int e = (tid + v * 256) * V, kk = e / GB, ii = e % GB;
+                vec<T, V> x;
+#pragma unroll
+                for (int q = 0; q < V; ++q) x.v[q] = ra[v * V + q];
+                *reinterpret_cast<vec<T, V>*>(&As[buf][kk][ii]) = x;
+            }
+        } else if (a_mode == 2) {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int e = (tid + v * 256) * V, ii = e / GBK, kk = e % GBK;
+#pragma unroll
+                for (int q = 0; q < V; ++q) As[buf][kk + q][ii] = ra[v * V + q];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = tid + u * 256;
+                As[buf][e / GB][e % GB] = ra[u];
+            }
+        }
+        if (b_mode == 1) {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int e = (tid + v * 256) * V, kk = e / GB, jj = e % GB;
+                vec<T, V> x;
+#pragma unroll
+                for (int q = 0; q < V; ++q) x.v[q] = rb[v * V + q];
+                *reinterpret_cast<vec<T, V>*>(&Bs[buf][kk][jj]) = x;
+            }
+        } else if (b_mode == 2) {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int e = (tid + v * 256) * V, jj = e / GBK, kk = e % GBK;
+#pragma unroll
+                for (int q = 0; q < V; ++q) Bs[buf][kk + q][jj] = rb[v * V + q];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = tid + u * 256;
+                Bs[buf][e / GB][e % GB] = rb[u];
+            }
+        }
+    };
+
+    f32x16 acc32[2][2];
+    f64x4 acc64[4][4];
+    if constexpr (is_f32) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[a][b][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc64[a][b][r] = 0.0;
+    }
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t k0 = 0; k0 < K; k0 += GBK) {
+        const bool more = k0 + GBK < K;
+        if (more) fetch(k0 + GBK);  // in flight under this step's MFMAs
+        if constexpr (is_f32) {
+#pragma unroll
+            for (int kk = 0; kk < GBK; kk += 2) {
+                const int kr = kk + (lane >> 5), c = lane & 31;
+                const float a0 = As[cur][kr][wi + c], a1 = As[cur][kr][wi + 32 + c];
+                const float b0 = Bs[cur][kr][wj + c], b1 = Bs[cur][kr][wj + 32 + c];
+                acc32[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc32[0][0], 0, 0, 0);
+                acc32[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc32[0][1], 0, 0, 0);
+                acc32[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc32[1][0], 0, 0, 0);
+                acc32[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc32[1][1], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < GBK; kk += 4) {
+                const int kr = kk + (lane >> 4), c = lane & 15;
+                double a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a[t] = As[cur][kr][wi + t * 16 + c];
+                    b[t] = Bs[cur][kr][wj + t * 16 + c];
+                }
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj)
+                        acc64[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc64[ti][tj], 0, 0, 0);
+            }
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    auto store = [&](int64_t gi, int64_t gj, T v) {
+        if (gi < M && gj < N && tri_keep<T>(tri, gi, gj)) {
+            T* c = C + gi * c_rs + gj * c_cs;
+            *c = beta_zero ? alpha * v : alpha * v + beta * (*c);
+        }
+    };
+    if constexpr (is_f32) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    store(i0 + wi + a * 32 + row, j0 + wj + b * 32 + (lane & 31), acc32[a][b][r]);
+                }
+    } else {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    store(i0 + wi + ti * 16 + (lane >> 4) + 4 * r, j0 + wj + tj * 16 + (lane & 15), acc64[ti][tj][r]);
+    }
+}
+
 // complex (and any) types: one thread per output element
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -173,9 +443,27 @@ static void gemm_run(int layout, int ta, int tb, int64_t m, int64_t n, int64_t k
                   static_cast<const T*>(sb.dev), b_rs, b_cs, (int)(tb == MI_CBLAS_CONJ_TRANS), beta, beta_zero,
                   static_cast<T*>(sc.dev), c_rs, c_cs, tri);
     } else {
-        MI_LAUNCH((k_gemm_mfma<T>), dim3((unsigned)ceil_div(n, GT), (unsigned)ceil_div(m, GT)), dim3(256), c.stream, m, n,
-                  k, alpha, static_cast<const T*>(sa.dev), a_rs, a_cs, static_cast<const T*>(sb.dev), b_rs, b_cs, beta,
-                  beta_zero, static_cast<T*>(sc.dev), c_rs, c_cs, tri);
+        // operands that fill the chip with 128 x 128 tiles take the pipelined kernel (k_gemm_mfma128), the rest the 64 x 64 one
+        const int64_t tm = ceil_div(m, (int64_t)GB), tn = ceil_div(n, (int64_t)GB);
+        const int64_t big_min = options().gemm_big_tiles >= 0 ? options().gemm_big_tiles : (int64_t)std::max(c.cus, 1);
+        // (fp64 stays on the 64 x 64 kernel: with 4 x 4 accumulator tiles per wave the 128-tile form needs every register of
+        // a SIMD for ONE wave and measures 31-36 TFLOP/s against 36-39)
+        if (sizeof(T) == 4 && options().gemm_big_tiles != 0 && tm * tn >= big_min && k >= 2 * gemm_bk<T>() && tm * tn < ((int64_t)1 << 31)) {
+            const T* ad = static_cast<const T*>(sa.dev);
+            const T* bd = static_cast<const T*>(sb.dev);
+            auto ok16 = [&](const T* ptr, int64_t ld) {  // 16-byte vectors: base and every row / column start aligned
+                return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+            };
+            // the stored leading dimension is whichever of the two strides is not 1
+            const int a_mode = gemm_vec_mode(a_rs, a_cs, ok16(ad, a_rs == 1 ? a_cs : a_rs));
+            const int b_mode = gemm_vec_mode(b_cs, b_rs, ok16(bd, b_cs == 1 ? b_rs : b_cs));
+            MI_LAUNCH((k_gemm_mfma128<T>), dim3((unsigned)(tm * tn)), dim3(256), c.stream, m, n, k, alpha, ad, a_rs, a_cs, a_mode, bd,
+                      b_rs, b_cs, b_mode, beta, beta_zero, static_cast<T*>(sc.dev), c_rs, c_cs, tri, (int)tn);
+        } else {
+            MI_LAUNCH((k_gemm_mfma<T>), dim3((unsigned)ceil_div(n, GT), (unsigned)ceil_div(m, GT)), dim3(256), c.stream, m, n,
+                      k, alpha, static_cast<const T*>(sa.dev), a_rs, a_cs, static_cast<const T*>(sb.dev), b_rs, b_cs, beta,
+                      beta_zero, static_cast<T*>(sc.dev), c_rs, c_cs, tri);
+        }
     }
     MI_HIP_CHECK(hipGetLastError());
     if (sa.host || sb.host) c.sync();

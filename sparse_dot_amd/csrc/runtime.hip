@@ -788,6 +788,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
         } else if (!strcmp(name, "spmm_hot_kb")) {
             if (value < 0) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_hot_kb must be >= 0");
             o.spmm_hot_kb = value;
+        } else if (!strcmp(name, "gemm_big_tiles")) {
+            o.gemm_big_tiles = value;
         } else if (!strcmp(name, "spmm_kpart")) {
             if (value < 0 || value > 2) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spmm_kpart must be 0, 1 or 2");
             o.spmm_kpart = value;
