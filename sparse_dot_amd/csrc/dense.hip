@@ -108,15 +108,15 @@ __global__ void __launch_bounds__(256)
 
 // ---- the same product for operands large enough to fill the chip (round 5): 128 x 128 tile per workgroup ------------------
 // The 64 x 64 kernel above reaches 0.48 of the fp32 MFMA peak at 4096^3 (75.8 of 157.3 TFLOP/s; B stored transposed 0.33;
-// fp64 39 of 78.6); this one 0.59-0.64 in fp32 either way (92-101 TFLOP/s; K steps of 32: the same), tools/gpu_gemm.py:
+// fp64 39 of 78.6); this one 0.63-0.74 in fp32 over the four storage orders (98-116 TFLOP/s, K steps of 32), tools/gpu_gemm.py:
 // its K step is a scalar gather of 8 elements per thread behind two barriers, with nothing in flight while the MFMAs run.
 // Here: four waves x (64 x 64) = 2 x 2 (fp32, 32x32x2) or 4 x 4 (fp64, 16x16x4) accumulator tiles per wave -- an A / B fragment
-// read from LDS feeds two / four MFMAs --, K stepped by 16 through TWO LDS buffers: the next step's panel of A and B is
+// read from LDS feeds two / four MFMAs --, K stepped by 32 (fp32) through TWO LDS buffers: the next step's panel of A and B is
 // requested from HBM (16-byte loads along whichever dimension is contiguous, 4 / 8-byte ones otherwise) BEFORE this step's 32 /
 // 64 MFMAs per wave are issued and written to the other buffer after them: one barrier per step, loads under the matrix pipe.
 // LDS images are k-major (As[k][i], Bs[k][j]): a fragment read is 32 (16) consecutive words per k, conflict-free.
 #ifndef MI_GEMM_BK32
-#define MI_GEMM_BK32 16
+#define MI_GEMM_BK32 32
 #endif
 constexpr int GB = 128;   // output tile
 template <typename T>
@@ -309,13 +309,41 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc64[a][b][r] = 0.0;
     }
+    // interior tiles with vector loads on both operands: the address of every load of a panel is formed ONCE (a pointer per
+    // vector, advanced by one K step per iteration) -- the general `fetch` above spends ~300 instructions per step on index
+    // arithmetic, 64-bit products and bounds, and two workgroups that share a CU run in lockstep (launched together, same
+    // work), so that phase is not hidden behind the other workgroup's MFMAs: 0.59 -> MfmaUtil of the fp32 kernel at 4096^3
+    const bool fast = a_mode != 0 && b_mode != 0 && i0 + GB <= M && j0 + GB <= N;
+    const T* pa[VPT];
+    const T* pb[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int e = (tid + v * 256) * V;
+        const int a_ii = a_mode == 1 ? e % GB : e / GBK, a_kk = a_mode == 1 ? e / GB : e % GBK;
+        const int b_jj = b_mode == 1 ? e % GB : e / GBK, b_kk = b_mode == 1 ? e / GB : e % GBK;
+        pa[v] = A + (i0 + a_ii) * a_rs + (int64_t)a_kk * a_cs;
+        pb[v] = B + (int64_t)b_kk * b_rs + (j0 + b_jj) * b_cs;
+    }
+    const int64_t a_step = (int64_t)GBK * a_cs, b_step = (int64_t)GBK * b_rs;
+    auto fetch_fast = [&]() {  // the next full K step of both panels
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            pa[v] += a_step;
+            pb[v] += b_step;
+            const vec<T, V> x = *reinterpret_cast<const vec<T, V>*>(pa[v]);
+            const vec<T, V> y = *reinterpret_cast<const vec<T, V>*>(pb[v]);
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                ra[v * V + q] = x.v[q];
+                rb[v * V + q] = y.v[q];
+            }
+        }
+    };
     fetch(0);
     stash(0);
     __syncthreads();
     int cur = 0;
-    for (int64_t k0 = 0; k0 < K; k0 += GBK) {
-        const bool more = k0 + GBK < K;
-        if (more) fetch(k0 + GBK);  // in flight under this step's MFMAs
+    auto mma = [&](int cur) {
         if constexpr (is_f32) {
 #pragma unroll
             for (int kk = 0; kk < GBK; kk += 2) {
@@ -344,6 +372,21 @@ __global__ void __launch_bounds__(256)
                         acc64[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc64[ti][tj], 0, 0, 0);
             }
         }
+    };
+    int64_t k0 = 0;
+    if (fast) {  // full K steps of interior tiles: requests, MFMAs and LDS writes in one straight line
+        for (; k0 + 2 * GBK <= K; k0 += GBK) {
+            fetch_fast();
+            mma(cur);
+            stash(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    for (; k0 < K; k0 += GBK) {
+        const bool more = k0 + GBK < K;
+        if (more) fetch(k0 + GBK);  // in flight under this step's MFMAs
+        mma(cur);
         if (more) stash(cur ^ 1);
         __syncthreads();
         cur ^= 1;

@@ -18,9 +18,11 @@ for a in (sys.argv[1:] or ["1024", "4096", "8192"]):
 for letter, tdt in (("s", torch.float32), ("d", torch.float64)):
     for (m, n, k) in shapes:
         A = torch.rand((m, k), device=dev, dtype=tdt); B = torch.rand((k, n), device=dev, dtype=tdt); C = torch.empty((m, n), device=dev, dtype=tdt)
-        for tb, Bop, ldb in ((111, B, n), (112, B.t().contiguous(), k)):  # B as stored, and B^T stored (op = T)
+        At = A.t().contiguous()
+        for ta, tb, Aop, lda, Bop, ldb in ((111, 111, A, k, B, n), (111, 112, A, k, B.t().contiguous(), k),  # NN, NT (B^T stored)
+                                           (112, 111, At, m, B, n), (112, 112, At, m, B.t().contiguous(), k)):  # TN (A^T stored), TT
             def step():
-                r = MI.call("mi_cblas_%sgemm" % letter, 101, 111, tb, m, n, k, 1.0, A.data_ptr(), k, Bop.data_ptr(), ldb, 0.0, C.data_ptr(), n)
+                r = MI.call("mi_cblas_%sgemm" % letter, 101, ta, tb, m, n, k, 1.0, Aop.data_ptr(), lda, Bop.data_ptr(), ldb, 0.0, C.data_ptr(), n)
                 if r:
                     _check_return_value(r, "gemm")
             step(); torch.cuda.synchronize()
@@ -38,6 +40,6 @@ for letter, tdt in (("s", torch.float32), ("d", torch.float64)):
             e1.record(); torch.cuda.synchronize()
             ms_t = e0.elapsed_time(e1) / reps
             tf = 2.0 * m * n * k / ms / 1e9
-            print(json.dumps({"gemm": letter, "m": m, "n": n, "k": k, "transb": tb == 112, "ms": round(ms, 4), "TFLOPs": round(tf, 2),
+            print(json.dumps({"gemm": letter, "m": m, "n": n, "k": k, "transa": ta == 112, "transb": tb == 112, "ms": round(ms, 4), "TFLOPs": round(tf, 2),
                               "frac_of_mfma_peak": round(tf / PEAK[letter], 4), "torch_matmul_TFLOPs": round(2.0 * m * n * k / ms_t / 1e9, 2),
                               "max_rel_err_vs_torch": err}), flush=True)
