@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256)
 // The 64 x 64 kernel above reaches 0.48 of the fp32 MFMA peak at 4096^3 (75.8 of 157.3 TFLOP/s; B stored transposed 0.33;
 // fp64 39 of 78.6); this one 0.63-0.74 in fp32 over the four storage orders (98-116 TFLOP/s, K steps of 32), tools/gpu_gemm.py:
 // its K step is a scalar gather of 8 elements per thread behind two barriers, with nothing in flight while the MFMAs run.
-// Here: four waves x (64 x 64) = 2 x 2 (fp32, 32x32x2) or 4 x 4 (fp64, 16x16x4) accumulator tiles per wave -- an A / B fragment
+// Here: four waves x (64 x 64) = 2 x 2 accumulator tiles (fp32, 32x32x2) or eight waves x (32 x 64) = 2 x 4 (fp64, 16x16x4) per wave -- an A / B fragment
 // read from LDS feeds two / four MFMAs --, K stepped by 32 (fp32) through TWO LDS buffers: the next step's panel of A and B is
 // requested from HBM (16-byte loads along whichever dimension is contiguous, 4 / 8-byte ones otherwise) BEFORE this step's 32 /
 // 64 MFMAs per wave are issued and written to the other buffer after them: one barrier per step, loads under the matrix pipe.
@@ -136,7 +136,10 @@ __host__ __device__ inline int gemm_vec_mode(int64_t s_mn, int64_t s_k, int64_t 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256)
+constexpr int gemm_threads() { return sizeof(T) == 4 ? 256 : 512; }
+
+template <typename T>
+__global__ void __launch_bounds__(gemm_threads<T>())
     k_gemm_mfma128(int64_t M, int64_t N, int64_t K, T alpha, const T* __restrict__ A, int64_t a_rs, int64_t a_cs, int a_mode,
                    const T* __restrict__ B, int64_t b_rs, int64_t b_cs, int b_mode, T beta, int beta_zero,
                    T* __restrict__ C, int64_t c_rs, int64_t c_cs, int tri, int tiles_n)
@@ -144,7 +147,8 @@ __global__ void __launch_bounds__(256)
     constexpr bool is_f32 = std::is_same<T, float>::value;
     constexpr int GBK = gemm_bk<T>();
     constexpr int V = 16 / (int)sizeof(T);            // elements per 16-byte vector
-    constexpr int EPT = GB * GBK / 256;               // elements of each panel per thread (8)
+    constexpr int NT = gemm_threads<T>();             // 256 (fp32: four waves x 64 x 64) / 512 (fp64: eight waves x 32 x 64)
+    constexpr int EPT = GB * GBK / NT;                // elements of each panel per thread
     constexpr int VPT = EPT / V;                      // vectors of each panel per thread (2 / 4)
     constexpr int GBP = gemm_pad<T>();
     __shared__ __attribute__((aligned(16))) T As[2][GBK][GB + GBP];
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(256)
     if (tri == 1 && j0 + GB - 1 < i0) return;  // tile entirely below the diagonal
     if (tri == 2 && i0 + GB - 1 < j0) return;
     const int tid = threadIdx.x, wave = tid / WAVE, lane = tid % WAVE;
-    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+    const int wi = is_f32 ? (wave >> 1) * 64 : (wave >> 1) * 32, wj = (wave & 1) * 64;
 
     // ---- HBM -> registers -> LDS, one panel of A (GB x GBK) and one of B (GBK x GB) per K step ----
     T ra[EPT], rb[EPT];
@@ -172,7 +176,7 @@ __global__ void __launch_bounds__(256)
         if (a_mode == 1) {  // vectors along i (A stored with i contiguous)
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
-                const int e = (tid + v * 256) * V, kk = e / GB, ii = e % GB;
+                const int e = (tid + v * NT) * V, kk = e / GB, ii = e % GB;
                 const int64_t gi = i0 + ii, gk = k0 + kk;
                 if (gi + V <= M && gk < K) {
                     const vec<T, V> x = *reinterpret_cast<const vec<T, V>*>(A + gi * a_rs + gk * a_cs);
@@ -186,7 +190,7 @@ __global__ void __launch_bounds__(256)
         } else if (a_mode == 2) {  // vectors along k
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
-                const int e = (tid + v * 256) * V, ii = e / GBK, kk = e % GBK;
+                const int e = (tid + v * NT) * V, ii = e / GBK, kk = e % GBK;
                 const int64_t gi = i0 + ii, gk = k0 + kk;
                 if (gi < M && gk + V <= K) {
                     const vec<T, V> x = *reinterpret_cast<const vec<T, V>*>(A + gi * a_rs + gk * a_cs);
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(256)
         } else {
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
-                const int e = tid + u * 256, kk = e / GB, ii = e % GB;
+                const int e = tid + u * NT, kk = e / GB, ii = e % GB;
                 const int64_t gi = i0 + ii, gk = k0 + kk;
                 ra[u] = (gi < M && gk < K) ? A[gi * a_rs + gk * a_cs] : T(0);
             }
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(256)
         if (b_mode == 1) {  // vectors along j
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
-                const int e = (tid + v * 256) * V, kk = e / GB, jj = e % GB;
+                const int e = (tid + v * NT) * V, kk = e / GB, jj = e % GB;
                 const int64_t gj = j0 + jj, gk = k0 + kk;
                 if (gj + V <= N && gk < K) {
                     const vec<T, V> x = *reinterpret_cast<const vec<T, V>*>(B + gk * b_rs + gj * b_cs);
@@ -223,7 +227,7 @@ __global__ void __launch_bounds__(256)
         } else if (b_mode == 2) {  // vectors along k
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
-                const int e = (tid + v * 256) * V, jj = e / GBK, kk = e % GBK;
+                const int e = (tid + v * NT) * V, jj = e / GBK, kk = e % GBK;
                 const int64_t gj = j0 + jj, gk = k0 + kk;
                 if (gj < N && gk + V <= K) {
                     const vec<T, V> x = *reinterpret_cast<const vec<T, V>*>(B + gk * b_rs + gj * b_cs);
@@ -237,7 +241,7 @@ __global__ void __launch_bounds__(256)
         } else {
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
-                const int e = tid + u * 256, kk = e / GB, jj = e % GB;
+                const int e = tid + u * NT, kk = e / GB, jj = e % GB;
                 const int64_t gj = j0 + jj, gk = k0 + kk;
                 rb[u] = (gj < N && gk < K) ? B[gk * b_rs + gj * b_cs] : T(0);
             }
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(256)
         if (a_mode == 1) {
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
-                const int e = (tid + v * 256) * V, kk = e / GB, ii = e % GB;
+                const int e = (tid + v * NT) * V, kk = e / GB, ii = e % GB;
                 vec<T, V> x;
 #pragma unroll
                 for (int q = 0; q < V; ++q) x.v[q] = ra[v * V + q];
@@ -256,21 +260,21 @@ __global__ void __launch_bounds__(256)
         } else if (a_mode == 2) {
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
-                const int e = (tid + v * 256) * V, ii = e / GBK, kk = e % GBK;
+                const int e = (tid + v * NT) * V, ii = e / GBK, kk = e % GBK;
 #pragma unroll
                 for (int q = 0; q < V; ++q) As[buf][kk + q][ii] = ra[v * V + q];
             }
         } else {
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
-                const int e = tid + u * 256;
+                const int e = tid + u * NT;
                 As[buf][e / GB][e % GB] = ra[u];
             }
         }
         if (b_mode == 1) {
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
-                const int e = (tid + v * 256) * V, kk = e / GB, jj = e % GB;
+                const int e = (tid + v * NT) * V, kk = e / GB, jj = e % GB;
                 vec<T, V> x;
 #pragma unroll
                 for (int q = 0; q < V; ++q) x.v[q] = rb[v * V + q];
@@ -279,21 +283,21 @@ __global__ void __launch_bounds__(256)
         } else if (b_mode == 2) {
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
-                const int e = (tid + v * 256) * V, jj = e / GBK, kk = e % GBK;
+                const int e = (tid + v * NT) * V, jj = e / GBK, kk = e % GBK;
 #pragma unroll
                 for (int q = 0; q < V; ++q) Bs[buf][kk + q][jj] = rb[v * V + q];
             }
         } else {
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
-                const int e = tid + u * 256;
+                const int e = tid + u * NT;
                 Bs[buf][e / GB][e % GB] = rb[u];
             }
         }
     };
 
     f32x16 acc32[2][2];
-    f64x4 acc64[4][4];
+    f64x4 acc64[2][4];
     if constexpr (is_f32) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -303,7 +307,7 @@ __global__ void __launch_bounds__(256)
                 for (int r = 0; r < 16; ++r) acc32[a][b][r] = 0.f;
     } else {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -318,7 +322,7 @@ __global__ void __launch_bounds__(256)
     const T* pb[VPT];
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-        const int e = (tid + v * 256) * V;
+        const int e = (tid + v * NT) * V;
         const int a_ii = a_mode == 1 ? e % GB : e / GBK, a_kk = a_mode == 1 ? e / GB : e % GBK;
         const int b_jj = b_mode == 1 ? e % GB : e / GBK, b_kk = b_mode == 1 ? e / GB : e % GBK;
         pa[v] = A + (i0 + a_ii) * a_rs + (int64_t)a_kk * a_cs;
@@ -359,14 +363,14 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
             for (int kk = 0; kk < GBK; kk += 4) {
                 const int kr = kk + (lane >> 4), c = lane & 15;
-                double a[4], b[4];
+                double a[2], b[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    a[t] = As[cur][kr][wi + t * 16 + c];
+                    if (t < 2) a[t] = As[cur][kr][wi + t * 16 + c];
                     b[t] = Bs[cur][kr][wj + t * 16 + c];
                 }
 #pragma unroll
-                for (int ti = 0; ti < 4; ++ti)
+                for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < 4; ++tj)
                         acc64[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc64[ti][tj], 0, 0, 0);
@@ -410,7 +414,7 @@ __global__ void __launch_bounds__(256)
                 }
     } else {
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+        for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -489,9 +493,7 @@ static void gemm_run(int layout, int ta, int tb, int64_t m, int64_t n, int64_t k
         // operands that fill the chip with 128 x 128 tiles take the pipelined kernel (k_gemm_mfma128), the rest the 64 x 64 one
         const int64_t tm = ceil_div(m, (int64_t)GB), tn = ceil_div(n, (int64_t)GB);
         const int64_t big_min = options().gemm_big_tiles >= 0 ? options().gemm_big_tiles : (int64_t)std::max(c.cus, 1);
-        // (fp64 stays on the 64 x 64 kernel: with 4 x 4 accumulator tiles per wave the 128-tile form needs every register of
-        // a SIMD for ONE wave and measures 31-36 TFLOP/s against 36-39)
-        if (sizeof(T) == 4 && options().gemm_big_tiles != 0 && tm * tn >= big_min && k >= 2 * gemm_bk<T>() && tm * tn < ((int64_t)1 << 31)) {
+        if (options().gemm_big_tiles != 0 && tm * tn >= big_min && k >= 2 * gemm_bk<T>() && tm * tn < ((int64_t)1 << 31)) {
             const T* ad = static_cast<const T*>(sa.dev);
             const T* bd = static_cast<const T*>(sb.dev);
             auto ok16 = [&](const T* ptr, int64_t ld) {  // 16-byte vectors: base and every row / column start aligned
@@ -500,7 +502,7 @@ static void gemm_run(int layout, int ta, int tb, int64_t m, int64_t n, int64_t k
             // the stored leading dimension is whichever of the two strides is not 1
             const int a_mode = gemm_vec_mode(a_rs, a_cs, ok16(ad, a_rs == 1 ? a_cs : a_rs));
             const int b_mode = gemm_vec_mode(b_cs, b_rs, ok16(bd, b_cs == 1 ? b_rs : b_cs));
-            MI_LAUNCH((k_gemm_mfma128<T>), dim3((unsigned)(tm * tn)), dim3(256), c.stream, m, n, k, alpha, ad, a_rs, a_cs, a_mode, bd,
+            MI_LAUNCH((k_gemm_mfma128<T>), dim3((unsigned)(tm * tn)), dim3(gemm_threads<T>()), c.stream, m, n, k, alpha, ad, a_rs, a_cs, a_mode, bd,
                       b_rs, b_cs, b_mode, beta, beta_zero, static_cast<T*>(sc.dev), c_rs, c_cs, tri, (int)tn);
         } else {
             MI_LAUNCH((k_gemm_mfma<T>), dim3((unsigned)ceil_div(n, GT), (unsigned)ceil_div(m, GT)), dim3(256), c.stream, m, n,
