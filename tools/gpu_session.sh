@@ -33,6 +33,8 @@ import json,os
 d=json.load(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/session/bench_line.json"))
 print(json.dumps({k:d[k] for k in ("value","ms_per_step","roofline")})[:900])
 for k,v in d.get("secondary",{}).items():
+    if k=="gemm_dense":
+        print(k, {t:(v[t].get("value"), v[t].get("roofline",{}).get("frac")) for t in ("f32","f64") if t in v}); continue
     rf=v.get("roofline") or {}
     print(k, {kk:v.get(kk) for kk in ("ms","ms_per_step","value","error") if kk in v}, {kk:rf.get(kk) for kk in ("frac","traffic","traffic_over_algorithmic")}, v.get("gpu_on_cpu_sample_shape"))
 PY
