@@ -572,9 +572,11 @@ def secondary_spgemm(torch, abi, dev, kind, with_cpu):
 
 def secondary_gemm(torch, abi, dev, with_cpu):
     """SURVEY section 8 a7 / a8 (the dense x dense fallback, the only MFMA consumer): mi_cblas_sgemm / mi_cblas_dgemm on
-    device-resident 4096^3 operands against the dense MFMA peak; numpy's BLAS on the host beside it."""
+    device-resident 4096^3 operands against the dense MFMA peak; numpy's BLAS on the host beside it (timed AFTER both device
+    measurements: its threads keep spinning on the host cores for a while and slow the launches of whatever follows)."""
     m = n = k = 4096
     out = {"workload": "dense x dense fallback (cblas_?gemm, reference _dense_dense.py:53-66): 4096 x 4096 x 4096, row-major, device-resident"}
+    host = {}
     for letter, tdt, peak in (("s", torch.float32, 157.3), ("d", torch.float64, 78.6)):
         A = torch.rand((m, k), device=dev, dtype=tdt)
         Bm = torch.rand((k, n), device=dev, dtype=tdt)
@@ -589,26 +591,29 @@ def secondary_gemm(torch, abi, dev, with_cpu):
         want = A[rows].double() @ Bm.double()
         err = float(((C[rows].double() - want).abs() / want.abs().clamp(min=1e-300)).max())
         ok = err <= (1e-5 if letter == "s" else 1e-12)  # (recorded, not asserted: 4096-term fp32 sums sit within a factor 3 of the bar)
-        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(5):
             step()
+        e1.record()
         torch.cuda.synchronize()
-        t = (time.perf_counter() - t0) / 5
+        t = e0.elapsed_time(e1) / 5 / 1e3
         tf = 2.0 * m * n * k / t / 1e12
-        ent = {"ms": round(t * 1e3, 3), "value": round(tf, 2), "unit": "TFLOP/s", "max_rel_err_rows": err, "within_tolerance": bool(ok),
-               "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                            "note": "dense %s MFMA peak (MI355X_MICROARCH.md)" % ("fp32" if letter == "s" else "fp64")}}
+        key = "f32" if letter == "s" else "f64"
+        out[key] = {"ms": round(t * 1e3, 3), "value": round(tf, 2), "unit": "TFLOP/s", "max_rel_err_rows": err, "within_tolerance": bool(ok),
+                    "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                                 "note": "dense %s MFMA peak (MI355X_MICROARCH.md); device time of 5 calls (events on the launch stream)" % key}}
         if with_cpu:
-            import numpy as np
-            ah, bh = A.cpu().numpy(), Bm.cpu().numpy()
-            np.dot(ah[:512], bh)
-            t0 = time.perf_counter()
-            np.dot(ah, bh)
-            tc = time.perf_counter() - t0
-            ent["cpu_baseline"] = {"value": round(2.0 * m * n * k / tc / 1e12, 3), "unit": "TFLOP/s", "cores": _host_cores(), "kind": "port",
-                                   "sample": "numpy.dot of the same operands on the host (its BLAS, all threads), one call after a warm-up"}
-        out["f32" if letter == "s" else "f64"] = ent
+            host[key] = (A.cpu().numpy(), Bm.cpu().numpy())
         del A, Bm, C
+    for key, (ah, bh) in host.items():
+        import numpy as np
+        np.dot(ah[:512], bh)
+        t0 = time.perf_counter()
+        np.dot(ah, bh)
+        tc = time.perf_counter() - t0
+        out[key]["cpu_baseline"] = {"value": round(2.0 * m * n * k / tc / 1e12, 3), "unit": "TFLOP/s", "cores": _host_cores(), "kind": "port",
+                                    "sample": "numpy.dot of the same operands on the host (its BLAS, all threads), one call after a warm-up"}
     return out
 
 
@@ -1272,19 +1277,19 @@ def main():
                 secondary["host_api"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if "uniform" in want_sec:
             secondary["spmm_uniform"] = secondary_uniform_spmm(torch, abi, dev, n, N, B, args.steps, args.warmup)
+        if "gemm" in want_sec:
+            try:
+                secondary["gemm_dense"] = secondary_gemm(torch, abi, dev, with_cpu)  # (before the SpMM's CPU baselines: see its docstring)
+            except AssertionError:
+                raise
+            except Exception as exc:  # noqa: BLE001
+                secondary["gemm_dense"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if with_cpu:
             line["cpu_baseline"] = cpu_baseline_spmm(indptr.cpu().numpy(), indices.cpu().numpy(), vals.cpu().numpy(), n, B.cpu().numpy())
         else:
             line["cpu_baseline"] = None
         del B, indptr, indices, vals
         torch.cuda.empty_cache()
-        if "gemm" in want_sec:
-            try:
-                secondary["gemm_dense"] = secondary_gemm(torch, abi, dev, with_cpu)
-            except AssertionError:
-                raise
-            except Exception as exc:  # noqa: BLE001
-                secondary["gemm_dense"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         for key, fn in (("spgemm_uniform", lambda: secondary_spgemm(torch, abi, dev, "uniform", with_cpu)),
                         ("spgemm_rmat_literal", lambda: secondary_spgemm(torch, abi, dev, "rmat", with_cpu)),
                         ("gram_dense", lambda: secondary_gram(torch, abi, dev, with_cpu))):
