@@ -570,6 +570,70 @@ def secondary_spgemm(torch, abi, dev, kind, with_cpu):
     return out
 
 
+def secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, steps):
+    """SURVEY section 8 f1 (SpMV, mkl_sparse_?_mv, _sparse_vector.py:87-95) on the headline matrix and a5 (the SPARSE gram matrix,
+    mkl_sparse_syrk, _gram_matrix.py:70-74) on a uniform 2^20 x 2^18, 16 / row fp64 operand -- the two rows of the scope table the
+    line did not carry a measurement for."""
+    out = {}
+    h = abi.create("s", indptr, indices, vals, n, n)
+    x = torch.rand(n, device=dev, dtype=torch.float32)
+    y = torch.empty(n, device=dev, dtype=torch.float32)
+    for _ in range(3):
+        abi.mv("s", h, x, y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        abi.mv("s", h, x, y)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / steps / 1e3
+    ip = indptr.to(torch.int64)
+    rows = torch.randint(0, n, (64,), device=dev)
+    err = 0.0
+    for r in rows.tolist():
+        lo, hi = int(ip[r]), int(ip[r + 1])
+        if hi > lo:
+            w = float((vals[lo:hi].double() * x[indices[lo:hi].long()].double()).sum())
+            err = max(err, abs(float(y[r]) - w) / max(abs(w), 1e-30))
+    nnz = int(indices.numel())
+    nbytes = nnz * 8 + (n + 1) * 8 + 2 * n * 4
+    out["spmv"] = {"workload": "y = A x on the headline matrix (%d nnz), fp32" % nnz, "ms": round(t * 1e3, 4),
+                   "value": round(2.0 * nnz / t / 1e9, 1), "unit": "GFLOP/s", "parity_max_rel_err_rows": err,
+                   "roofline": {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes,
+                                "note": "nnz * 8 + (M + 1) * 8 + 2 M * 4; device time (events) of %d calls" % steps}}
+    abi.destroy(h)
+    m_, c_ = 1 << 20, 1 << 18
+    u = uniform_csr(torch, m_, 16, 5, dev, ncols=c_)
+    uv = u[2].double()
+    hu = abi.create("d", u[0], u[1], uv, m_, c_)
+    ts = []
+    nnzc = 0
+    for rep in range(4):
+        hc = abi.handle_t()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        abi.check(abi.MI.call("mi_sparse_syrk", 11, hu, ct.byref(hc)), "syrk")
+        torch.cuda.synchronize()
+        if rep:
+            ts.append(time.perf_counter() - t0)
+        nnzc = abi.info(hc)[2]
+        abi.destroy(hc)
+    tg = _median(ts)
+    lens = (u[0][1:] - u[0][:-1]).double()
+    prod = float((lens * (lens + 1) / 2).sum())
+    gbytes = (int(u[1].numel()) * 2 + nnzc) * 12 + 3 * (c_ + 1) * 8
+    out["gram_sparse"] = {"workload": "upper triangle of A^T A as CSR (mkl_sparse_syrk): uniform %d x %d, 16 / row fp64; %d entries" % (m_, c_, nnzc),
+                          "ms": round(tg * 1e3, 3), "value": round(2 * prod / tg / 1e9, 2), "unit": "GFLOP/s",
+                          "roofline": {"bound": "hbm", "achieved": round(gbytes / tg / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(gbytes / tg / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": gbytes,
+                                       "note": "(nnz(A) + nnz(A^T) + nnz(C)) * 12 + 3 (n + 1) * 8 over the whole call (cached transpose + SpGEMM "
+                                               "restricted to col >= row), median of 3 after 1"}}
+    abi.destroy(hu)
+    return out
+
+
 def secondary_gemm(torch, abi, dev, with_cpu):
     """SURVEY section 8 a7 / a8 (the dense x dense fallback, the only MFMA consumer): mi_cblas_sgemm / mi_cblas_dgemm on
     device-resident 4096^3 operands against the dense MFMA peak; numpy's BLAS on the host beside it (timed AFTER both device
@@ -933,7 +997,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 in this run (use the committed summary)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
-    ap.add_argument("--secondary", default="all", help="comma list of: uniform,spgemm,spgemm_rmat,gram,host_api,gemm (default all)")
+    ap.add_argument("--secondary", default="all", help="comma list of: uniform,spgemm,spgemm_rmat,gram,host_api,gemm,spmv (default all)")
     ap.add_argument("--gather-mode", default="bcast", choices=["bcast", "padded", "p2p"])
     ap.add_argument("--bcast-mode", default="bcast", choices=["bcast", "scatter_allgather"])
     ap.add_argument("--no-variants", action="store_true", help="N > 1: skip the p2p / pipelined forms and configs[4]")
@@ -1266,7 +1330,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    want_sec = set(args.secondary.split(",")) if args.secondary != "all" else {"uniform", "spgemm", "spgemm_rmat", "gram", "host_api", "gemm"}
+    want_sec = set(args.secondary.split(",")) if args.secondary != "all" else {"uniform", "spgemm", "spgemm_rmat", "gram", "host_api", "gemm", "spmv"}
     with_cpu = not args.no_cpu
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "rmat":
         secondary = {}
@@ -1277,6 +1341,13 @@ def main():
                 secondary["host_api"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if "uniform" in want_sec:
             secondary["spmm_uniform"] = secondary_uniform_spmm(torch, abi, dev, n, N, B, args.steps, args.warmup)
+        if "spmv" in want_sec:
+            try:
+                secondary.update(secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, args.steps))
+            except AssertionError:
+                raise
+            except Exception as exc:  # noqa: BLE001
+                secondary["spmv"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if "gemm" in want_sec:
             try:
                 secondary["gemm_dense"] = secondary_gemm(torch, abi, dev, with_cpu)  # (before the SpMM's CPU baselines: see its docstring)
