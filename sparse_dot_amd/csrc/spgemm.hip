@@ -55,9 +55,10 @@ constexpr int ROWUB_LONG = 512;      // rows of A with more nonzeros go to k_row
 
 __device__ __forceinline__ void row_ub_one(int64_t p, int32_t row, const int32_t* __restrict__ acol, int64_t b0, int64_t b1,
                                            const int32_t* __restrict__ bcol, int upper, int64_t& s, int64_t* __restrict__ ext0,
-                                           int32_t* __restrict__ extlen)
+                                           int32_t* __restrict__ extlen, int32_t row_shift)
 {
-    if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, row);
+    // row_shift: B is a column PANEL of a wider matrix with its columns rebased (spgemm_panels): the diagonal sits at column row - shift
+    if (upper == 2 && b0 < b1) b0 = lower_bound_col(bcol, b0, b1, row - row_shift);
     s += b1 - b0;
     ext0[p] = b0;
     extlen[p] = (int32_t)(b1 - b0);
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(256)
     k_row_ub(int64_t rows, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
              const BP* __restrict__ bptr, const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub,
              int64_t* __restrict__ ext0, int32_t* __restrict__ extlen, int32_t* __restrict__ long_list,
-             unsigned* __restrict__ long_count)
+             unsigned* __restrict__ long_count, int32_t row_shift)
 {
     constexpr int LPR = 1 << ROWUB_LPR_LOG2;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256)
         } else {
             for (int64_t p = a0 + sub; p < a1; p += LPR) {
                 const int32_t k = acol[p];
-                row_ub_one(p, (int32_t)row, acol, (int64_t)bptr[k], (int64_t)bptr[k + 1], bcol, upper, s, ext0, extlen);
+                row_ub_one(p, (int32_t)row, acol, (int64_t)bptr[k], (int64_t)bptr[k + 1], bcol, upper, s, ext0, extlen, row_shift);
             }
         }
     }
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(256)
     k_row_ub_long(const int32_t* __restrict__ long_list, const unsigned* __restrict__ long_count,
                   const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol, const BP* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, int upper, int64_t* __restrict__ ub, int64_t* __restrict__ ext0,
-                  int32_t* __restrict__ extlen)
+                  int32_t* __restrict__ extlen, int32_t row_shift)
 {
     __shared__ long long wave_s[4];
     const unsigned n = *long_count;
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(256)
         int64_t s = 0;
         for (int64_t p = a0 + threadIdx.x; p < a1; p += 256) {
             const int32_t k = acol[p];
-            row_ub_one(p, row, acol, (int64_t)bptr[k], (int64_t)bptr[k + 1], bcol, upper, s, ext0, extlen);
+            row_ub_one(p, row, acol, (int64_t)bptr[k], (int64_t)bptr[k + 1], bcol, upper, s, ext0, extlen, row_shift);
         }
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) s += __shfl_xor(s, d);
@@ -1182,7 +1183,7 @@ __global__ void __launch_bounds__(256)
                   const int64_t* __restrict__ item_off, const int32_t* __restrict__ bounds,
                   const int64_t* __restrict__ boff_by_row, const int64_t* __restrict__ aptr,
                   const int32_t* __restrict__ acol, const int64_t* __restrict__ bptr,
-                  const int32_t* __restrict__ bcol, int upper, const int64_t* __restrict__ slice_base,
+                  const int32_t* __restrict__ bcol, int upper, int32_t diag_shift, const int64_t* __restrict__ slice_base,
                   int32_t* __restrict__ bnd, const int32_t* __restrict__ work_t)
 {
     __shared__ int32_t tile_all[4][64][SLICE_EB + 1];  // [wave][range lane][nonzero]
@@ -1215,7 +1216,7 @@ __global__ void __launch_bounds__(256)
     const bool is_end = p_ok && (p0 + pl == P);
     if (p_ok && !is_end) {
         x = rb[p0 + pl];
-        if (upper && x < row) x = row;
+        if (upper && x < row - diag_shift) x = row - diag_shift;  // (diag_shift: B is a column panel with rebased columns)
     }
     // SLICE_ILP nonzeros per lane at a time: their bisections advance in lockstep with unconditional loads, so
     // SLICE_ILP dependent chains are in flight per lane (one search after the other was ~10 dependent cache
@@ -1333,7 +1334,7 @@ __global__ void __launch_bounds__(PART_THREADS)
                   const int32_t* __restrict__ bounds, int64_t ncols, int64_t cap,
                   const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
-                  const int32_t* __restrict__ bnd, int32_t* __restrict__ ccol, T* __restrict__ cval, int32_t col_base)
+                  const int32_t* __restrict__ bnd, int32_t* __restrict__ ccol, T* __restrict__ cval, int32_t col_base, int32_t diag_shift)
 {
     constexpr int S = 1 << LOG2S;
     constexpr int NT = PART_THREADS;
@@ -1387,7 +1388,7 @@ __global__ void __launch_bounds__(PART_THREADS)
             } else {
                 int32_t c_lo = rb[pass];
                 const int64_t c_hi = pass + 1 < d.npass ? rb[pass + 1] : ncols;
-                if (upper && c_lo < row) c_lo = row;
+                if (upper && c_lo < row - diag_shift) c_lo = row - diag_shift;
                 const int32_t kk = acol[p];
                 const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
                 s_n = b0;
@@ -2202,6 +2203,11 @@ struct BigRows {
     DevBuf ext0, extlen;       // per nonzero of A: first counted entry of B's row (int64) and their number (int32) -- k_row_ub
     bool grp = false;          // every row of B has <= 32 entries: the LDS bins up to 512 products run k_spgemm_grp
     int32_t col_base = 0;      // numeric phase: added to every column index written (B is a column panel of a wider matrix, spgemm_panels)
+    // upper-triangle product of a column panel: the extents (ext0 / extlen) are cut at the diagonal shifted by the panel's first
+    // column and the kernels that read them run as a full product; the two kernels that cut rows of B into column ranges from
+    // B's own row pointer (k_part_slices, k_spgemm_part) clamp at row - diag_shift themselves
+    bool panel_upper = false;
+    int32_t diag_shift = 0;
     // round 4, accumulate-by-rank path (k_spgemm_rank): the symbolic phase's bitmaps and what the numeric phase needs with them
     bool have_rank = false;
     bool want_rank = false;    // the caller will order the result (mi_sparse_spmm_ordered): take the rank path when its bitmaps are affordable
@@ -2437,8 +2443,8 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                     launch_batched(ceil_div(total_work, 4), 256, [&](int64_t off, int64_t nblk) {  // total_work = waves
                         MI_LAUNCH(k_part_slices, dim3((unsigned)nblk), dim3(256), c.stream, off, (const int32_t*)big_list, nbig,
                                   (const int64_t*)work_off, (const int64_t*)item_off, bounds, brow, (const int64_t*)A.ptr,
-                                  (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, upper,
-                                  (const int64_t*)slice_base, bnd, (const int32_t*)work_t);
+                                  (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, big.panel_upper ? 1 : upper,
+                                  big.diag_shift, (const int64_t*)slice_base, bnd, (const int32_t*)work_t);
                     });
                 }
                 // work items of the numeric kernel: groups of PART_GROUP consecutive ranges of a row
@@ -2464,8 +2470,8 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                     launch_batched(ceil_div(n_groups, run8) * run8, PART_THREADS, [&](int64_t off, int64_t nblk) {
                         MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)nblk), dim3(PART_THREADS), c.stream, off, n_groups,
                                   (const int32_t*)item_t, (const PartDesc*)desc, bounds, B.cols, CAP, (const int32_t*)A.col,
-                                  (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val, upper,
-                                  (const int32_t*)bnd, ccol, cval, big.col_base);
+                                  (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val,
+                                  big.panel_upper ? 1 : upper, (const int32_t*)bnd, ccol, cval, big.col_base, big.diag_shift);
                     });
                 };
                 if (n_groups) {
@@ -2611,7 +2617,8 @@ static void trace_mark(const char* what, std::chrono::steady_clock::time_point& 
 
 // k_row_ub + k_row_ub_long on the context's stream.  B's row extents are gathered from an int32 copy of its row pointer made
 // here (scratch of the call) when nnz(B) < 2^31: half the table, twice the pointers per 128-byte line.
-static void launch_row_ub(const Csr& A, const Csr& B, int upper_mode, int64_t* ub, int64_t* ext0, int32_t* extlen)
+static void launch_row_ub(const Csr& A, const Csr& B, int upper_mode, int64_t* ub, int64_t* ext0, int32_t* extlen,
+                          int64_t row_shift = 0)
 {
     Context& c = ctx();
     if (A.rows <= 0) return;
@@ -2624,9 +2631,10 @@ static void launch_row_ub(const Csr& A, const Csr& B, int upper_mode, int64_t* u
     auto run = [&](auto* bptr) {
         using BP = std::remove_cv_t<std::remove_pointer_t<decltype(bptr)>>;
         MI_LAUNCH(k_row_ub<BP>, grid, dim3(256), c.stream, A.rows, (const int64_t*)A.ptr, (const int32_t*)A.col, (const BP*)bptr,
-                  (const int32_t*)B.col, upper_mode, ub, ext0, extlen, long_list, long_count);
+                  (const int32_t*)B.col, upper_mode, ub, ext0, extlen, long_list, long_count, (int32_t)row_shift);
         MI_LAUNCH(k_row_ub_long<BP>, dim3(long_grid), dim3(256), c.stream, (const int32_t*)long_list, (const unsigned*)long_count,
-                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const BP*)bptr, (const int32_t*)B.col, upper_mode, ub, ext0, extlen);
+                  (const int64_t*)A.ptr, (const int32_t*)A.col, (const BP*)bptr, (const int32_t*)B.col, upper_mode, ub, ext0, extlen,
+                  (int32_t)row_shift);
     };
     if (options().spgemm_narrow_ptr && B.nnz < ((int64_t)1 << 31) - 1 && A.nnz >= ((int64_t)1 << 18) && B.rows >= ((int64_t)1 << 16)) {
         int32_t* bptr32 = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(B.rows + 1)));
@@ -2639,7 +2647,7 @@ static void launch_row_ub(const Csr& A, const Csr& B, int upper_mode, int64_t* u
 }
 
 template <typename T>
-static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st)
+static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st, int64_t panel_col0 = -1)
 {
     Context& c = ctx();
     auto t_last = std::chrono::steady_clock::now();
@@ -2675,7 +2683,18 @@ static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C
         if (cache_get(B.gram_max_row) < 0) cache_set(B.gram_max_row, device_max_row_len(B));
         big.grp = cache_get(B.gram_max_row) <= 32;
     }
-    launch_row_ub(A, B, st.upper_mode, bd.ub, big.ext0.as<int64_t>(), big.extlen.as<int32_t>());
+    if (panel_col0 >= 0 && upper) {
+        // B is the column panel starting at column panel_col0 of a wider matrix (spgemm_panels; its rows are sorted): the extents
+        // are cut at the shifted diagonal HERE, and the kernels behind them run without the per-product test (whose column
+        // indices are the panel's own)
+        if (st.upper_mode != 2) fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "column panel with unsorted rows");
+        launch_row_ub(A, B, 2, bd.ub, big.ext0.as<int64_t>(), big.extlen.as<int32_t>(), panel_col0);
+        st.upper_mode = 0;
+        big.panel_upper = true;
+        big.diag_shift = (int32_t)panel_col0;
+    } else {
+        launch_row_ub(A, B, st.upper_mode, bd.ub, big.ext0.as<int64_t>(), big.extlen.as<int32_t>());
+    }
     st.a_gen = A.order_gen;
     st.b_gen = B.order_gen;
     st.a_nnz = A.nnz;
@@ -2969,7 +2988,7 @@ struct SpgemmPanel {
 
 // false: not done (the panels' copies of B did not fit) -- the caller takes the global-memory path
 template <typename T>
-static bool spgemm_panels(const Csr& A, const Csr& B, Csr& C)
+static bool spgemm_panels(const Csr& A, const Csr& B, bool upper, Csr& C)
 {
     Context& c = ctx();
     auto t_last = std::chrono::steady_clock::now();
@@ -3022,7 +3041,7 @@ static bool spgemm_panels(const Csr& A, const Csr& B, Csr& C)
             Bq.valid = true;
             cache_set(Bq.sorted, true);
             Bq.order_gen = next_order_gen();
-            SpgemmBounds bdq = spgemm_bounds<T>(A, Bq, false, pn->Cp, pn->st);
+            SpgemmBounds bdq = spgemm_bounds<T>(A, Bq, upper, pn->Cp, pn->st, q * PANEL_COLS);
             spgemm_symbolic<T>(A, Bq, pn->Cp, pn->st, bdq);
             if (pn->Cp.nnz == 0) continue;
             base_of.push_back(q * PANEL_COLS);
@@ -3066,7 +3085,7 @@ static bool spgemm_panels(const Csr& A, const Csr& B, Csr& C)
     C.sorted = false;
     C.range_cap = 0;  // a row is the concatenation of the panels' pieces: not one sequence of full ranges
     counters().spgemm_panels += (double)np;
-    if (options().deterministic && C.nnz > 0) spgemm_values_deterministic<T>(A, B, C, 0);
+    if (options().deterministic && C.nnz > 0) spgemm_values_deterministic<T>(A, B, C, upper ? 1 : 0);
     return true;
 }
 
@@ -3077,9 +3096,9 @@ static void spgemm_typed(const Csr& A, const Csr& B, bool upper, Csr& C, bool wa
     SpgemmSymbolic st;
     SpgemmBounds bd = spgemm_bounds<T>(A, B, upper, C, st);
     // rows beyond the LDS hash classes and a B too wide for the LDS bitmap: column panels (see above)
-    if (!upper && bd.max_ub > 4096 && options().spgemm_col_panels && !options().spgemm_force_global && B.nnz > 0 &&
+    if (bd.max_ub > 4096 && options().spgemm_col_panels && !options().spgemm_force_global && B.nnz > 0 &&
         B.nnz < ((int64_t)1 << 31) && bitmap_lds_bytes(B.cols) > (size_t)140 * 1024) {
-        if (spgemm_panels<T>(A, B, C)) return;
+        if (spgemm_panels<T>(A, B, upper, C)) return;
         C = Csr();
         bd = spgemm_bounds<T>(A, B, upper, C, st);
     }

@@ -965,6 +965,48 @@ def test_gram_sparse_hub_rows(gpu, dtype):
         assert rel_err(g.data, want.data) <= tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gram_sparse_wide_matrix_by_column_panels(gpu, dtype):
+    """Upper triangle of A^T A (mkl_sparse_syrk, reference _gram_matrix.py:70-74) of a matrix with 2^21 + 9 columns: the
+    product's hub rows go panel by panel (three panels of 2^20 columns) with the extents of every panel cut at the SHIFTED
+    diagonal.  Heavy columns on both sides of every panel boundary (their rows of A^T A start in one panel's last column /
+    another's first), one in the last column; same pattern and values as scipy, with and without option deterministic;
+    option spgemm_col_panels = 0 is the global-memory hash."""
+    rng = np.random.default_rng(31)
+    W = 1 << 20
+    m, n = 3000, 2 * W + 9
+    rows, cols = [], []
+    for r in range(m):
+        c = rng.integers(0, n, 22)
+        rows.append(np.full(c.size, r))
+        cols.append(c)
+    for hub, share in ((5, 0.9), (W - 1, 0.5), (W, 0.5), (2 * W - 1, 0.4), (2 * W, 0.4), (n - 1, 0.6), (W + 12345, 0.8)):
+        rr = rng.choice(m, int(share * m), replace=False)
+        rows.append(rr)
+        cols.append(np.full(rr.size, hub))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    a = sps.coo_matrix((np.ones(rows.size), (rows, cols)), shape=(m, n)).tocsr()  # duplicates summed
+    a.data[:] = rng.uniform(0.5, 1.5, a.nnz)
+    a = a.astype(dtype)
+    want = sps.triu((a.T.astype(np.float64) @ a.astype(np.float64))).tocsr()
+    want.sort_indices()
+    assert np.diff(want.indptr).max() > 40000
+    for panels, det in ((1, 0), (1, 1), (0, 0)):
+        gpu.mi_set_option("spgemm_col_panels", panels)
+        gpu.mi_set_option("deterministic", det)
+        gpu.mi_get_counter("reset")
+        try:
+            got = gpu.gram_matrix_mkl(a, reorder_output=True)
+            used = gpu.mi_get_counter("spgemm_panels")
+        finally:
+            gpu.mi_set_option("spgemm_col_panels", 1)
+            gpu.mi_set_option("deterministic", 0)
+        assert used == (3 if panels else 0)
+        g = got.tocsr()
+        assert np.array_equal(g.indptr, want.indptr) and np.array_equal(g.indices, want.indices)
+        assert rel_err(g.data, want.data) <= tol(dtype)
+
+
 def test_device_block_cache_options(gpu, oracle):
     """Released device blocks are cached for reuse (hipMalloc of large results is slow); the cache can be
     switched off, capped and trimmed through mi_sparse_set_option, and results do not depend on it."""
