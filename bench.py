@@ -634,6 +634,58 @@ def secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, steps)
     return out
 
 
+def secondary_rows_f3_f4_a4(torch, abi, dev):
+    """The remaining rows of the scope table: f3 (BSR x dense through the block kernel, _common.py:327-384) and f4 (staged product,
+    pattern reuse) measured by tools/bench_ops.py in a child process (its last JSON line, trimmed); a4 (mkl_sparse_?_spmmd,
+    _sparse_sparse.py:94-101: sparse x sparse into a DENSE row-major result) here."""
+    import subprocess
+    out = {}
+    for key, argv in (("bsr_spmm", ["bsr", "--rows-log2", "18", "--block", "4", "--ncols", "128", "--reps", "2"]),
+                      ("sp2m_pattern_reuse", ["sp2m", "--kind", "rmat", "--scale", "18", "--reps", "2"])):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_ops.py")] + argv, stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, timeout=300)
+            lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+            d = json.loads(lines[-1]) if lines else {"error": "no output (rc %d)" % r.returncode}
+            out[key] = {k: v for k, v in d.items() if not isinstance(v, (list, dict)) or k in ("block_kernel", "csr_expansion", "checks")}
+        except Exception as exc:  # noqa: BLE001
+            out[key] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    try:
+        n = 1 << 14
+        a = uniform_csr(torch, n, 32, 11, dev)
+        b = uniform_csr(torch, n, 32, 12, dev)
+        av, bv = a[2].double(), b[2].double()
+        ha = abi.create("d", a[0], a[1], av, n, n)
+        hb = abi.create("d", b[0], b[1], bv, n, n)
+        C = torch.empty((n, n), device=dev, dtype=torch.float64)
+        ts = []
+        for rep in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            abi.check(abi.MI.call("mi_sparse_d_spmmd", 10, ha, hb, 101, C.data_ptr(), n), "spmmd")
+            torch.cuda.synchronize()
+            if rep:
+                ts.append(time.perf_counter() - t0)
+        t = _median(ts)
+        ones = torch.ones(n, device=dev, dtype=torch.float64)
+        b1, ab1 = torch.empty(n, device=dev, dtype=torch.float64), torch.empty(n, device=dev, dtype=torch.float64)
+        abi.mv("d", hb, ones, b1)
+        abi.mv("d", ha, b1, ab1)
+        torch.cuda.synchronize()
+        err = float(((C.sum(1) - ab1).abs() / ab1.abs().clamp(min=1e-300)).max())
+        nbytes = (int(a[1].numel()) + int(b[1].numel())) * 12 + n * n * 8
+        out["spmmd"] = {"workload": "sparse x sparse -> dense (mkl_sparse_d_spmmd): two uniform CSR 2^14 x 2^14, 32 / row fp64, 2 GiB row-major result",
+                        "ms": round(t * 1e3, 3), "rowsum_max_rel_err": err,
+                        "roofline": {"bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes,
+                                     "note": "(nnz(A) + nnz(B)) * 12 + M N * 8 (the dense result written once), median of 3 after 1"}}
+        for h in (ha, hb):
+            abi.destroy(h)
+    except Exception as exc:  # noqa: BLE001
+        out["spmmd"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    return out
+
+
 def secondary_gemm(torch, abi, dev, with_cpu):
     """SURVEY section 8 a7 / a8 (the dense x dense fallback, the only MFMA consumer): mi_cblas_sgemm / mi_cblas_dgemm on
     device-resident 4096^3 operands against the dense MFMA peak; numpy's BLAS on the host beside it (timed AFTER both device
@@ -997,7 +1049,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 in this run (use the committed summary)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
-    ap.add_argument("--secondary", default="all", help="comma list of: uniform,spgemm,spgemm_rmat,gram,host_api,gemm,spmv (default all)")
+    ap.add_argument("--secondary", default="all", help="comma list of: uniform,spgemm,spgemm_rmat,gram,host_api,gemm,spmv,rows (default all)")
     ap.add_argument("--gather-mode", default="bcast", choices=["bcast", "padded", "p2p"])
     ap.add_argument("--bcast-mode", default="bcast", choices=["bcast", "scatter_allgather"])
     ap.add_argument("--no-variants", action="store_true", help="N > 1: skip the p2p / pipelined forms and configs[4]")
@@ -1330,7 +1382,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    want_sec = set(args.secondary.split(",")) if args.secondary != "all" else {"uniform", "spgemm", "spgemm_rmat", "gram", "host_api", "gemm", "spmv"}
+    want_sec = set(args.secondary.split(",")) if args.secondary != "all" else {"uniform", "spgemm", "spgemm_rmat", "gram", "host_api", "gemm", "spmv", "rows"}
     with_cpu = not args.no_cpu
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "rmat":
         secondary = {}
@@ -1348,6 +1400,8 @@ def main():
                 raise
             except Exception as exc:  # noqa: BLE001
                 secondary["spmv"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        if "rows" in want_sec:
+            secondary.update(secondary_rows_f3_f4_a4(torch, abi, dev))
         if "gemm" in want_sec:
             try:
                 secondary["gemm_dense"] = secondary_gemm(torch, abi, dev, with_cpu)  # (before the SpMM's CPU baselines: see its docstring)
