@@ -620,6 +620,7 @@ struct Options {
     int64_t transpose_radix_bits = 7;  // ... most bits of the column index per pass (4 .. 9): 2^18 columns = 3 passes of 6 bits (8.7 ms for 2.7e8 entries; 2 passes of 9 bits scatter 64-byte runs: 10.8 ms)
     int64_t transpose_lds_hist = 1;  // column histogram of a transpose through LDS ranges (>= 2^22 entries, <= 2^20 columns); 0: one global atomic per entry
     int64_t spgemm_narrow_ptr = 1;   // k_row_ub gathers B's row extents from an int32 copy of its row pointer made per call (nnz(B) < 2^31, >= 2^16 rows): half the table, twice the pointers per line
+    int64_t spmmd_lds = 1;           // sparse x sparse -> dense: rows of the result built in LDS tiles and written once (0: zero fill + global atomics)
     int64_t spgemm_col_panels = 1;   // B wider than the LDS bitmap of the big-row path (~1.1 M columns) and rows of the product too long for the LDS hash: product by panels of 2^20 columns (0: global-memory hash)
     int64_t spgemm_sort_ingest = 1;  // B with unsorted rows and rows of the product too long for the LDS hash: multiply by a sorted copy of B (0: global-memory hash)
     int64_t spgemm_onepass = 1;      // products whose rows all fit the small LDS tables: ONE kernel (no symbolic pass), rows placed by a decoupled look-back; 0: always two phases

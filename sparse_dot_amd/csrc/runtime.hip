@@ -853,6 +853,8 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.transpose_lds_hist = value;
         } else if (!strcmp(name, "spgemm_narrow_ptr")) {
             o.spgemm_narrow_ptr = value;
+        } else if (!strcmp(name, "spmmd_lds")) {
+            o.spmmd_lds = value;
         } else if (!strcmp(name, "spgemm_col_panels")) {
             o.spgemm_col_panels = value;
         } else if (!strcmp(name, "spgemm_sort_ingest")) {

@@ -2726,6 +2726,42 @@ static void spgemm_symbolic(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& 
     trace_mark("scan", t_last);
 }
 
+// The same product with the row of C built in LDS (round 5): one workgroup per output row walks the row's products once per
+// column tile of 128 KiB, adds them into the tile (LDS atomics: no global atomic, no zero fill of C beforehand) and writes the
+// tile once.  k_fill_dense + k_spmmd wrote the 2 GiB result of two 2^14-square operands twice and went through global atomics:
+// 1.39 ms.  Rows of C wider than a tile re-walk the row's products per tile (the dense form is for small M N: SURVEY a4).
+constexpr int SPMMD_TILE_BYTES = 128 * 1024;
+template <typename T>
+__global__ void __launch_bounds__(1024)
+    k_spmmd_lds(int64_t rows, int64_t ncols, const int64_t* __restrict__ aptr, const int32_t* __restrict__ acol,
+                const T* __restrict__ aval, const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol,
+                const T* __restrict__ bval, T* __restrict__ C, int64_t c_rs, int64_t c_cs)
+{
+    constexpr int TW = SPMMD_TILE_BYTES / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) T acc[TW];
+    const int tid = threadIdx.x, wave = tid / WAVE, lane = tid % WAVE, nwaves = blockDim.x / WAVE;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int64_t a0 = aptr[row], a1 = aptr[row + 1];
+        T* crow = C + row * c_rs;
+        for (int64_t j0 = 0; j0 < ncols; j0 += TW) {
+            const int64_t j1 = j0 + TW < ncols ? j0 + TW : ncols;
+            for (int k = tid; k < (int)(j1 - j0); k += blockDim.x) acc[k] = vt<T>::zero();
+            __syncthreads();
+            for (int64_t p = a0 + wave; p < a1; p += nwaves) {
+                const int32_t kk = acol[p];
+                const T a = aval[p];
+                for (int64_t q = bptr[kk] + lane; q < bptr[kk + 1]; q += WAVE) {
+                    const int64_t j = bcol[q];
+                    if (j >= j0 && j < j1) lds_accum(&acc[j - j0], vt<T>::mul(a, bval[q]));
+                }
+            }
+            __syncthreads();
+            for (int k = tid; k < (int)(j1 - j0); k += blockDim.x) crow[(j0 + k) * c_cs] = acc[k];
+            __syncthreads();
+        }
+    }
+}
+
 // option "deterministic": the hash kernels add the products of an entry in whatever order their waves arrive: keep their
 // PATTERN, put the columns of every row in order (a unique arrangement) and form the values again in a fixed order
 template <typename T>
@@ -3214,11 +3250,18 @@ static int spmmd_generic(int op, mi_sparse_matrix_t A, mi_sparse_matrix_t B, int
         const size_t extent = row_major ? (size_t)((m - 1) * ldc + n) : (size_t)((n - 1) * ldc + m);
         Staged sc;
         sc.stage_in(C, sizeof(T) * extent, false);
-        MI_LAUNCH((k_fill_dense<T>), dim3((unsigned)ceil_div(m * n, 256)), dim3(256), c.stream, static_cast<T*>(sc.dev), m,
-                  n, c_rs, c_cs, vt<T>::zero());
-        MI_LAUNCH((k_spmmd<T>), dim3((unsigned)ceil_div(m * WAVE, 256)), dim3(256), c.stream, m, (const int64_t*)a.ptr,
-                  (const int32_t*)a.col, (const T*)a.val, (const int64_t*)b.ptr, (const int32_t*)b.col,
-                  (const T*)b.val, static_cast<T*>(sc.dev), c_rs, c_cs);
+        if (options().spmmd_lds) {
+            const unsigned grid = (unsigned)std::min<int64_t>(m, (int64_t)std::max(c.cus, 1) * 64);
+            MI_LAUNCH((k_spmmd_lds<T>), dim3(grid), dim3(1024), c.stream, m, n, (const int64_t*)a.ptr, (const int32_t*)a.col,
+                      (const T*)a.val, (const int64_t*)b.ptr, (const int32_t*)b.col, (const T*)b.val, static_cast<T*>(sc.dev), c_rs,
+                      c_cs);
+        } else {
+            MI_LAUNCH((k_fill_dense<T>), dim3((unsigned)ceil_div(m * n, 256)), dim3(256), c.stream, static_cast<T*>(sc.dev), m,
+                      n, c_rs, c_cs, vt<T>::zero());
+            MI_LAUNCH((k_spmmd<T>), dim3((unsigned)ceil_div(m * WAVE, 256)), dim3(256), c.stream, m, (const int64_t*)a.ptr,
+                      (const int32_t*)a.col, (const T*)a.val, (const int64_t*)b.ptr, (const int32_t*)b.col,
+                      (const T*)b.val, static_cast<T*>(sc.dev), c_rs, c_cs);
+        }
         MI_HIP_CHECK(hipGetLastError());
         sc.copy_back();
     });
