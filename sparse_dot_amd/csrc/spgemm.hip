@@ -85,10 +85,59 @@ __global__ void __launch_bounds__(256)
         is_long = a1 - a0 > ROWUB_LONG;
         if (is_long) {
             if (sub == 0) long_list[atomicAdd(long_count, 1u)] = (int32_t)row;
-        } else {
+        } else if (upper != 2) {
             for (int64_t p = a0 + sub; p < a1; p += LPR) {
                 const int32_t k = acol[p];
                 row_ub_one(p, (int32_t)row, acol, (int64_t)bptr[k], (int64_t)bptr[k + 1], bcol, upper, s, ext0, extlen, row_shift);
+            }
+        }
+    }
+    if (upper == 2) {
+        // Upper triangle, sorted rows of B: where row k of B crosses the diagonal.  A bisection per nonzero of A is four or five
+        // DEPENDENT gathers (1.08 of the 3.8 ms of a sparse gram product with 16-entry rows).  Rows of B of at most 16 entries
+        // are instead read whole by the 16 lanes of the group -- sixteen nonzeros of A per step, their sixteen loads issued
+        // together, the position = the number of entries left of the diagonal (one ballot each); longer rows keep the search.
+        // (Every lane of the wave runs the loop: rows past the end / listed rows have an empty extent.)
+        const bool mine = row < rows && !is_long;
+        const int64_t a0 = mine ? aptr[row] : 0, a1 = mine ? aptr[row + 1] : 0;
+        const int grp_shift = (threadIdx.x & 63) & ~(LPR - 1);
+        const int32_t diag = (int32_t)row - row_shift;
+        int64_t steps = (a1 - a0 + LPR - 1) / LPR;
+#pragma unroll
+        for (int d = LPR; d < 64; d <<= 1) {  // the longest row of the wave's four groups
+            const int64_t o = __shfl_xor(steps, d);
+            steps = o > steps ? o : steps;
+        }
+        for (int64_t it = 0; it < steps; ++it) {
+            const int64_t p = a0 + it * LPR + sub;
+            const bool valid = p < a1;
+            int64_t b0 = 0, b1 = 0;
+            if (valid) {
+                const int32_t k = acol[p];
+                b0 = (int64_t)bptr[k];
+                b1 = (int64_t)bptr[k + 1];
+            }
+            const int len = (int)(b1 - b0);
+            int32_t cv[LPR];
+#pragma unroll
+            for (int e = 0; e < LPR; ++e) {
+                const int64_t be = __shfl(b0, e, LPR);
+                const int le = __shfl(len, e, LPR);
+                cv[e] = (le <= LPR && sub < le) ? bcol[be + sub] : 0x7fffffff;
+            }
+            int left = 0;
+#pragma unroll
+            for (int e = 0; e < LPR; ++e) {
+                const unsigned long long m = __ballot(cv[e] < diag);
+                const int cnt = __popc((unsigned)((m >> grp_shift) & ((1u << LPR) - 1u)));
+                if (sub == e) left = cnt;
+            }
+            if (valid) {
+                int64_t start = b0;
+                if (b0 < b1) start = len <= LPR ? b0 + left : lower_bound_col(bcol, b0, b1, diag);
+                s += b1 - start;
+                ext0[p] = start;
+                extlen[p] = (int32_t)(b1 - start);
             }
         }
     }
