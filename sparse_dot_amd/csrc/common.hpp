@@ -360,6 +360,7 @@ struct Context {
     bool initialised = false;
     int device = -1;  // -1: adopt the calling thread's current HIP device at first use (mi_sparse_set_device overrides)
     int cus = 0;      // compute units of `device` (persistent-kernel grids)
+    size_t total_bytes = 0;  // memory of `device` (asked once: hipMemGetInfo is a driver query)
     hipStream_t stream = nullptr;
     // grow-only scratch arena; kernels on one stream execute in order, so a later call may reuse
     // the arena as soon as it is enqueued behind the earlier one
@@ -374,6 +375,7 @@ struct Context {
     void sync();
 };
 Context& ctx();
+size_t device_total_bytes();  // of the calling thread's device
 
 // Large host <-> device copies of PAGEABLE caller memory (the reference's calling convention hands over numpy
 // buffers): a plain hipMemcpy stages them through one pinned bounce buffer on one thread (~18 GB/s measured);

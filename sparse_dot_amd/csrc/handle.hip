@@ -1756,6 +1756,7 @@ mi_sparse_status_t mi_sparse_order(mi_sparse_matrix_t A)
         // entries have moved (the row partition itself depends only on the row pointer and stays valid)
         for (mi::SpmmPlan* p : {&h->plan, &h->planT}) {
             p->reset_hot();
+            p->reset_kpart();  // (its own copy of the entries stays a valid matrix, but it is rebuilt from the ordered arrays: one summation order per handle state)
         }
         // MKL orders the caller's arrays in place; mirror that for host-created handles
         if (!was_sorted && h->user_col && h->user_val && h->origin != 'b' && primary.nnz) {

@@ -269,7 +269,17 @@ void Context::ensure()
     int n_cu = 0;
     MI_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
     cus = n_cu > 0 ? n_cu : 256;
+    size_t free_b = 0, total_b = 0;
+    MI_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    total_bytes = total_b;
     initialised = true;
+}
+
+size_t device_total_bytes()
+{
+    Context& c = ctx();
+    c.ensure();
+    return c.total_bytes;
 }
 
 void* Context::scratch_alloc(size_t bytes)

@@ -3261,6 +3261,15 @@ static void sp2m_run(int op_a, mi_sparse_matrix* ha, int op_b, mi_sparse_matrix*
             }
             if (finishes) spgemm_numeric<T>(a, b, r->csr, st->sym);
         });
+        if (finishes && !created) {
+            // a numeric re-run rewrote the values of an EXISTING result in place: whatever was derived from the old values is
+            // stale -- the transpose, the packed records of the dense gram, the column-partitioned SpMM plans (value copies)
+            std::lock_guard<std::mutex> lk(r->mtx);
+            r->csrT = Csr();
+            r->csr.gram_rec.release();
+            r->plan.reset_kpart();
+            r->planT.reset_kpart();
+        }
         ctx().sync();
     } catch (...) {
         if (created) {

@@ -1119,7 +1119,7 @@ __global__ void __launch_bounds__(256)
 
 // Build the column-partitioned form of `m` (synchronous: three scans whose totals size the arrays; ~1 ms of device time at
 // the headline's 31 M entries, paid once, ahead of the third product of a handle).  Sets p.kpart_state to 1 (declined) or 2.
-static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
+static void build_kpart_impl(SpmmPlan& p, const Csr& m, char vtype)
 {
     Context& c = ctx();
     const Options& o = options();
@@ -1128,9 +1128,17 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
     p.kpart_state = 1;
     p.kpart.reset();
     if (m.rows == 0 || m.nnz == 0) return;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    MI_HIP_CHECK(hipEventCreate(&e0));
-    MI_HIP_CHECK(hipEventCreate(&e1));
+    struct Events {  // destroyed on every way out (an allocation below may throw)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events()
+        {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } evs;
+    MI_HIP_CHECK(hipEventCreate(&evs.e0));
+    MI_HIP_CHECK(hipEventCreate(&evs.e1));
+    hipEvent_t e0 = evs.e0, e1 = evs.e1;
     MI_HIP_CHECK(hipEventRecord(e0, c.stream));
     const size_t vb = value_bytes(vtype);
     DevBuf flag_b, lidx_b, slen_b;
@@ -1157,11 +1165,7 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
     // worth it when the long rows carry a real share of the gather (their partial rows cost 2 P row widths each, so a row
     // must gather a multiple of that) and there is something left to balance across the chip
     const bool pays = n_long > 0 && kp->nnz_long * 4 >= m.nnz;
-    if (!(pays || (o.spmm_kpart == 2 && n_long > 0))) {
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        return;
-    }
+    if (!(pays || (o.spmm_kpart == 2 && n_long > 0))) return;
     kp->rowid.alloc(sizeof(int32_t) * (size_t)n_long);
     MI_LAUNCH(k_kp_rowid, dim3((unsigned)ceil_div(m.rows, 256)), dim3(256), c.stream, (const int64_t*)flag, (const int64_t*)lidx,
               m.rows, kp->rowid.as<int32_t>());
@@ -1214,11 +1218,25 @@ static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
     }
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     counters().spmm_kpart_build_ms += ms;
     p.kpart = std::move(kp);
     p.kpart_state = 2;
+}
+
+// The partitioned form is a second copy of the matrix ((4 + sizeof value) bytes per entry and a few row-sized arrays): on a
+// device that cannot hold it the product must not fail -- the row-owned kernel of the first two calls still works.  The plan
+// is then declined for good (kpart_state 1; set_values / order look again).
+static void build_kpart(SpmmPlan& p, const Csr& m, char vtype)
+{
+    try {
+        build_kpart_impl(p, m, vtype);
+    } catch (const status_error& e) {
+        if (e.status != MI_SPARSE_STATUS_ALLOC_FAILED) throw;
+        clear_error();
+        (void)hipGetLastError();
+        p.kpart.reset();
+        p.kpart_state = 1;
+    }
 }
 
 // One product with plan `p` of matrix `m` (row-major or column-major strides as given; see spmm_device for the layouts).
@@ -1400,14 +1418,11 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
             p.kpart_state = 0;  // the options changed (tools; the partitions' chunk ranges follow spmm_kpart_chunk): build again
         if (p.kpart_state == 0 && (p.uses >= 2 || o.spmm_plan_sync || o.spmm_kpart == 2)) build_kpart(p, m, h->vtype);
         hold_hot = p.kpart_state != 1;
-        if (p.kpart_state == 2) {
-            // the partial rows (one per long row and partition) live in the scratch arena: not for operands so wide that
-            // they would take a real share of the device
-            size_t free_b = 0, total_b = 0;
-            MI_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-            if ((double)p.kpart->cat.rows * (double)N * (double)sizeof(T) <= (double)total_b / 8.0) kp_keep = p.kpart;
-        }
+        if (p.kpart_state == 2) kp_keep = p.kpart;
     }
+    // the partial rows (one per long row and partition) live in the scratch arena: not for operands so wide that they would
+    // take a real share of the device (its size: asked once per host thread, outside the handle's mutex)
+    if (kp_keep && (double)kp_keep->cat.rows * (double)N * (double)sizeof(T) > (double)device_total_bytes() / 8.0) kp_keep.reset();
     if (kp_keep) {
         SpmmKpart& kp = *kp_keep;
         counters().spmm_last_kpart = (double)kp.P;

@@ -154,3 +154,45 @@ def test_sypr_sparse_and_dense(gpu, dtype, transpose_a):
         gpu.sparse_sypr(x.tocsc(), bu)
     with pytest.raises(ValueError):
         gpu.sparse_sypr(x.astype(np.complex128), bu.astype(np.complex128))
+
+
+def test_staged_refinalize_drops_value_copies_of_the_result(gpu):
+    """a FINALIZE re-run rewrites the values of an EXISTING result handle in place; what was derived from the
+    old values (the column-partitioned SpMM plan's copy, the cached transpose) must go.  NNZ_COUNT, FINALIZE, products with C
+    as the left operand until the partitioned plan is in use, set_values(A), FINALIZE, product again."""
+    import ctypes as ct
+    from sparse_dot_amd._mi_interface import MI, _check_return_value, matrix_descr
+    a = _pos(400, 300, 0.05, np.float64, 21)
+    a = sps.vstack([a[:100], _pos(4, 300, 0.9, np.float64, 22), a[100:]]).tocsr()  # long rows of C: the plan has something to split
+    b = _pos(300, 2000, 0.05, np.float64, 23)
+    x = np.random.default_rng(5).uniform(0.5, 1.5, (2000, 32))
+    y = np.empty((a.shape[0], 32))
+
+    def mm(hc, op=10):
+        out = y if op == 10 else np.empty((2000, 32))
+        rhs = x if op == 10 else np.ones((a.shape[0], 32))
+        _check_return_value(MI.call("mi_sparse_d_mm", op, ct.c_double(1.0), hc.ptr, matrix_descr(), 101, rhs.ctypes.data,
+                                    ct.c_int64(32), ct.c_int64(32), ct.c_double(0.0), out.ctypes.data, ct.c_int64(32)), "mm")
+        return out.copy()
+
+    opts = dict(spmm_kpart=2, spmm_kpart_min_row=16)
+    for k, v in opts.items():
+        gpu.mi_set_option(k, v)
+    try:
+        with gpu.StagedProduct(a, b) as p:
+            p.count()
+            p.finalize()
+            want = (a @ b) @ x
+            for _ in range(3):
+                assert np.allclose(mm(p._hc), want, rtol=1e-12)
+            assert gpu.mi_get_counter("spmm_last_kpart") == 8.0
+            assert np.allclose(mm(p._hc, 11), (a @ b).T @ np.ones((a.shape[0], 32)), rtol=1e-12)  # caches the transpose
+            a2 = a.copy()
+            a2.data[:] = np.random.default_rng(6).uniform(0.5, 1.5, a.nnz)
+            p.set_values(a=a2.data)
+            p.finalize()
+            assert np.allclose(mm(p._hc), (a2 @ b) @ x, rtol=1e-12)
+            assert np.allclose(mm(p._hc, 11), (a2 @ b).T @ np.ones((a.shape[0], 32)), rtol=1e-12)
+    finally:
+        gpu.mi_set_option("spmm_kpart", 1)
+        gpu.mi_set_option("spmm_kpart_min_row", 64)
