@@ -1243,8 +1243,13 @@ def main():
     worst = 0.0
     if rank == 0:
         Bfull = B
-        sel = torch.randint(0, n, (64,), device=dev)
         ip = indptr.to(torch.int64)
+        lens = ip[1:] - ip[:-1]
+        mid = torch.nonzero((lens >= 64) & (lens < 128)).flatten()
+        # the 8 longest rows, 8 rows just past the column-partition threshold (64 .. 127 entries), 24 random ones: the long-row
+        # kernels the timed steps ran are sampled on purpose (64 random rows of a power-law matrix contain ~3 long ones)
+        sel = torch.cat([torch.topk(lens, min(8, n)).indices, mid[torch.randperm(mid.numel(), device=dev)[:8]],
+                         torch.randint(0, n, (24,), device=dev)])
         for r in sel.tolist():
             lo, hi = int(ip[r]), int(ip[r + 1])
             want = (vals[lo:hi].double()[:, None] * Bfull[indices[lo:hi].long()].double()).sum(0)

@@ -492,6 +492,10 @@ const char *mi_sparse_last_error(void);
  *   spgemm_lds_parts, spgemm_slice_table, spgemm_slice_table_max, spgemm_part_log2s_bias,
  *   spgemm_force_global, spgemm_global_mode, spgemm_rank (1: big rows accumulate by rank on the stored row bitmaps and come
  *                   out sorted, 0 (default): range-partitioned LDS hash)                              (SpGEMM big-row paths)
+ *   spgemm_hub (0 (default): off; 2: hub rows of a full product -- rows beyond the LDS hash classes -- through dense LDS
+ *                   accumulators over popularity-ordered column blocks of a relabelled copy of B (csrc/spgemm_hub.inc), 1: the same
+ *                   from spgemm_hub_min_products products on; 3: the relabelling alone.  Measured at parity with the default
+ *                   range path on the literal configs[2]; tuning: spgemm_hub_fill_pct, spgemm_hub_acc_kb, spgemm_hub_block_kb)
  *   spgemm_onepass (1: a product whose rows all have <= 512 products runs as ONE kernel -- no symbolic pass, the rows of the
  *                   result are placed by a decoupled look-back; 0: always symbolic + numeric)
  *   transpose_lds_hist (1: the column histogram of a device transpose -- CSC operands, gram matrices -- runs through LDS ranges of

@@ -626,6 +626,11 @@ struct Options {
     int64_t spgemm_col_panels = 1;   // B wider than the LDS bitmap of the big-row path (~1.1 M columns) and rows of the product too long for the LDS hash: product by panels of 2^20 columns (0: global-memory hash)
     int64_t spgemm_sort_ingest = 1;  // B with unsorted rows and rows of the product too long for the LDS hash: multiply by a sorted copy of B (0: global-memory hash)
     int64_t spgemm_onepass = 1;      // products whose rows all fit the small LDS tables: ONE kernel (no symbolic pass), rows placed by a decoupled look-back; 0: always two phases
+    int64_t spgemm_hub = 0;          // hub rows of a (full) product through dense LDS accumulators over popularity-ordered column blocks of a relabelled copy of B (spgemm_hub.inc): 0 never (default: measured at parity with the range path on the literal configs[2] -- 166 vs 154 ms, profiles/r06_spgemm_hub_steps.log), 1 when the product is large and skewed enough, 2 whenever a row is beyond the LDS hash classes (tests), 3 the relabelling alone (range path on the relabelled copy: 164 ms)
+    int64_t spgemm_hub_min_products = (int64_t)1 << 28;  // ... option value 1: products (upper bound) from which the relabelled copies pay
+    int64_t spgemm_hub_fill_pct = 20;  // ... a block is accumulated densely for the rows whose expected products fill at least this share of it
+    int64_t spgemm_hub_acc_kb = 64;    // ... accumulators of one workgroup (widest block = this many KiB of values, at most 16384 columns)
+    int64_t spgemm_hub_block_kb = 1 << 20;  // ... a block holds at most this many KiB of B's entries (narrower blocks where the columns are popular)
     int64_t pool_enable = 1;       // cache released device blocks for reuse (0: hipFree at once)
     int64_t pool_max_mb = -1;      // cap on cached bytes; -1 = half of the device memory
     int64_t trace_phases = 0;      // print host wall-clock per SpGEMM phase to stderr (diagnostics; synchronises)
@@ -650,6 +655,7 @@ struct Counters {
     double spmm_plans_built = 0.0;
     double spmm_last_kpart = 0.0;     // column partitions the last SpMM ran its long rows with (0: row-owned only)
     double spmm_kpart_long_share = 0.0;  // share of the nonzeros in partitioned rows (last SpMM)
+    double spgemm_hub_items = 0.0;    // (hub row, column block) pairs accumulated densely by SpGEMM products, accumulated
     double spgemm_panels = 0.0;       // column panels multiplied by SpGEMM products of a B wider than the LDS bitmap, accumulated
     double spmm_kpart_build_ms = 0.0; // host wall time spent building column-partitioned plans, accumulated
     double bsr_native_calls = 0.0;    // products served by the BSR block kernel

@@ -871,6 +871,20 @@ mi_sparse_status_t mi_sparse_set_option(const char* name, int64_t value)
             o.spgemm_sort_ingest = value;
         } else if (!strcmp(name, "spgemm_onepass")) {
             o.spgemm_onepass = value;
+        } else if (!strcmp(name, "spgemm_hub")) {
+            if (value < 0 || value > 3) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spgemm_hub must be 0, 1, 2 or 3");
+            o.spgemm_hub = value;
+        } else if (!strcmp(name, "spgemm_hub_min_products")) {
+            o.spgemm_hub_min_products = value;
+        } else if (!strcmp(name, "spgemm_hub_fill_pct")) {
+            if (value < 1 || value > 1000) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spgemm_hub_fill_pct must be in [1, 1000]");
+            o.spgemm_hub_fill_pct = value;
+        } else if (!strcmp(name, "spgemm_hub_acc_kb")) {
+            if (value < 1 || value > 128) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spgemm_hub_acc_kb must be in [1, 128]");
+            o.spgemm_hub_acc_kb = value;
+        } else if (!strcmp(name, "spgemm_hub_block_kb")) {
+            if (value < 1) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "spgemm_hub_block_kb must be >= 1");
+            o.spgemm_hub_block_kb = value;
         } else if (!strcmp(name, "pool_enable")) {
             o.pool_enable = value;
             if (!value) mi::pool_trim();
@@ -925,6 +939,7 @@ mi_sparse_status_t mi_sparse_get_counter(const char* name, double* value)
         else if (!strcmp(name, "spmm_kpart_long_share")) *value = k.spmm_kpart_long_share;
         else if (!strcmp(name, "spmm_kpart_build_ms")) *value = k.spmm_kpart_build_ms;
         else if (!strcmp(name, "spgemm_panels")) *value = k.spgemm_panels;
+        else if (!strcmp(name, "spgemm_hub_items")) *value = k.spgemm_hub_items;
         else if (!strcmp(name, "bsr_native_calls")) *value = k.bsr_native_calls;
         else mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "unknown counter '%s'", name);
     });

@@ -21,6 +21,13 @@ namespace mi {
 
 constexpr int32_t HASH_EMPTY = -1;
 
+// how a numeric kernel writes a column index of C: key + base, or map[key] (the product ran on a relabelled copy of B)
+struct ColOut {
+    int32_t base = 0;
+    const int32_t* map = nullptr;
+    __device__ __forceinline__ int32_t operator()(int32_t key) const { return map ? map[key] : key + base; }
+};
+
 __device__ __forceinline__ uint32_t hash_col(int32_t c, int log2s)
 {
     return (uint32_t)((uint32_t)c * 2654435761u) >> (32 - log2s);
@@ -318,7 +325,7 @@ __global__ void __launch_bounds__(THREADS)
                  const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
                  const int32_t* __restrict__ bcol, const T* __restrict__ bval, int gw, int upper,
                  int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
-                 T* __restrict__ cval, int32_t col_base)
+                 T* __restrict__ cval, ColOut col_base)
 {
     constexpr int S = 1 << LOG2S;
     __shared__ int32_t keys[S];
@@ -415,7 +422,7 @@ __global__ void __launch_bounds__(THREADS)
             const int32_t key = keys[k];
             if (key != HASH_EMPTY) {
                 const int pos = atomicAdd(&counter, 1);
-                ccol[out0 + pos] = key + col_base;
+                ccol[out0 + pos] = col_base(key);
                 cval[out0 + pos] = vals[k];
             }
         }
@@ -435,7 +442,7 @@ __global__ void __launch_bounds__(64)
                  const int64_t* __restrict__ ext0, const int32_t* __restrict__ extlen, const T* __restrict__ aval,
                  const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
                  int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
-                 T* __restrict__ cval, int32_t col_base)
+                 T* __restrict__ cval, ColOut col_base)
 {
     constexpr int S = 1 << LOG2S, GW = 16, NG = 64 / GW, U = 4;
     __shared__ __attribute__((aligned(16))) int32_t keys[S];
@@ -531,7 +538,7 @@ __global__ void __launch_bounds__(64)
             int cnt;
             const int pos = wave_rank(key != HASH_EMPTY, cnt);
             if (key != HASH_EMPTY) {
-                ccol[out0 + written + pos] = key + col_base;
+                ccol[out0 + written + pos] = col_base(key);
                 cval[out0 + written + pos] = vals[k0 + lane];
             }
             written += cnt;
@@ -774,7 +781,7 @@ __global__ void __launch_bounds__(1024)
                     const T* __restrict__ aval, const int64_t* __restrict__ bptr, const int32_t* __restrict__ bcol,
                     const T* __restrict__ bval, int gw, int upper, int32_t* slab_keys, T* slab_vals, int64_t slab,
                     int64_t* __restrict__ row_nnz, const int64_t* __restrict__ cptr, int32_t* __restrict__ ccol,
-                    T* __restrict__ cval, unsigned long long* work_counter, int32_t col_base)
+                    T* __restrict__ cval, unsigned long long* work_counter, ColOut col_base)
 {
     __shared__ int counter;
     __shared__ long long next_idx;
@@ -837,7 +844,7 @@ __global__ void __launch_bounds__(1024)
                 const int32_t key = load_l2(&keys[k]);
                 if (key != HASH_EMPTY) {
                     const int pos = atomicAdd(&counter, 1);
-                    ccol[base + pos] = key + col_base;
+                    ccol[base + pos] = col_base(key);
                     T v;
                     if (vt<T>::is_complex) {
                         using R = typename vt<T>::real;
@@ -940,7 +947,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
     k_spgemm_gcompact(const int32_t* __restrict__ row_list, const int32_t* keys_all, const T* vals_all, int log2s,
                       unsigned long long* __restrict__ cursor, const int64_t* __restrict__ cptr,
-                      int32_t* __restrict__ ccol, T* __restrict__ cval, int32_t col_base)
+                      int32_t* __restrict__ ccol, T* __restrict__ cval, ColOut col_base)
 {
     __shared__ int count;
     __shared__ long long base;
@@ -973,7 +980,7 @@ __global__ void __launch_bounds__(256)
     for (int u = 0; u < PER; ++u) {
         if (pos[u] >= 0) {
             const int64_t k = k0 + tid + (int64_t)u * 256;
-            ccol[out0 + pos[u]] = key[u] + col_base;
+            ccol[out0 + pos[u]] = col_base(key[u]);
             cval[out0 + pos[u]] = vals[k];
         }
     }
@@ -1233,7 +1240,7 @@ __global__ void __launch_bounds__(256)
                   const int64_t* __restrict__ boff_by_row, const int64_t* __restrict__ aptr,
                   const int32_t* __restrict__ acol, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, int upper, int32_t diag_shift, const int64_t* __restrict__ slice_base,
-                  int32_t* __restrict__ bnd, const int32_t* __restrict__ work_t)
+                  int32_t* __restrict__ bnd, const int32_t* __restrict__ work_t, const int32_t* __restrict__ cfloor)
 {
     __shared__ int32_t tile_all[4][64][SLICE_EB + 1];  // [wave][range lane][nonzero]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1266,6 +1273,7 @@ __global__ void __launch_bounds__(256)
     if (p_ok && !is_end) {
         x = rb[p0 + pl];
         if (upper && x < row - diag_shift) x = row - diag_shift;  // (diag_shift: B is a column panel with rebased columns)
+        if (cfloor && x < cfloor[row]) x = cfloor[row];            // hub path: the columns left of the row's floor are not this path's
     }
     // SLICE_ILP nonzeros per lane at a time: their bisections advance in lockstep with unconditional loads, so
     // SLICE_ILP dependent chains are in flight per lane (one search after the other was ~10 dependent cache
@@ -1383,7 +1391,7 @@ __global__ void __launch_bounds__(PART_THREADS)
                   const int32_t* __restrict__ bounds, int64_t ncols, int64_t cap,
                   const int32_t* __restrict__ acol, const T* __restrict__ aval, const int64_t* __restrict__ bptr,
                   const int32_t* __restrict__ bcol, const T* __restrict__ bval, int upper,
-                  const int32_t* __restrict__ bnd, int32_t* __restrict__ ccol, T* __restrict__ cval, int32_t col_base, int32_t diag_shift)
+                  const int32_t* __restrict__ bnd, int32_t* __restrict__ ccol, T* __restrict__ cval, ColOut col_base, int32_t diag_shift, const int32_t* __restrict__ cfloor)
 {
     constexpr int S = 1 << LOG2S;
     constexpr int NT = PART_THREADS;
@@ -1438,6 +1446,7 @@ __global__ void __launch_bounds__(PART_THREADS)
                 int32_t c_lo = rb[pass];
                 const int64_t c_hi = pass + 1 < d.npass ? rb[pass + 1] : ncols;
                 if (upper && c_lo < row - diag_shift) c_lo = row - diag_shift;
+                if (cfloor && c_lo < cfloor[row]) c_lo = cfloor[row];
                 const int32_t kk = acol[p];
                 const int64_t b0 = bptr[kk], b1 = bptr[kk + 1];
                 s_n = b0;
@@ -1525,7 +1534,7 @@ __global__ void __launch_bounds__(PART_THREADS)
                 const int pos = atomicAdd(&n_out, 1);
                 // non-temporal: 117 GB of C on the literal configs[2], written once -- as plain stores they evict the slices of
                 // B that neighbouring ranges share (profiles/r04_spgemm_nt_stores_ab.log: 158.2 -> 153.5 ms)
-                __builtin_nontemporal_store(key + col_base, &ccol[out0 + pos]);
+                __builtin_nontemporal_store(col_base(key), &ccol[out0 + pos]);
                 if constexpr (!vt<T>::is_complex) __builtin_nontemporal_store(vals[k], &cval[out0 + pos]);
                 else cval[out0 + pos] = vals[k];
                 keys[k] = HASH_EMPTY;
@@ -1762,7 +1771,7 @@ __global__ void __launch_bounds__(NT, (sizeof(T) <= 8 ? 2 : 1) * NT / 256)  // t
                   const unsigned* __restrict__ bm, int64_t wpr, const int32_t* __restrict__ acol, const T* __restrict__ aval,
                   const int64_t* __restrict__ ext0, const int32_t* __restrict__ blkptr, int nblk1,
                   const int32_t* __restrict__ bcol, const T* __restrict__ bval, int32_t* __restrict__ ccol,
-                  T* __restrict__ cval, int32_t col_base)
+                  T* __restrict__ cval, ColOut col_base)
 {
     constexpr int CAP = rank_cap<T>();
     constexpr int WPT = RANK_SPANW / NT;  // bitmap words per thread
@@ -1889,7 +1898,7 @@ __global__ void __launch_bounds__(NT, (sizeof(T) <= 8 ? 2 : 1) * NT / 256)  // t
                 if (need >= c) { pos += 2; need -= c; }
                 c = (int)((x >> pos) & 1u);
                 if (need >= c) pos += 1;
-                ccol[d.out0 + k] = c0 + wi[u] * 32 + pos + col_base;
+                ccol[d.out0 + k] = col_base(c0 + wi[u] * 32 + pos);
             }
         }
 #pragma unroll
@@ -2096,6 +2105,8 @@ __global__ void k_fill_dense(T* C, int64_t r, int64_t cdim, int64_t c_rs, int64_
     C[i * c_rs + j * c_cs] = v;
 }
 
+#include "spgemm_hub.inc"
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -2251,7 +2262,8 @@ struct BigRows {
     DevBuf bounds;             // int32: range starts, P_max = ceil(min(ub, cols) / cap) slots per big row
     DevBuf ext0, extlen;       // per nonzero of A: first counted entry of B's row (int64) and their number (int32) -- k_row_ub
     bool grp = false;          // every row of B has <= 32 entries: the LDS bins up to 512 products run k_spgemm_grp
-    int32_t col_base = 0;      // numeric phase: added to every column index written (B is a column panel of a wider matrix, spgemm_panels)
+    ColOut col_base;           // numeric phase: how a column index is written -- plus a constant (B is a column panel of a wider matrix, spgemm_panels) or through a map (hub path: B was relabelled)
+    const int32_t* cfloor = nullptr;  // hub path: per row of A, the first (relabelled) column the range path owns -- the dense blocks left of it are accumulated by k_hub_num
     // upper-triangle product of a column panel: the extents (ext0 / extlen) are cut at the diagonal shifted by the panel's first
     // column and the kernels that read them run as a full product; the two kernels that cut rows of B into column ranges from
     // B's own row pointer (k_part_slices, k_spgemm_part) clamp at row - diag_shift themselves
@@ -2373,7 +2385,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                 }
                 // round 4: keep the bitmaps for k_spgemm_rank when they (and the block starts of B's rows) are affordable
                 bool rank_path = false;
-                if (big.b_sorted && (options().spgemm_rank || big.want_rank) && sizeof(T) <= 8) {
+                if (big.b_sorted && (options().spgemm_rank || big.want_rank) && sizeof(T) <= 8 && !big.cfloor) {
                     const int nblk = (int)ceil_div(B.cols, (int64_t)RANK_G);
                     const int64_t wpr = (int64_t)nblk * RANK_GW;
                     const size_t need = sizeof(unsigned) * (size_t)wpr * (size_t)nbig + sizeof(uint16_t) * (size_t)nblk * (size_t)nbig +
@@ -2489,13 +2501,15 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                         MI_LAUNCH(k_part_item_map, dim3((unsigned)(wb < (1 << 20) ? wb : (1 << 20))), dim3(256), c.stream, total_work,
                                   nbig, (const int64_t*)work_off, work_t);
                     }
+                    if (options().trace_phases > 1) { MI_HIP_CHECK(hipStreamSynchronize(c.stream)); fprintf(stderr, "[mi_sparse spgemm]   small bins done\n"); }
                     launch_batched(ceil_div(total_work, 4), 256, [&](int64_t off, int64_t nblk) {  // total_work = waves
                         MI_LAUNCH(k_part_slices, dim3((unsigned)nblk), dim3(256), c.stream, off, (const int32_t*)big_list, nbig,
                                   (const int64_t*)work_off, (const int64_t*)item_off, bounds, brow, (const int64_t*)A.ptr,
                                   (const int32_t*)A.col, (const int64_t*)B.ptr, (const int32_t*)B.col, big.panel_upper ? 1 : upper,
-                                  big.diag_shift, (const int64_t*)slice_base, bnd, (const int32_t*)work_t);
+                                  big.diag_shift, (const int64_t*)slice_base, bnd, (const int32_t*)work_t, big.cfloor);
                     });
                 }
+                if (options().trace_phases > 1) { MI_HIP_CHECK(hipStreamSynchronize(c.stream)); fprintf(stderr, "[mi_sparse spgemm]   slices done\n"); }
                 // work items of the numeric kernel: groups of PART_GROUP consecutive ranges of a row
                 int64_t* groups = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
                 int64_t* group_off = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(nbig + 1)));
@@ -2520,7 +2534,7 @@ static void run_phase(const Csr& A, const Csr& B, int upper, const int64_t* cnt,
                         MI_LAUNCH((k_spgemm_part<T, L, P>), dim3((unsigned)nblk), dim3(PART_THREADS), c.stream, off, n_groups,
                                   (const int32_t*)item_t, (const PartDesc*)desc, bounds, B.cols, CAP, (const int32_t*)A.col,
                                   (const T*)A.val, (const int64_t*)B.ptr, (const int32_t*)B.col, (const T*)B.val,
-                                  big.panel_upper ? 1 : upper, (const int32_t*)bnd, ccol, cval, big.col_base, big.diag_shift);
+                                  big.panel_upper ? 1 : upper, (const int32_t*)bnd, ccol, cval, big.col_base, big.diag_shift, big.cfloor);
                     });
                 };
                 if (n_groups) {
@@ -2755,9 +2769,32 @@ static SpgemmBounds spgemm_bounds(const Csr& A, const Csr& B, bool upper, Csr& C
     return bd;
 }
 
+// One product on the hub path (spgemm_hub.inc): lives for the call.
+struct HubState {
+    int nbd = 0;          // dense-capable column blocks (relabelled columns [0, bcol0[nbd]))
+    int wmax = 0;         // widest of them (accumulators of k_hub_num)
+    int nw = 4;           // waves per workgroup of k_hub_sym / k_hub_num: one per 1024 slots of the widest block (8, 4, 2 or 1)
+    int64_t nhub = 0;     // rows with at least one dense block, in order of decreasing block count
+    int64_t rows1 = 0;    // B.rows + 1: stride of a block's row pointer in ptrb
+    int64_t n_items = 0;  // (row, block) pairs
+    DevBuf newid, inv;    // int32[cols]: relabelling of B's columns and its inverse
+    DevBuf bcol0;         // int32[nbd + 1]: first relabelled column of every block
+    DevBuf lut;           // uint16 per granule of HUB_GRAN relabelled columns: its block
+    DevBuf ptrb;          // int32[nbd * rows1]: CSR row pointers of the blocks into lcol / lval
+    DevBuf lcol, lval;    // uint16 local column, value: the dense-capable entries of B, block-major
+    DevBuf hrow;          // HubRow[nhub]
+    DevBuf off;           // int64[nbd + 1]: first item of every block
+    DevBuf items;         // HubItem[n_items], block-major
+    DevBuf dcnt, doff;    // int32[nbd * nhub]: entries of C per (block, hub row) and where they start inside the row's dense part
+    DevBuf dtot;          // int64[A.rows + 1]: length of the dense part of every row of C (0: not a hub row)
+    DevBuf cfloor;        // int32[A.rows]: first relabelled column of the range path (0: the whole row)
+    DevBuf err;           // unsigned: items whose numeric count differed from the symbolic one
+    Csr Bs;               // B relabelled, rows sorted
+};
+
 // Phase 1: row pointer of C (C.ptr, C.nnz) -- binning, symbolic hash / bitmap kernels, scan.
 template <typename T>
-static void spgemm_symbolic(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, SpgemmBounds& bd)
+static void spgemm_symbolic(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, SpgemmBounds& bd, HubState* hub = nullptr)
 {
     Context& c = ctx();
     auto t_last = std::chrono::steady_clock::now();
@@ -2767,6 +2804,33 @@ static void spgemm_symbolic(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& 
     run_phase<T, false>(A, B, st.upper_mode, bd.ub, bd.stats, row_nnz, nullptr, nullptr, nullptr, st.big, &bd.lists);
     bd.lists_valid = bd.max_ub <= 2048;  // every row in an LDS class of every value type (classes 0-6)
     trace_mark("symbolic", t_last);
+    if (hub) {
+        // dense blocks of the hub rows: distinct columns per (row, block), their places inside the row, the rows' totals
+        HubState& h = *hub;
+        {
+            const unsigned grid_s = (unsigned)std::min<int64_t>(h.n_items, (int64_t)c.cus * (32 / h.nw));
+            auto go = [&](auto nw_tag) {
+                constexpr int NW = decltype(nw_tag)::value;
+                MI_LAUNCH((k_hub_sym<NW>), dim3(grid_s), dim3(NW * 64), c.stream, h.n_items, (const HubItem*)h.items.as<HubItem>(), h.nhub,
+                          (const int32_t*)A.col, (const int32_t*)h.ptrb.as<int32_t>(), h.rows1, (const uint16_t*)h.lcol.as<uint16_t>(),
+                          (const int32_t*)h.bcol0.as<int32_t>(), h.dcnt.as<int32_t>());
+            };
+            if (h.nw == 8) go(std::integral_constant<int, 8>{});
+            else if (h.nw == 4) go(std::integral_constant<int, 4>{});
+            else if (h.nw == 2) go(std::integral_constant<int, 2>{});
+            else go(std::integral_constant<int, 1>{});
+        }
+        MI_LAUNCH(k_hub_offsets, dim3((unsigned)ceil_div(h.nhub, 256)), dim3(256), c.stream, h.nhub, (const HubRow*)h.hrow.as<HubRow>(),
+                  (const int32_t*)h.dcnt.as<int32_t>(), h.doff.as<int32_t>(), h.dtot.as<int64_t>());
+        trace_mark("hub symbolic", t_last);
+        // a row of C = [range-path part: row_nnz][dense part: dtot]
+        int64_t* total = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
+        MI_LAUNCH(k_hub_add_len, dim3((unsigned)ceil_div(A.rows, 256)), dim3(256), c.stream, A.rows, (const int64_t*)row_nnz,
+                  (const int64_t*)h.dtot.as<int64_t>(), total);
+        C.nnz = exclusive_scan_i64(total, C.ptr, C.rows);
+        MI_LAUNCH(k_hub_out0, dim3((unsigned)ceil_div(h.nhub, 256)), dim3(256), c.stream, h.nhub, h.hrow.as<HubRow>(),
+                  (const int64_t*)C.ptr, (const int64_t*)row_nnz);
+    } else
     C.nnz = exclusive_scan_i64(row_nnz, C.ptr, C.rows);
     C.col = nullptr;
     C.val = nullptr;
@@ -2922,7 +2986,7 @@ static bool spgemm_onepass(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
 
 // Phase 2: column indices and values of C (storage allocated on the first run; repeatable).
 template <typename T>
-static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, SpgemmBounds* bd = nullptr)
+static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, SpgemmBounds* bd = nullptr, HubState* hub = nullptr)
 {
     Context& c = ctx();
     if (!st.done) fail(MI_SPARSE_STATUS_INVALID_VALUE, "numeric SpGEMM phase requested before the symbolic one");
@@ -2943,6 +3007,7 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     if (!C.val_own.p || C.val_own.bytes < sizeof(T) * (size_t)C.nnz) C.val_own.alloc(sizeof(T) * (size_t)C.nnz);
     C.col = C.col_own.as<int32_t>();
     C.val = C.val_own.p;
+    auto t_last = std::chrono::steady_clock::now();
     if (C.nnz > 0) {
         if (bd && bd->lists_valid) {  // same API call as the symbolic phase, small rows only: its row lists serve again
             run_phase<T, true>(A, B, st.upper_mode, st.row_nnz.as<int64_t>(), bd->stats, nullptr, C.ptr, C.col,
@@ -2953,6 +3018,35 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
                                static_cast<T*>(C.val), st.big);
         }
     }
+    trace_mark("numeric", t_last);
+    if (hub && C.nnz > 0) {
+        HubState& h = *hub;
+        MI_HIP_CHECK(hipMemsetAsync(h.err.p, 0, sizeof(unsigned), c.stream));
+        const size_t smem = sizeof(T) * (size_t)h.wmax;
+        // persistent workgroups: as many as the accumulators let a CU hold
+        auto go = [&](auto nw_tag) {
+            constexpr int NW = decltype(nw_tag)::value;
+            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / NW, (int64_t)(156 * 1024) / (int64_t)(smem + NW * sizeof(HubStage<T>) + 256)));
+            if (smem > 32 * 1024)  // more than 64 KiB of LDS per workgroup (static + dynamic) needs the attribute
+                MI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hub_num<T, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            MI_LAUNCH_SMEM((k_hub_num<T, NW>), dim3((unsigned)std::min<int64_t>(h.n_items, (int64_t)c.cus * per_cu)), dim3(NW * 64), smem,
+                           c.stream, h.n_items, (const HubItem*)h.items.as<HubItem>(), (const HubRow*)h.hrow.as<HubRow>(), h.nhub,
+                           (const int32_t*)A.col, (const T*)A.val, (const int32_t*)h.ptrb.as<int32_t>(), h.rows1,
+                           (const uint16_t*)h.lcol.as<uint16_t>(), (const T*)h.lval.as<T>(), (const int32_t*)h.bcol0.as<int32_t>(),
+                           (const int32_t*)h.inv.as<int32_t>(), (const int32_t*)h.dcnt.as<int32_t>(), (const int32_t*)h.doff.as<int32_t>(),
+                           C.col, static_cast<T*>(C.val), h.err.as<unsigned>(), h.wmax);
+        };
+        if (h.nw == 8) go(std::integral_constant<int, 8>{});
+        else if (h.nw == 4) go(std::integral_constant<int, 4>{});
+        else if (h.nw == 2) go(std::integral_constant<int, 2>{});
+        else go(std::integral_constant<int, 1>{});
+        note_kernel("k_hub_num<%s> + range path", type_name<T>());
+        unsigned bad = 0;
+        MI_HIP_CHECK(hipMemcpyAsync(&bad, h.err.p, sizeof(unsigned), hipMemcpyDeviceToHost, c.stream));
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+        if (bad) fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "hub path: %u (row, block) items counted differently by the two phases", bad);
+        trace_mark("hub numeric", t_last);
+    }
     if (options().trace_phases) {
         MI_HIP_CHECK(hipStreamSynchronize(c.stream));
         fprintf(stderr, "[mi_sparse spgemm] numeric done\n");
@@ -2962,7 +3056,7 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     C.sorted = false;
     // what mi_sparse_order may rely on (handle.hip, k_sort_ranges): rows longer than the LDS classes were written range by
     // range -- consecutive runs of `cap` entries whose column sets are disjoint and ascending from run to run
-    C.range_cap = st.big.out_range_cap;
+    C.range_cap = hub ? 0 : st.big.out_range_cap;  // (hub path: a long row is [ranges][dense blocks], and the ranges ascend in the RELABELLED column order)
     C.range_min_len = bin_limit((sizeof(T) >= 16 ? 7 : 8) - 1);
     C.sorted_min_len = st.big.have_rank ? C.range_min_len : 0;  // k_spgemm_rank wrote every longer row in column order
     if (options().deterministic && C.nnz > 0) {
@@ -2972,11 +3066,270 @@ static void spgemm_numeric(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& s
     }
 }
 
+
+// ---- hub path (spgemm_hub.inc): relabel B's columns by popularity, dense LDS accumulators for the leading blocks of the hub
+// rows, the range path for everything else.  `bd` / `st` come from spgemm_bounds(A, B) (full product: the extents are whole
+// rows of B, valid for the relabelled copy too -- it shares B's row pointer).  false: declined, nothing changed.
+template <typename T>
+static bool spgemm_hub(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, SpgemmBounds& bd)
+{
+    Context& c = ctx();
+    const Options& o = options();
+    constexpr int first_big = sizeof(T) >= 16 ? 7 : 8;
+    const int64_t hub_min = bin_limit(first_big - 1);  // rows of more products are beyond the LDS hash classes
+    if (!o.spgemm_hub || o.spgemm_force_global || !o.spgemm_lds_parts || o.spgemm_rank) return false;
+    if (bd.max_ub <= hub_min || B.nnz <= 0 || B.nnz >= ((int64_t)1 << 31) - 1 || A.nnz >= ((int64_t)1 << 31) - 1) return false;
+    if (bitmap_lds_bytes(B.cols) > (size_t)140 * 1024 || B.cols < 2 * HUB_GRAN) return false;  // (the range path's own limit)
+    if ((double)A.rows * (double)ceil_div(B.cols, st.big.cap) >= 2147483647.0) return false;   // its range-start table
+    // worth it for products with real hubs only: the relabelled copies of B cost a few milliseconds
+    if (o.spgemm_hub == 1 && (bd.sum_ub < o.spgemm_hub_min_products || bd.max_ub < 8 * hub_min)) return false;
+    auto t_last = std::chrono::steady_clock::now();
+    auto h = std::make_unique<HubState>();
+    const int64_t cols = B.cols, rowsB = B.rows;
+    const int64_t ngran = ceil_div(cols, (int64_t)HUB_GRAN);
+    try {
+        // 1. popularity of B's columns -> relabelling (most popular first), entries per granule of new columns
+        unsigned* hist = static_cast<unsigned*>(c.scratch_alloc(sizeof(unsigned) * (size_t)(cols + 1)));
+        unsigned* ccount = static_cast<unsigned*>(c.scratch_alloc(sizeof(unsigned) * 512));
+        unsigned* ccursor = ccount + 256;
+        unsigned* gran = static_cast<unsigned*>(c.scratch_alloc(sizeof(unsigned) * (size_t)(ngran + 1)));
+        MI_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)(cols + 1), c.stream));
+        MI_HIP_CHECK(hipMemsetAsync(ccount, 0, sizeof(unsigned) * 512, c.stream));
+        MI_HIP_CHECK(hipMemsetAsync(gran, 0, sizeof(unsigned) * (size_t)(ngran + 1), c.stream));
+        h->newid.alloc(sizeof(int32_t) * (size_t)cols);
+        h->inv.alloc(sizeof(int32_t) * (size_t)cols);
+        const unsigned egrid = (unsigned)std::min<int64_t>(ceil_div(B.nnz, 256), (int64_t)1 << 16);
+        const unsigned cgrid = (unsigned)std::min<int64_t>(ceil_div(cols, 256), (int64_t)1 << 14);
+        MI_LAUNCH(k_hub_colhist, dim3(egrid), dim3(256), c.stream, B.nnz, (const int32_t*)B.col, hist);
+        MI_LAUNCH(k_hub_class_count, dim3(cgrid), dim3(256), c.stream, cols, (const unsigned*)hist, ccount);
+        MI_LAUNCH(k_hub_class_scan, dim3(1), dim3(256), c.stream, (const unsigned*)ccount, ccursor);
+        MI_LAUNCH(k_hub_assign, dim3((unsigned)ceil_div(cols, 256)), dim3(256), c.stream, cols, (const unsigned*)hist, ccursor,
+                  h->newid.as<int32_t>(), h->inv.as<int32_t>(), gran);
+        std::vector<unsigned> hgran((size_t)ngran);
+        MI_HIP_CHECK(hipMemcpyAsync(hgran.data(), gran, sizeof(unsigned) * (size_t)ngran, hipMemcpyDeviceToHost, c.stream));
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+        // 2. column blocks: at most wmax columns (the accumulators of one workgroup) and at most ent_max entries of B (what one
+        //    block's slices may take of an L2) each; block b is dense for a row of ub products when ub * share_b >= thr * width_b
+        int wmax = (int)((o.spgemm_hub_acc_kb * 1024 / (int64_t)sizeof(T)) / HUB_GRAN * HUB_GRAN);
+        if (wmax > HUB_WMAX) wmax = HUB_WMAX;
+        if (wmax < HUB_GRAN) wmax = HUB_GRAN;
+        const int64_t ent_max = std::max<int64_t>(o.spgemm_hub_block_kb * 1024 / (int64_t)(2 + sizeof(T)), 1);
+        const double thr = (double)o.spgemm_hub_fill_pct / 100.0;
+        std::vector<int32_t> bcol0{0};
+        std::vector<double> tmin;
+        {
+            int64_t ent = 0;
+            int32_t start = 0;
+            for (int64_t g = 0; g < ngran && (int)tmin.size() < HUB_MAX_BLOCKS; ++g) {
+                const int32_t gend = (int32_t)std::min<int64_t>((g + 1) * HUB_GRAN, cols);
+                ent += hgran[(size_t)g];
+                const int32_t width = gend - start;
+                if (width >= wmax || ent >= ent_max || g + 1 == ngran) {
+                    const double share = (double)ent / (double)B.nnz;
+                    const double t = share > 0.0 ? thr * (double)width / share : 1e300;
+                    if ((double)bd.max_ub < t) break;  // not even the heaviest row is dense here (and the blocks only get emptier)
+                    bcol0.push_back(gend);
+                    tmin.push_back(t);
+                    start = gend;
+                    ent = 0;
+                }
+            }
+        }
+        if (o.spgemm_hub == 3) {
+            // experiment: the relabelling alone -- the range path on the relabelled, sorted copy of B (popular columns adjacent:
+            // a range of 1280 distinct columns is a narrow stripe of B there, its slices of B's rows are long)
+            Csr& Bs = h->Bs;
+            Bs.rows = B.rows;
+            Bs.cols = B.cols;
+            Bs.nnz = B.nnz;
+            Bs.ptr = B.ptr;
+            Bs.col_own.alloc(sizeof(int32_t) * (size_t)B.nnz);
+            Bs.val_own.alloc(sizeof(T) * (size_t)B.nnz);
+            Bs.col = Bs.col_own.as<int32_t>();
+            Bs.val = Bs.val_own.p;
+            MI_LAUNCH(k_hub_relabel, dim3(egrid), dim3(256), c.stream, B.nnz, (const int32_t*)B.col, (const int32_t*)h->newid.as<int32_t>(), Bs.col);
+            MI_HIP_CHECK(hipMemcpyAsync(Bs.val, B.val, sizeof(T) * (size_t)B.nnz, hipMemcpyDeviceToDevice, c.stream));
+            Bs.valid = true;
+            Bs.sorted = false;
+            sort_csr(type_char<T>::value, Bs);
+            cache_set(Bs.sorted, true);
+            trace_mark("relabelled copy of B", t_last);
+            st.big.b_sorted = true;
+            st.b_gen = Bs.order_gen;
+            st.big.col_base.map = h->inv.as<int32_t>();
+            st.big.want_rank = false;
+            spgemm_symbolic<T>(A, Bs, C, st, bd);
+            spgemm_numeric<T>(A, Bs, C, st, &bd);
+            C.range_cap = 0;
+            c.sync();
+            st.big.col_base.map = nullptr;
+            return true;
+        }
+        const int nbd = (int)tmin.size();
+        if (nbd == 0) return false;
+        h->nbd = nbd;
+        h->wmax = 0;
+        for (int b = 0; b < nbd; ++b) h->wmax = std::max(h->wmax, (int)(bcol0[(size_t)b + 1] - bcol0[(size_t)b]));
+        h->nw = h->wmax > 4096 ? 8 : h->wmax > 2048 ? 4 : h->wmax > 1024 ? 2 : 1;
+        h->rows1 = rowsB + 1;
+        const int32_t cmax = bcol0[(size_t)nbd];
+        std::vector<uint16_t> lut((size_t)ceil_div(cmax, (int64_t)HUB_GRAN) + 1, 0);
+        for (int b = 0; b < nbd; ++b)
+            for (int32_t g = bcol0[(size_t)b] >> HUB_GRAN_LOG2; g < (bcol0[(size_t)b + 1] + HUB_GRAN - 1) >> HUB_GRAN_LOG2; ++g) lut[(size_t)g] = (uint16_t)b;
+        // the block table must be affordable next to the result
+        if ((double)nbd * (double)h->rows1 * 4.0 > (double)device_total_bytes() / 32.0) return false;
+        h->bcol0.alloc(sizeof(int32_t) * (size_t)(nbd + 1));
+        h->lut.alloc(lut.size() * sizeof(uint16_t));
+        double* tmin_d = static_cast<double*>(c.scratch_alloc(sizeof(double) * (size_t)nbd));
+        MI_HIP_CHECK(hipMemcpyAsync(h->bcol0.p, bcol0.data(), sizeof(int32_t) * (size_t)(nbd + 1), hipMemcpyHostToDevice, c.stream));
+        MI_HIP_CHECK(hipMemcpyAsync(h->lut.p, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c.stream));
+        MI_HIP_CHECK(hipMemcpyAsync(tmin_d, tmin.data(), sizeof(double) * (size_t)nbd, hipMemcpyHostToDevice, c.stream));
+        // 3. hub rows: how many dense blocks each, in order of decreasing count; floors
+        int32_t* nd_of_row = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)(A.rows + 1)));
+        unsigned* ndcount = static_cast<unsigned*>(c.scratch_alloc(sizeof(unsigned) * (size_t)(nbd + 2)));
+        MI_HIP_CHECK(hipMemsetAsync(ndcount, 0, sizeof(unsigned) * (size_t)(nbd + 2), c.stream));
+        const unsigned rgrid = (unsigned)ceil_div(A.rows, 256);
+        MI_LAUNCH(k_hub_nd, dim3(rgrid), dim3(256), c.stream, A.rows, (const int64_t*)bd.ub, hub_min, nbd, (const double*)tmin_d,
+                  nd_of_row, ndcount);
+        std::vector<unsigned> hnd((size_t)nbd + 2);
+        MI_HIP_CHECK(hipMemcpyAsync(hnd.data(), ndcount, sizeof(unsigned) * (size_t)(nbd + 2), hipMemcpyDeviceToHost, c.stream));
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+        // rows with nd == m start at the number of rows with nd > m; block b is owned by the rows with nd > b
+        std::vector<unsigned> start((size_t)nbd + 2, 0);
+        std::vector<int64_t> off((size_t)nbd + 1, 0);
+        {
+            unsigned run = 0;
+            for (int m = nbd; m >= 1; --m) {
+                start[(size_t)m] = run;
+                run += hnd[(size_t)m];
+            }
+            h->nhub = run;
+            int64_t items = 0;
+            unsigned above = 0;  // rows with nd > b
+            std::vector<unsigned> owners((size_t)nbd, 0);
+            for (int b = nbd - 1; b >= 0; --b) {
+                above += hnd[(size_t)b + 1];
+                owners[(size_t)b] = above;
+            }
+            for (int b = 0; b < nbd; ++b) {
+                off[(size_t)b] = items;
+                items += owners[(size_t)b];
+            }
+            off[(size_t)nbd] = items;
+            h->n_items = items;
+        }
+        if (h->nhub == 0 || h->n_items == 0) return false;
+        if ((double)nbd * (double)h->nhub * 8.0 > (double)device_total_bytes() / 32.0) return false;
+        MI_HIP_CHECK(hipMemcpyAsync(ndcount, start.data(), sizeof(unsigned) * (size_t)(nbd + 2), hipMemcpyHostToDevice, c.stream));
+        h->off.alloc(sizeof(int64_t) * (size_t)(nbd + 1));
+        MI_HIP_CHECK(hipMemcpyAsync(h->off.p, off.data(), sizeof(int64_t) * (size_t)(nbd + 1), hipMemcpyHostToDevice, c.stream));
+        h->hrow.alloc(sizeof(HubRow) * (size_t)h->nhub);
+        h->cfloor.alloc(sizeof(int32_t) * (size_t)(A.rows + 1));
+        h->dtot.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
+        h->err.alloc(sizeof(unsigned));
+        MI_HIP_CHECK(hipMemsetAsync(h->dtot.p, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
+        MI_LAUNCH(k_hub_rank, dim3(rgrid), dim3(256), c.stream, A.rows, (const int32_t*)nd_of_row, ndcount,
+                  (const int32_t*)h->bcol0.as<int32_t>(), (const int64_t*)A.ptr, h->cfloor.as<int32_t>(), h->hrow.as<HubRow>());
+        h->items.alloc(sizeof(HubItem) * (size_t)h->n_items);
+        MI_LAUNCH(k_hub_items, dim3((unsigned)std::min<int64_t>(ceil_div(h->n_items, 256), (int64_t)1 << 16)), dim3(256), c.stream, h->n_items,
+                  (const int64_t*)h->off.as<int64_t>(), nbd, (const HubRow*)h->hrow.as<HubRow>(), h->items.as<HubItem>());
+        trace_mark("hub: relabel, rows", t_last);
+        // 4. B relabelled, rows sorted (shares B's row pointer)
+        Csr& Bs = h->Bs;
+        Bs.rows = B.rows;
+        Bs.cols = B.cols;
+        Bs.nnz = B.nnz;
+        Bs.ptr = B.ptr;
+        Bs.col_own.alloc(sizeof(int32_t) * (size_t)B.nnz);
+        Bs.val_own.alloc(sizeof(T) * (size_t)B.nnz);
+        Bs.col = Bs.col_own.as<int32_t>();
+        Bs.val = Bs.val_own.p;
+        MI_LAUNCH(k_hub_relabel, dim3(egrid), dim3(256), c.stream, B.nnz, (const int32_t*)B.col, (const int32_t*)h->newid.as<int32_t>(), Bs.col);
+        MI_HIP_CHECK(hipMemcpyAsync(Bs.val, B.val, sizeof(T) * (size_t)B.nnz, hipMemcpyDeviceToDevice, c.stream));
+        Bs.valid = true;
+        Bs.sorted = false;
+        sort_csr(type_char<T>::value, Bs);
+        cache_set(Bs.sorted, true);
+        trace_mark("hub: sorted copy of B", t_last);
+        // 5. its dense-capable columns block-major
+        {
+            DevBuf rowid_b;
+            rowid_b.alloc(sizeof(int32_t) * (size_t)B.nnz);
+            MI_LAUNCH(k_hub_rowid, dim3(egrid), dim3(256), c.stream, B.nnz, (const int64_t*)Bs.ptr, Bs.rows, rowid_b.as<int32_t>());
+            const int64_t ntab = (int64_t)nbd * h->rows1;
+            h->ptrb.alloc(sizeof(int32_t) * (size_t)(ntab + 1));
+            MI_HIP_CHECK(hipMemsetAsync(h->ptrb.p, 0, sizeof(int32_t) * (size_t)(ntab + 1), c.stream));
+            MI_LAUNCH(k_hub_blk_count, dim3(egrid), dim3(256), c.stream, B.nnz, (const int32_t*)rowid_b.as<int32_t>(), (const int64_t*)Bs.ptr,
+                      (const int32_t*)Bs.col, cmax, (const uint16_t*)h->lut.as<uint16_t>(), (const int32_t*)h->bcol0.as<int32_t>(), h->rows1,
+                      h->ptrb.as<int32_t>());
+            const int64_t ntiles = ceil_div(ntab + 1, (int64_t)HUB_SCAN_TILE);
+            int64_t* sums = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(ntiles + 1)));
+            int64_t* offs = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(ntiles + 1)));
+            MI_LAUNCH(k_hub_scan_sums, dim3((unsigned)ntiles), dim3(256), c.stream, (const int32_t*)h->ptrb.as<int32_t>(), ntab + 1, sums);
+            const int64_t nblk_entries = exclusive_scan_i64(sums, offs, ntiles);
+            MI_LAUNCH(k_hub_scan_apply, dim3((unsigned)ntiles), dim3(256), c.stream, h->ptrb.as<int32_t>(), ntab + 1, (const int64_t*)offs);
+            h->lcol.alloc(sizeof(uint16_t) * (size_t)(nblk_entries + 1));
+            h->lval.alloc(sizeof(T) * (size_t)(nblk_entries + 1));
+            MI_LAUNCH((k_hub_blk_fill<T>), dim3(egrid), dim3(256), c.stream, B.nnz, (const int32_t*)rowid_b.as<int32_t>(), (const int64_t*)Bs.ptr,
+                      (const int32_t*)Bs.col, (const T*)Bs.val, cmax, (const uint16_t*)h->lut.as<uint16_t>(), (const int32_t*)h->bcol0.as<int32_t>(),
+                      h->rows1, (const int32_t*)h->ptrb.as<int32_t>(), h->lcol.as<uint16_t>(), h->lval.as<T>());
+            MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // rowid_b goes (not Context::sync: that would release retired scratch arenas -- bd.ub may live in one)
+            if (o.trace_phases)
+                fprintf(stderr, "[mi_sparse spgemm] hub: %d blocks (<= %d columns) over %d of %lld columns, %lld of %lld entries of B; %lld hub rows, %lld items\n",
+                        nbd, h->wmax, (int)cmax, (long long)cols, (long long)nblk_entries, (long long)B.nnz, (long long)h->nhub, (long long)h->n_items);
+        }
+        trace_mark("hub: block-major copy", t_last);
+        // 6. the range path keeps what is right of every hub row's floor
+        MI_LAUNCH(k_hub_cut, dim3((unsigned)std::min<int64_t>(h->nhub, (int64_t)1 << 20)), dim3(256), c.stream, h->nhub,
+                  (const HubRow*)h->hrow.as<HubRow>(), (const int32_t*)A.col, (const int64_t*)Bs.ptr, (const int32_t*)Bs.col,
+                  (const int32_t*)h->cfloor.as<int32_t>(), st.big.ext0.as<int64_t>(), st.big.extlen.as<int32_t>(), bd.ub);
+        bd.stats = device_row_stats(bd.ub, A.rows);
+        bd.sum_ub = bd.stats.sum;
+        bd.max_ub = bd.stats.max;
+        bd.lists_valid = false;
+        h->dcnt.alloc(sizeof(int32_t) * (size_t)nbd * (size_t)h->nhub);
+        h->doff.alloc(sizeof(int32_t) * (size_t)nbd * (size_t)h->nhub);
+        trace_mark("hub: floors", t_last);
+    } catch (const status_error& e) {
+        if (e.status != MI_SPARSE_STATUS_ALLOC_FAILED) throw;
+        // the extents may have been cut already: the caller recomputes its bounds
+        clear_error();
+        (void)hipStreamSynchronize(c.stream);
+        return false;
+    }
+    st.big.b_sorted = true;
+    st.b_gen = h->Bs.order_gen;  // the extents were laid out for the relabelled copy (spgemm_numeric would rebuild them -- whole rows -- for an operand whose entries moved)
+    st.big.cfloor = h->cfloor.as<int32_t>();
+    st.big.col_base.map = h->inv.as<int32_t>();
+    st.big.want_rank = false;
+    st.upper_mode = 0;
+    spgemm_symbolic<T>(A, h->Bs, C, st, bd, h.get());
+    if (!st.big.have_bounds && bd.max_ub > hub_min)
+        fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "hub path: the range path recorded no range starts");
+    spgemm_numeric<T>(A, h->Bs, C, st, &bd, h.get());
+    c.sync();  // the relabelled copies are released on return
+    st.big.cfloor = nullptr;
+    st.big.col_base.map = nullptr;
+    counters().spgemm_hub_items += (double)h->n_items;
+    return true;
+}
+
 // C := A * B (or its upper triangle) for bounds `bd` / state `st` already computed by spgemm_bounds.
 template <typename T>
 static void spgemm_core(const Csr& A, const Csr& B, bool upper, Csr& C, SpgemmSymbolic& st, SpgemmBounds& bd, bool want_sorted = false)
 {
     st.big.want_rank = want_sorted;
+    // Hub rows through dense accumulators over popularity-ordered column blocks (round 6, spgemm_hub.inc): takes B sorted or
+    // not (it multiplies by a relabelled, sorted copy)
+    if (!upper && !options().deterministic) {
+        const int64_t ub_max0 = bd.max_ub;
+        if (spgemm_hub<T>(A, B, C, st, bd)) return;
+        if (bd.max_ub != ub_max0) {  // declined after the extents were cut (out of memory half way): start over
+            C = Csr();
+            bd = spgemm_bounds<T>(A, B, upper, C, st);
+            st.big.want_rank = want_sorted;
+        }
+    }
     // Sort on ingest (round 5): rows too long for the LDS hash tables need B's rows in column order (the bitmap path cuts
     // them into column ranges by search); with unsorted rows they fell to the global-memory hash -- correct, and several
     // times slower.  mkl_sparse_spmm takes unsorted input without penalty (reference _sparse_sparse.py:35-40), so: a sorted
@@ -3152,7 +3505,7 @@ static bool spgemm_panels(const Csr& A, const Csr& B, bool upper, Csr& C)
         for (size_t k = 0; k < panels.size(); ++k) {
             Panel& pn = *panels[k];
             const RowStats rs = device_row_stats(pn.st.row_nnz.as<int64_t>(), A.rows);
-            pn.st.big.col_base = (int32_t)base_of[k];  // the numeric kernels write the panel's columns at their place in B
+            pn.st.big.col_base.base = (int32_t)base_of[k];  // the numeric kernels write the panel's columns at their place in B
             run_phase<T, true>(A, pn.B, pn.st.upper_mode, pn.st.row_nnz.as<int64_t>(), rs, nullptr, cursor, C.col,
                                static_cast<T*>(C.val), pn.st.big);
             MI_LAUNCH(k_panel_add_len, dim3(agrid), dim3(256), c.stream, A.rows, (const int64_t*)pn.Cp.ptr, cursor);

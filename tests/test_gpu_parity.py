@@ -1424,13 +1424,26 @@ def test_config2_scale_properties(gpu):
         mm(b1, acc, 1.0, 1.0)
         torch.cuda.synchronize()
         assert ((acc - (r1 + r2)).abs() / acc.abs().clamp(min=1e-30)).max().item() <= 4 * F32_TOL
-        sel = torch.cat([torch.argmax(ip[1:] - ip[:-1]).reshape(1), torch.randint(0, n, (40,), device=dev)])
-        for r in sel.tolist():
-            lo, hi = int(ip[r]), int(ip[r + 1])
-            if hi == lo:
-                continue
-            want = (vals[lo:hi].double()[:, None] * b1[indices[lo:hi].long()].double()).sum(0)
-            assert ((r1[r].double() - want).abs() / want.abs()).max().item() <= F32_TOL
+        # (3) fp64 row sample on the kernels the bench TIMES: by now the handle has taken more than two products, so this one runs
+        # the column-partitioned plan (long rows by XCD partition + combine, short rows row-owned) -- asserted through the
+        # library's own counter; rows: the 8 longest, 8 of 64..127 entries (just past the partition threshold), 24 random
+        r3 = torch.empty((n, N), device=dev)
+        mm(b1, r3)
+        torch.cuda.synchronize()
+        assert gpu.mi_get_counter("spmm_last_kpart") == 8.0
+        lens = ip[1:] - ip[:-1]
+        mid = torch.nonzero((lens >= 64) & (lens < 128)).flatten()
+        sel = torch.cat([torch.topk(lens, 8).indices, mid[torch.randperm(mid.numel(), device=dev)[:8]],
+                         torch.randint(0, n, (24,), device=dev)])
+        assert mid.numel() >= 8
+        for res in (r1, r3):  # r1: the second product of the handle (row-owned kernel); r3: the partitioned plan
+            for r in sel.tolist():
+                lo, hi = int(ip[r]), int(ip[r + 1])
+                if hi == lo:
+                    assert not res[r].any()
+                    continue
+                want = (vals[lo:hi].double()[:, None] * b1[indices[lo:hi].long()].double()).sum(0)
+                assert ((res[r].double() - want).abs() / want.abs()).max().item() <= F32_TOL
     finally:
         if h:
             MI.call("mi_sparse_destroy", h)
