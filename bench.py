@@ -232,6 +232,22 @@ def cpu_baseline_gram(a, nrep=3):
                           % (a.shape[0], n, a.nnz, str(e)[:60])}
 
 
+def cpu_baseline_mkl(flops, make_call, sample, nrep=5, unit="GFLOP/s"):
+    """MKL through the build's own shim for one more entry point: `make_call(mkl)` returns (callable to time, cleanup)."""
+    try:
+        from oracle import mkl_shim
+        mkl = mkl_shim.MklSpmm()
+        fn, cleanup = make_call(mkl)
+        t = _median(_timed(fn, nrep))
+        cleanup()
+        time.sleep(0.4)  # MKL's OpenMP threads spin for a while after a parallel region: not into the next device measurement
+        return {"value": round(flops / t / 1e9, 3), "unit": unit, "cores": mkl.threads(), "kind": "reference", "ms": round(t * 1e3, 3),
+                "sample": "%s, median of %d calls after 1 warm-up via oracle/mkl_shim.py; %s; host has %d logical cpus"
+                          % (sample, nrep, mkl.version(), os.cpu_count())}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "note": "libmkl_rt unavailable or the call failed (%s)" % (str(e)[:120],)}
+
+
 # ------------------------------------------------------------------------------------------------
 # C-ABI helpers over torch device tensors
 # ------------------------------------------------------------------------------------------------
@@ -570,7 +586,7 @@ def secondary_spgemm(torch, abi, dev, kind, with_cpu):
     return out
 
 
-def secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, steps):
+def secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, steps, with_cpu=True):
     """SURVEY section 8 f1 (SpMV, mkl_sparse_?_mv, _sparse_vector.py:87-95) on the headline matrix and a5 (the SPARSE gram matrix,
     mkl_sparse_syrk, _gram_matrix.py:70-74) on a uniform 2^20 x 2^18, 16 / row fp64 operand -- the two rows of the scope table the
     line did not carry a measurement for."""
@@ -604,6 +620,17 @@ def secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, steps)
                                 "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes,
                                 "note": "nnz * 8 + (M + 1) * 8 + 2 M * 4; device time (events) of %d calls" % steps}}
     abi.destroy(h)
+    if with_cpu:
+        import numpy as np
+        import scipy.sparse as sps
+        ah = sps.csr_matrix((vals.cpu().numpy(), indices.cpu().numpy(), indptr.cpu().numpy()), shape=(n, n))
+        xh, yh = x.cpu().numpy(), np.zeros(n, dtype=np.float32)
+
+        def mk(mkl):
+            hh = mkl.make(ah)
+            return (lambda: mkl.mv(hh, xh, yh)), (lambda: mkl.destroy(hh))
+        out["spmv"]["cpu_baseline"] = cpu_baseline_mkl(2.0 * nnz, mk, "full workload (mkl_sparse_s_mv, %d nnz)" % nnz)
+        del ah
     m_, c_ = 1 << 20, 1 << 18
     u = uniform_csr(torch, m_, 16, 5, dev, ncols=c_)
     uv = u[2].double()
@@ -619,6 +646,25 @@ def secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, steps)
         if rep:
             ts.append(time.perf_counter() - t0)
         nnzc = abi.info(hc)[2]
+        if rep == 3:
+            # parity at scale: the row sums of triu(A^T A), from the result (C 1) and from the operand -- on the device, fp64:
+            # (triu(A^T A) 1)_i = sum over rows r of A with a_ri != 0 of a_ri * (sum of a_rj over j >= i)
+            onesc = torch.ones(c_, device=dev, dtype=torch.float64)
+            c1 = torch.empty(c_, device=dev, dtype=torch.float64)
+            abi.mv("d", hc, onesc, c1)
+            torch.cuda.synchronize()
+            ipu = u[0].to(torch.int64)
+            lens_u = ipu[1:] - ipu[:-1]
+            rows_of = torch.repeat_interleave(torch.arange(m_, device=dev), lens_u)
+            pos = torch.arange(int(u[1].numel()), device=dev) - ipu[:-1][rows_of]  # position of the entry inside its (sorted) row
+            wmax = int(lens_u.max())
+            dense_rows = torch.zeros((m_, wmax), device=dev, dtype=torch.float64)
+            dense_rows[rows_of, pos] = uv
+            suffix = torch.flip(torch.cumsum(torch.flip(dense_rows, [1]), 1), [1])[rows_of, pos]  # sum of a_rj over j >= this column
+            want = torch.zeros(c_, device=dev, dtype=torch.float64)
+            want.index_add_(0, u[1].long(), uv * suffix)
+            gram_parity = float(((c1 - want).abs() / want.abs().clamp(min=1e-300)).max())
+            del onesc, c1, rows_of, pos, dense_rows, suffix, want
         abi.destroy(hc)
     tg = _median(ts)
     lens = (u[0][1:] - u[0][:-1]).double()
@@ -626,15 +672,50 @@ def secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, steps)
     gbytes = (int(u[1].numel()) * 2 + nnzc) * 12 + 3 * (c_ + 1) * 8
     out["gram_sparse"] = {"workload": "upper triangle of A^T A as CSR (mkl_sparse_syrk): uniform %d x %d, 16 / row fp64; %d entries" % (m_, c_, nnzc),
                           "ms": round(tg * 1e3, 3), "value": round(2 * prod / tg / 1e9, 2), "unit": "GFLOP/s",
+                          "parity_rowsum_max_rel_err": gram_parity,
                           "roofline": {"bound": "hbm", "achieved": round(gbytes / tg / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(gbytes / tg / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": gbytes,
                                        "note": "(nnz(A) + nnz(A^T) + nnz(C)) * 12 + 3 (n + 1) * 8 over the whole call (cached transpose + SpGEMM "
                                                "restricted to col >= row), median of 3 after 1"}}
+    assert gram_parity <= 1e-12, "sparse gram row-sum parity check failed: %g" % gram_parity
     abi.destroy(hu)
+    if with_cpu:
+        # MKL's mkl_sparse_syrk in a CHILD process: oneMKL 2021.4 aborts with heap corruption on the full 2^20 x 2^18 operand
+        # (observed on the GPU box: "corrupted size vs. prev_size" inside the call), so the full workload is tried first and a row
+        # sample (the first 2^18 rows: a quarter of the products) second; whatever happens to the child, the line survives
+        import subprocess
+        import tempfile
+        import numpy as np
+        up, ui, ud = u[0].cpu().numpy(), u[1].cpu().numpy(), uv.cpu().numpy()
+        base = None
+        notes = []
+        for rows_s, what in ((m_, "full workload"), (m_ // 4, "row sample: the first 2^18 of the 2^20 rows")):
+            with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+                e = int(up[rows_s])
+                np.savez(os.path.join(tmp, "u.npz"), data=ud[:e], indices=ui[:e], indptr=up[:rows_s + 1], shape=np.array([rows_s, c_]))
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mkl_child.py"), "syrk", os.path.join(tmp, "u.npz"), "3"],
+                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+                    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+                except Exception as exc:  # noqa: BLE001
+                    r, lines = None, []
+                    notes.append("%s: %s" % (what, str(exc)[:80]))
+            if lines:
+                d = json.loads(lines[-1])
+                lens_s = (u[0][1:rows_s + 1] - u[0][:rows_s]).double()
+                prod_s = float((lens_s * (lens_s + 1) / 2).sum())
+                base = {"value": round(2 * prod_s / (d["ms"] / 1e3) / 1e9, 3), "unit": "GFLOP/s", "cores": d["cores"], "kind": "reference",
+                        "ms": round(d["ms"], 2),
+                        "sample": "%s (mkl_sparse_syrk, multiply only: no export), median of 3 after 1 in a child process via "
+                                  "oracle/mkl_shim.py; %s%s" % (what, d["version"], ("; " + "; ".join(notes)) if notes else "")}
+                break
+            notes.append("%s: MKL died (rc %s)" % (what, r.returncode if r is not None else "?"))
+        out["gram_sparse"]["cpu_baseline"] = base or {"value": None, "note": "; ".join(notes)}
+        time.sleep(0.4)
     return out
 
 
-def secondary_rows_f3_f4_a4(torch, abi, dev):
+def secondary_rows_f3_f4_a4(torch, abi, dev, with_cpu=True):
     """The remaining rows of the scope table: f3 (BSR x dense through the block kernel, _common.py:327-384) and f4 (staged product,
     pattern reuse) measured by tools/bench_ops.py in a child process (its last JSON line, trimmed); a4 (mkl_sparse_?_spmmd,
     _sparse_sparse.py:94-101: sparse x sparse into a DENSE row-major result) here."""
@@ -681,6 +762,21 @@ def secondary_rows_f3_f4_a4(torch, abi, dev):
                                      "note": "(nnz(A) + nnz(B)) * 12 + M N * 8 (the dense result written once), median of 3 after 1"}}
         for h in (ha, hb):
             abi.destroy(h)
+        if with_cpu:
+            import numpy as np
+            import scipy.sparse as sps
+            ah = sps.csr_matrix((av.cpu().numpy(), a[1].cpu().numpy(), a[0].cpu().numpy()), shape=(n, n))
+            bh = sps.csr_matrix((bv.cpu().numpy(), b[1].cpu().numpy(), b[0].cpu().numpy()), shape=(n, n))
+            del C
+            outh = np.zeros((n, n), dtype=np.float64)
+            prods = float((np.bincount(ah.indices, minlength=n).astype(np.float64) * np.diff(bh.indptr)).sum())
+
+            def mk(mkl):
+                h1, h2 = mkl.make(ah), mkl.make(bh)
+                return (lambda: mkl.spmmd(h1, h2, outh)), (lambda: (mkl.destroy(h1), mkl.destroy(h2)))
+            out["spmmd"]["cpu_baseline"] = cpu_baseline_mkl(2 * prods, mk, "full workload (mkl_sparse_d_spmmd into a preallocated 2 GiB array)", nrep=3)
+            out["spmmd"]["value"] = round(2 * prods / t / 1e9, 2)
+            out["spmmd"]["unit"] = "GFLOP/s"
     except Exception as exc:  # noqa: BLE001
         out["spmmd"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     return out
@@ -766,6 +862,15 @@ def secondary_gram(torch, abi, dev, with_cpu):
         else:
             first_call = time.perf_counter() - t0
     t = min(times)
+    # a FRESH handle in the now-warm process (what every later gram_matrix_mkl call pays: the released tables of the previous
+    # handle come back from the library's block cache instead of hipMalloc, the scratch arena is grown)
+    abi.destroy(h)
+    h = abi.create("s", ip, idx, val, m, ncols)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    abi.check(abi.MI.call("mi_sparse_s_syrkd", 11, h, 1.0, 0.0, C.data_ptr(), 101, ncols), "syrkd")
+    torch.cuda.synchronize()
+    fresh_warm = time.perf_counter() - t0
     colsq = torch.zeros(ncols, device=dev, dtype=torch.float64)
     for lo in range(0, int(idx.numel()), 1 << 24):  # in pieces: next to the 256 GiB output and the library's tables ~1 GiB is free
         colsq.index_add_(0, idx[lo:lo + (1 << 24)].long(), val[lo:lo + (1 << 24)].double() ** 2)
@@ -781,7 +886,11 @@ def secondary_gram(torch, abi, dev, with_cpu):
                                                                      ncols * ncols * 4 / 2**30),
            "ms": round(t * 1e3, 2), "value": round(flops / t / 1e9, 2), "unit": "GFLOP/s", "dtype": "f32",
            "first_call_ms": round(first_call * 1e3, 2),
-           "first_call_note": "mi_sparse_s_syrkd on a FRESH handle -- what the public gram_matrix_mkl pays on every call, as it "
+           "fresh_handle_warm_process_ms": round(fresh_warm * 1e3, 2),
+           "first_call_note": "first_call_ms: the FIRST mi_sparse_s_syrkd of the process (cold block cache: its tables are hipMalloc'ed); "
+                              "fresh_handle_warm_process_ms: the first call of a second fresh handle after the first was destroyed -- the "
+                              "tables come back from the block cache, the scratch arena is grown: transpose + tables + product.  "
+                              "mi_sparse_s_syrkd on a FRESH handle is what the public gram_matrix_mkl pays on every call, as it "
                               "creates its handle per call like the reference (_gram_matrix.py:121-127): the transpose of X "
                               "(round 5: a stable radix sort of the entries, 2 passes here), the tile tables and the packed "
                               "records, then the product; `ms` is the product alone on the same handle.  Device kernels of the first call: ~68 ms "
@@ -1088,6 +1197,17 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+    devices_seen = None
+    if dist is not None:
+        # every rank's (hostname-independent) device identity: index + PCI bus id, gathered once
+        try:
+            props = torch.cuda.get_device_properties(dev_index)
+            ident = "%d:%s" % (dev_index, getattr(props, "pci_bus_id", getattr(props, "uuid", "?")))
+        except Exception:  # noqa: BLE001
+            ident = str(dev_index)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ident)
+        devices_seen = {"distinct": len(set(gathered)), "by_rank": gathered}
 
     sda.mi_set_device(dev_index)
     stream = torch.cuda.current_stream()
@@ -1170,6 +1290,27 @@ def main():
             return ts
         cold = first_calls()   # first handle of the process: also pays the scratch arena / block cache / pinned slab set-up
         warm = first_calls()   # a fresh handle in a warm process: what every later handle pays
+
+        def single_call(optimize):
+            """create (device pointers) [+ mi_sparse_optimize] + ONE product + destroy on a fresh handle: what a caller of the
+            public dot_product_mkl(scipy_matrix, b) pays per call on the device side (before PCIe)."""
+            out = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                h0 = abi.create("s", indptr, indices, vals, n, n)
+                if optimize:
+                    abi.check(abi.MI.call("mi_sparse_optimize", h0), "optimize")
+                t1 = time.perf_counter()
+                abi.mm("s", h0, B, C0, N)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                abi.destroy(h0)
+                out.append(((t2 - t0) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
+            out.sort()
+            return out[1]
+        single = single_call(False)
+        single_opt = single_call(True)
         del C0
         plan = {"first_call_ms": round(warm[0], 3), "second_call_ms": round(warm[1], 3),
                 "third_call_ms_incl_column_partition_build": round(warm[2], 3),
@@ -1177,6 +1318,14 @@ def main():
                 "plan_ms": round(max(0.0, warm[0] - warm[1]), 3),
                 "column_partition_build_ms": round(max(0.0, warm[2] - min(warm[3:])), 3),
                 "first_call_ms_cold_process": round(cold[0], 3),
+                "single_call_ms": round(single[0], 3),
+                "single_call_after_optimize": {"create_plus_optimize_ms": round(single_opt[1], 3), "product_ms": round(single_opt[2], 3),
+                                               "total_ms": round(single_opt[0], 3)},
+                "single_call_note": "single_call_ms = mi_sparse_s_create_csr (device pointers: aliased) + ONE mi_sparse_s_mm + synchronise "
+                                    "on a fresh handle, median of 3: the device side of one public dot_product_mkl(scipy_matrix, b) -- "
+                                    "the row-owned kernel plus its plan.  single_call_after_optimize = the same with mi_sparse_optimize "
+                                    "(to_device(a, optimize=True)) between create and product: the inspector's cost up front, the "
+                                    "product at the steady-state rate",
                 "note": "one synchronised mi_sparse_s_mm per entry on a FRESH handle.  Calls 1-2 = the row-owned kernel (call 1 "
                         "also builds the row partition + fix-up schedule: plan_ms = call 1 - call 2); two products prove the "
                         "reuse, so call 3 builds the column-partitioned form of the long rows (three scans + two fill passes, "
@@ -1234,9 +1383,38 @@ def main():
                 "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
                 "kernel_ms_is": "device time of ONE product = the sum of its kernels (hipEvents on the launch stream around all "
                                 "of them): achieved = algorithmic bytes / that"}
+    try:  # what the reference stream of this product costs at the fabric (tools/l2_bound.py: a CPU replay through one 4 MiB cache per XCD)
+        with open(os.path.join(ROOT, "profiles", "r06_l2_bound.json")) as fh:
+            lb = json.load(fh)
+        pt = lb["partitioned"]
+        roofline["formulation_floor_ms"] = pt["floor_ms_at_6.2TBps"]["lru"]
+        roofline["formulation_floor"] = {
+            "lru_ms_at_6.2TBps": pt["floor_ms_at_6.2TBps"]["lru"], "lru_ms_at_7.4TBps": pt["floor_ms_at_7.4TBps"]["lru"],
+            "belady_ms_at_6.2TBps": pt["floor_ms_at_6.2TBps"]["opt"], "belady_ms_at_7.4TBps": pt["floor_ms_at_7.4TBps"]["opt"],
+            "fabric_GB_lru": pt["fabric_GB_lru"], "fabric_GB_belady": pt["fabric_GB_opt"],
+            "row_owned_fabric_GB_lru": lb["row_owned"]["fabric_GB_lru"], "row_owned_fabric_GB_belady": lb["row_owned"]["fabric_GB_opt"],
+            "floor_over_achieved": round(pt["floor_ms_at_6.2TBps"]["lru"] / (k_ms if k_ms > 0 else float("nan")), 3),
+            "note": "tools/l2_bound.py (committed result: profiles/r06_l2_bound.json): the B-row references of THIS schedule (rows of >= 64 "
+                    "entries by 8 column partitions on one XCD each, the rest row-owned in 2 column slices; 128-item chunks dealt to the XCDs "
+                    "as k_spmm maps them, 256 chunks in flight per XCD) replayed on the CPU through one fully associative 4 MiB cache per "
+                    "XCD.  LRU: the bytes a real L2 must fetch -- the model reproduces the counters (row-owned 10.2 GB against 10.3 GB "
+                    "measured in round 4; partitioned 6.8 GB against 7.5 GB measured) -- plus A once, C once and the partial rows twice, "
+                    "divided by the fabric rate the product's own kernels reach (6.2 TB/s) = the floor of this schedule on an LRU cache; "
+                    "Belady: the same with the optimal replacement policy (no hardware has it).  Matrix: the bench's generator on the CPU "
+                    "(same distribution, other random numbers)"}
+    except Exception as exc:  # noqa: BLE001
+        roofline["formulation_floor_ms"] = None
+        roofline["formulation_floor"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
     if world == 1:
-        copy_gbs = measured_copy_gbs(torch, dev)
+        torch_copy = measured_copy_gbs(torch, dev)
+        try:  # the library's own tuned copy kernel (16 B / lane, 4 - 8 in flight, plain and non-temporal, 4 - 32 workgroups per CU)
+            copy_gbs = max(torch_copy, float(sda.mi_probe_copy_gbs(1 << 31, 3)))
+        except Exception:  # noqa: BLE001
+            copy_gbs = torch_copy
         roofline["measured_copy_GBps"] = round(copy_gbs, 1)
+        roofline["measured_copy_note"] = ("best of the library's tuned copy kernel (mi_sparse_probe_copy: 2 GiB buffers, 16 variants, hipEvents) "
+                                          "and torch's tensor copy (%.0f GB/s); read + write bytes per second; the guide quotes 6.29 TB/s "
+                                          "for a float4 copy" % torch_copy)
         roofline["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)
 
     # ---- parity spot check of the timed configuration (a row sample of the gathered C vs fp64 on the GPU) ----
@@ -1281,6 +1459,11 @@ def main():
         if world > 1:
             line["collectives"] = {k: round(res[k] * 1e3, 3) for k in ("t_bcast", "t_gather_bcast", "t_gather_padded") if k in res}
             line["collectives"]["backend"] = backend
+            # what the process group itself reports (not what --gpus asked for): ranks, the backend torch resolved, and the
+            # devices behind the ranks (gathered): a line from "8 ranks on 1 GPU" or from gloo cannot pass as an 8-GPU RCCL run
+            line["collectives"]["ranks_seen"] = int(dist.get_world_size())
+            line["collectives"]["backend_seen"] = str(dist.get_backend())
+            line["collectives"]["devices_seen"] = devices_seen
             line["collectives"]["note"] = ("ms, this rank; bcast = B (%.0f MB) from rank 0; gather_bcast = all-gatherv as one "
                                            "broadcast per rank into its slice of C (no padding); gather_padded = pad to the "
                                            "tallest block + all_gather_into_tensor" % (n * N * 4 / 1e6))
@@ -1400,13 +1583,20 @@ def main():
             secondary["spmm_uniform"] = secondary_uniform_spmm(torch, abi, dev, n, N, B, args.steps, args.warmup)
         if "spmv" in want_sec:
             try:
-                secondary.update(secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, args.steps))
+                secondary.update(secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, args.steps, with_cpu))
             except AssertionError:
                 raise
             except Exception as exc:  # noqa: BLE001
                 secondary["spmv"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if "rows" in want_sec:
-            secondary.update(secondary_rows_f3_f4_a4(torch, abi, dev))
+            secondary.update(secondary_rows_f3_f4_a4(torch, abi, dev, with_cpu))
+        if not args.no_pmc:  # counter traffic of the three small secondaries (children under rocprofv3, two --pmc passes each)
+            for key, child, inc in (("spmv", ["spmv", "--reps", "3"], ("k_spmv", "k_spmm_fixup")),
+                                    ("gram_sparse", ["syrk", "--reps", "2"], ("mi::",)),
+                                    ("spmmd", ["spmmd", "--reps", "2"], ("k_spmmd", "k_fill_dense"))):
+                if isinstance(secondary.get(key), dict) and "error" not in secondary[key]:
+                    exc = () if key == "spmv" else ("k_spmv", "k_spmm", "k_check_", "k_widen_ptr", "k_count_descents", "k_count_start_descents")
+                    attach_traffic(secondary[key], child, int(child[-1]) + 1, inc, True, exclude=exc, need_free_bytes=8 << 30)
         if "gemm" in want_sec:
             try:
                 secondary["gemm_dense"] = secondary_gemm(torch, abi, dev, with_cpu)  # (before the SpMM's CPU baselines: see its docstring)

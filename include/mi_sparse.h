@@ -201,6 +201,12 @@ mi_sparse_status_t mi_sparse_destroy(mi_sparse_matrix_t A);
  * indices / values are also written back to the caller's arrays (the reference documents that
  * inputs "may be reordered in place", README.md:45-46). */
 mi_sparse_status_t mi_sparse_order(mi_sparse_matrix_t A);
+/* mkl_sparse_optimize analogue (MKL's inspector stage; the reference never calls it -- it creates a handle per product,
+ * _common.py:245-293 -- so nothing binds it there).  For a handle that will be the left operand of several mi_sparse_?_mm
+ * products: builds now what the library otherwise builds behind its first three products (row partition, fix-up schedule,
+ * and for >= 2^21 entries the column-partitioned form of the long rows), so the next product already runs the steady-state
+ * kernels.  Costs one pass over the matrix (~2-3 ms at 3e7 entries) and a second copy of its entries. */
+mi_sparse_status_t mi_sparse_optimize(mi_sparse_matrix_t A);
 
 /* mkl_sparse_convert_csr (reference call site _common.py:705-707): new CSR handle holding
  * op(A) converted from whatever format A was created in.  op must be 10 (the reference never
@@ -516,6 +522,10 @@ const char *mi_sparse_last_error(void);
  *                  tile).  A validation mode: several times slower, minutes on hub rows of > 1e8 products)
  *   profile_events, trace_phases                                               (diagnostics) */
 mi_sparse_status_t mi_sparse_set_option(const char *name, int64_t value);
+/* The device's copy rate (read + write bytes per second, GB/s) as this library's own tuned copy kernel reaches it: 16 bytes
+ * per lane, 4 - 8 independent accesses in flight, plain and non-temporal, 4 - 32 workgroups per CU; the best variant over
+ * `reps` timed launches each (hipEvents) on two fresh buffers of `bytes` bytes.  The "measured HBM roofline" of bench.py. */
+mi_sparse_status_t mi_sparse_probe_copy(int64_t bytes, int reps, double *best_gbs);
 /* Diagnostic counters of the calling thread.  With option "profile_events" = 1 the SpMM executor
  * brackets its main kernel with hipEvents on the launch stream and accumulates
  * "spmm_kernel_ms" (sum of durations) and "spmm_kernel_launches"; "reset" (any value pointer)

@@ -165,6 +165,39 @@ class MklSpmm:
             raise RuntimeError("mkl_sparse_%s_syrkd returned %d" % (letter, st))
         return out
 
+    def mv(self, handle, x, y):
+        """y := A x: mkl_sparse_?_mv (reference _sparse_vector.py:87-95)."""
+        h, letter, _keep = handle
+        fn = getattr(self.lib, "mkl_sparse_%s_mv" % letter)
+        ct = _ct.c_float if letter == "s" else _ct.c_double
+        fn.restype = _ct.c_int
+        fn.argtypes = [_ct.c_int, ct, _ct.c_void_p, _Descr, _ct.c_void_p, ct, _ct.c_void_p]
+        st = fn(10, 1.0, h, _Descr(20, 0, 0), x.ctypes.data, 0.0, y.ctypes.data)
+        if st:
+            raise RuntimeError("mkl_sparse_%s_mv returned %d" % (letter, st))
+        return y
+
+    def syrk(self, handle):
+        """Upper triangle of A^T A as a sparse handle: mkl_sparse_syrk(op = 11) (reference _gram_matrix.py:70-74: the rows
+        are ordered first, as the reference does), result destroyed at once -- the multiply is what is timed."""
+        c = _ct.c_void_p()
+        self.lib.mkl_sparse_syrk.restype = _ct.c_int
+        st = self.lib.mkl_sparse_syrk(_ct.c_int(11), handle[0], _ct.byref(c))
+        if st:
+            raise RuntimeError("mkl_sparse_syrk returned %d" % st)
+        self.lib.mkl_sparse_destroy(c)
+
+    def spmmd(self, ha, hb, out):
+        """out := A @ B, dense row-major: mkl_sparse_?_spmmd (reference _sparse_sparse.py:94-101)."""
+        letter = ha[1]
+        fn = getattr(self.lib, "mkl_sparse_%s_spmmd" % letter)
+        fn.restype = _ct.c_int
+        fn.argtypes = [_ct.c_int, _ct.c_void_p, _ct.c_void_p, _ct.c_int, _ct.c_void_p, self.cint]
+        st = fn(10, ha[0], hb[0], 101, out.ctypes.data, out.shape[1])
+        if st:
+            raise RuntimeError("mkl_sparse_%s_spmmd returned %d" % (letter, st))
+        return out
+
     def order(self, handle):
         self.lib.mkl_sparse_order.restype = _ct.c_int
         return self.lib.mkl_sparse_order(handle[0])

@@ -13,7 +13,7 @@ __version__ = "0.1.0"
 from .sparse_dot import dot_product_mkl, dot_product_transpose_mkl, gram_matrix_mkl, set_debug_mode  # noqa: F401
 from ._mi_interface import (  # noqa: F401
     mi_get_version_string, mi_get_device_count, mi_set_device, mi_set_stream, mi_synchronize, mi_set_option,
-    mi_get_counter, mi_get_last_kernel, mi_interface_integer_dtype, DeviceMatrix, to_device,
+    mi_get_counter, mi_get_last_kernel, mi_probe_copy_gbs, mi_interface_integer_dtype, DeviceMatrix, to_device,
 )
 
 from ._sparse_sypr import _sparse_sypr as sparse_sypr  # noqa: F401,E402  (reference _sparse_sypr.py, dead upstream)

@@ -64,6 +64,13 @@ def mi_get_counter(name):
     return v.value
 
 
+def mi_probe_copy_gbs(nbytes=1 << 31, reps=3):
+    """The device's copy rate in GB/s (read + write) by the library's tuned copy kernel (mi_sparse_probe_copy)."""
+    v = _ct.c_double()
+    _check_return_value(MI.call("mi_sparse_probe_copy", int(nbytes), int(reps), _ct.byref(v)), "mi_sparse_probe_copy")
+    return v.value
+
+
 def mi_get_last_kernel():
     """Name of the dominant kernel this thread launched last, as the library instantiated it."""
     buf = _ct.create_string_buffer(256)

@@ -245,11 +245,13 @@ class DeviceMatrix:
     tags) is built on the first product and cached on the handle, so repeated calls pay neither the
     PCIe copy of A nor the inspection again.  Free it with .free() (or let it be garbage collected)."""
 
-    def __init__(self, matrix):
+    def __init__(self, matrix, optimize=False):
         from ._checks import _is_allowed_sparse_format
         if not _sps.issparse(matrix) or not _is_allowed_sparse_format(matrix):
             raise ValueError("to_device needs a scipy CSR, CSC or BSR matrix")
         self._handle = SparseHandle.from_scipy(matrix)
+        if optimize:
+            self.optimize()
         self.shape = tuple(matrix.shape)
         self.dtype = _np.dtype(matrix.dtype)
         self.ndim = 2
@@ -262,6 +264,13 @@ class DeviceMatrix:
             raise ValueError("DeviceMatrix has been freed")
         return self._handle
 
+    def optimize(self):
+        """The inspector stage (mi_sparse_optimize, the mkl_sparse_optimize analogue): build now what the library otherwise
+        builds behind the first three products of a handle, so that the next product runs the steady-state kernels."""
+        from ._checks import _check_return_value
+        _check_return_value(MI.call("mi_sparse_optimize", self.handle.ptr), "mi_sparse_optimize")
+        return self
+
     def free(self):
         if self._handle is not None:
             self._handle.destroy()
@@ -272,6 +281,7 @@ class DeviceMatrix:
             self.shape[0], self.shape[1], self.dtype, self.nnz)
 
 
-def to_device(matrix):
-    """Upload a scipy sparse matrix once; see DeviceMatrix."""
-    return DeviceMatrix(matrix)
+def to_device(matrix, optimize=False):
+    """Upload a scipy sparse matrix once; see DeviceMatrix.  optimize=True runs the inspector stage at once (the
+    mkl_sparse_optimize analogue): the first product already takes the steady-state kernels."""
+    return DeviceMatrix(matrix, optimize=optimize)

@@ -134,6 +134,7 @@ def _bind(lib):
         add("mi_cblas_%sgemm" % t, [_int, _int, _int, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64])
     add("mi_sparse_destroy", [H])
     add("mi_sparse_order", [H])
+    add("mi_sparse_optimize", [H])
     add("mi_sparse_convert_csr", [H, _int, HP])
     add("mi_sparse_spmm", [_int, H, H, HP])
     add("mi_sparse_spmm_ordered", [_int, H, H, HP])
@@ -154,6 +155,7 @@ def _bind(lib):
     add("mi_sparse_last_error", [], _ct.c_char_p)
     add("mi_sparse_set_option", [_ct.c_char_p, _i64])
     add("mi_sparse_get_counter", [_ct.c_char_p, _ct.POINTER(_ct.c_double)])
+    add("mi_sparse_probe_copy", [_i64, _int, _ct.POINTER(_ct.c_double)])
     add("mi_sparse_get_last_kernel", [_ct.c_char_p, _int])
     return table
 

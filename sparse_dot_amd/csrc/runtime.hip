@@ -707,6 +707,30 @@ int64_t exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t n)
 // ================================================================================================
 // service entry points
 // ================================================================================================
+// The device's copy rate as THIS library can reach it: the "measured HBM roofline" the fractions in bench.py are quoted
+// against.  Every lane moves 16 bytes per access (the guide's float4 copy: 6.29 TB/s of the 8 TB/s spec), UNROLL independent
+// accesses in flight per lane, non-temporal both ways, a grid of a few workgroups per CU striding over the buffer.
+namespace mi {
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(256) k_probe_copy(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+}  // namespace mi
+
+
 extern "C" {
 
 mi_sparse_status_t mi_sparse_get_version_string(char* buf, int len)
@@ -914,6 +938,52 @@ mi_sparse_status_t mi_sparse_get_last_kernel(char* buf, int len)
     return mi::guarded([&] {
         if (!buf || len <= 0) mi::fail(MI_SPARSE_STATUS_NOT_INITIALIZED, "NULL buffer");
         snprintf(buf, (size_t)len, "%s", mi::last_kernel_name());
+    });
+}
+
+mi_sparse_status_t mi_sparse_probe_copy(int64_t bytes, int reps, double* best_gbs)
+{
+    return mi::guarded([&] {
+        if (!best_gbs || bytes < (1 << 20) || reps < 1) mi::fail(MI_SPARSE_STATUS_INVALID_VALUE, "probe_copy: bytes >= 1 MiB, reps >= 1, non-NULL result");
+        mi::Context& c = mi::ctx();
+        c.ensure();
+        mi::DevBuf a, b;
+        const size_t n16 = (size_t)bytes / 16;
+        a.alloc(n16 * 16);
+        b.alloc(n16 * 16);
+        MI_HIP_CHECK(hipMemsetAsync(a.p, 1, n16 * 16, c.stream));
+        MI_HIP_CHECK(hipMemsetAsync(b.p, 2, n16 * 16, c.stream));
+        hipEvent_t e0, e1;
+        MI_HIP_CHECK(hipEventCreate(&e0));
+        MI_HIP_CHECK(hipEventCreate(&e1));
+        double best = 0.0;
+        // variants: (workgroups per CU, unroll, non-temporal); the best one is the machine's rate
+        const int wg_per_cu[] = {4, 8, 16, 32};
+        for (int variant = 0; variant < 16; ++variant) {
+            const int wpc = wg_per_cu[variant & 3];
+            const bool nt = (variant & 4) != 0;
+            const bool deep = (variant & 8) != 0;
+            const unsigned grid = (unsigned)(c.cus * wpc);
+            for (int r = 0; r < reps + 1; ++r) {
+                MI_HIP_CHECK(hipEventRecord(e0, c.stream));
+                if (deep) {
+                    if (nt) mi::k_probe_copy<8, true><<<grid, 256, 0, c.stream>>>((const mi::u32x4*)a.p, (mi::u32x4*)b.p, n16);
+                    else mi::k_probe_copy<8, false><<<grid, 256, 0, c.stream>>>((const mi::u32x4*)a.p, (mi::u32x4*)b.p, n16);
+                } else {
+                    if (nt) mi::k_probe_copy<4, true><<<grid, 256, 0, c.stream>>>((const mi::u32x4*)a.p, (mi::u32x4*)b.p, n16);
+                    else mi::k_probe_copy<4, false><<<grid, 256, 0, c.stream>>>((const mi::u32x4*)a.p, (mi::u32x4*)b.p, n16);
+                }
+                MI_HIP_CHECK(hipEventRecord(e1, c.stream));
+                MI_HIP_CHECK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                MI_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (r && ms > 0.f) best = std::max(best, 2.0 * (double)(n16 * 16) / ((double)ms * 1e6));
+            }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        MI_HIP_CHECK(hipGetLastError());
+        *best_gbs = best;
     });
 }
 

@@ -1525,6 +1525,30 @@ static inline cdouble cv(mi_complex16 x) { return cdouble{x.real, x.imag}; }
 
 extern "C" {
 
+/* The inspector stage (the analogue of mkl_sparse_optimize, which the reference never calls: it creates a handle per product,
+ * _common.py:245-293): everything the library would otherwise learn about A over its first three products as a left
+ * operand, done now -- the row partition and fix-up schedule, and for matrices with long rows the column-partitioned
+ * form (SpmmKpart).  The next product runs the steady-state kernels.  Optional: products are correct without it. */
+mi_sparse_status_t mi_sparse_optimize(mi_sparse_matrix_t A)
+{
+    return mi::guarded([&] {
+        mi_sparse_matrix* h = mi::check_handle(A);
+        mi::Context& c = mi::ctx();
+        c.scratch_reset();
+        const mi::Options& o = mi::options();
+        mi::Csr& m = mi::need_csr(h);
+        {
+            std::lock_guard<std::mutex> lk(h->mtx);
+            mi::SpmmPlan& p = h->plan;
+            if (p.uses < 2) p.uses = 2;  // reuse is declared, not observed: the hot / cold analysis follows the next product
+            if (o.spmm_kpart != 0 && !o.deterministic && !o.spmm_force_generic && p.kpart_state == 0 &&
+                (o.spmm_kpart == 2 || m.nnz >= ((int64_t)1 << 21)))
+                mi::build_kpart(p, m, h->vtype);
+        }
+        c.sync();
+    });
+}
+
 mi_sparse_status_t mi_sparse_s_mm(int op, float alpha, mi_sparse_matrix_t A, struct mi_matrix_descr descr, int layout,
                                   const float* B, int64_t columns, int64_t ldb, float beta, float* C, int64_t ldc)
 {

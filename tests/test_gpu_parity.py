@@ -338,6 +338,70 @@ def test_sharded_dot_product_rccl_single_rank(gpu, oracle):
         gpu.mi_set_stream(0)
 
 
+def test_rccl_single_rank_every_collective_path(gpu, oracle):
+    """Every RCCL code path of sparse_dot_amd.distributed on the one GPU available here (degenerate groups of one rank), so
+    that the first 8-GPU run is not also the first execution of that code on the nccl backend: ShardedCSR.dot with the three
+    all-gatherv forms and both broadcast forms, the panel pipeline with its second process group for the gathers, the sparse
+    x sparse product (broadcast of B's CSR arrays, gather of indices / values) and the gram matrix by output bands."""
+    torch = pytest.importorskip("torch")
+    import os
+    import socket
+    import torch.distributed as dist
+    from sparse_dot_amd import distributed as D
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        a = pos_csr(1100, 640, 0.03, np.float32, 61)
+        b = dense((640, 128), np.float32, 62)
+        want = oracle.spmm(a.astype(np.float64), b.astype(np.float64))
+        bounds = D.partition_rows(a.indptr, 1)
+        g2 = dist.new_group([0])  # the gathers' own communicator (bench.py --gpus N does the same)
+        with D.ShardedCSR(a, bounds) as sh:
+            bt = torch.from_numpy(b).to(dev)
+            for gmode in ("bcast", "padded", "p2p"):
+                for bmode in ("bcast", "scatter_allgather"):
+                    got = sh.dot(bt.clone(), src=0, gather_mode=gmode, bcast_mode=bmode)
+                    torch.cuda.synchronize()
+                    assert rel_err(got.cpu().numpy(), want) <= F32_TOL, (gmode, bmode)
+            # collectives called directly on device tensors
+            full = torch.from_numpy(want.astype(np.float32)).to(dev)
+            D.gather_rows_p2p(full, bounds).wait()
+            D.broadcast_rows(full, 0, None, "scatter_allgather").wait()
+            w = dist.broadcast(full, src=0, async_op=True)
+            w.wait()
+            torch.cuda.synchronize()
+            assert rel_err(full.cpu().numpy(), want) <= F32_TOL
+            # panel pipeline: 4 panels of 32 columns
+            bp = torch.from_numpy(np.ascontiguousarray(b.reshape(640, 4, 32).transpose(1, 0, 2))).to(dev)
+            cp = sh.dot_pipelined(bp, src=0, gather_group=g2, depth=2)
+            torch.cuda.synchronize()
+            got = cp.permute(1, 0, 2).reshape(1100, 128).cpu().numpy()
+            assert rel_err(got, want) <= F32_TOL
+        # sparse x sparse and gram through the same backend
+        a64 = pos_csr(700, 500, 0.02, np.float64, 63)
+        b64 = pos_csr(500, 900, 0.02, np.float64, 64)
+        c = D.sharded_sparse_dot_product(a64, b64, [700], src=0)
+        ref = (a64 @ b64).tocsr()
+        ref.sort_indices()
+        c.sort_indices()
+        assert np.array_equal(c.indptr, ref.indptr) and np.array_equal(c.indices, ref.indices) and rel_err(c.data, ref.data) <= F64_TOL
+        x = pos_csr(900, 300, 0.05, np.float64, 65)
+        gm = D.sharded_gram_matrix(x)
+        assert rel_err(np.triu(gm), np.triu((x.T @ x).toarray())) <= F64_TOL
+    finally:
+        dist.destroy_process_group()
+        gpu.mi_set_stream(0)
+
+
 def test_concurrent_host_threads(gpu, oracle):
     """ctypes releases the GIL, so products may be issued from several Python threads at once
     (Threading): per-thread context / scratch, handles are independent."""

@@ -221,3 +221,24 @@ def test_spmm_randomised_shapes_row_owned_and_partitioned(gpu, oracle, seed):
         assert got.shape == (m, n) and rel_err(got, want) <= tol(dtype), (opts, rel_err(got, want))
         if got2 is not None:
             np.testing.assert_allclose(got2, want + beta * c0.astype(wide(dtype)), rtol=20 * tol(dtype), atol=20 * tol(dtype))
+
+
+def test_optimize_builds_the_partitioned_plan_up_front(gpu, oracle):
+    """mi_sparse_optimize / to_device(a, optimize=True) -- the mkl_sparse_optimize analogue: the FIRST product of the handle
+    already runs the column-partitioned kernels (without it: the third); same result as the row-owned product to tolerance,
+    same bits on every later call; harmless on a matrix without long rows."""
+    a = skewed_csr(3000, 20000, np.float32, 19, max_len=40)
+    b = dense((20000, 128), np.float32, 20)
+    want = oracle.spmm(a.astype(np.float64), b.astype(np.float64))
+    with kpart_forced(gpu, 16, 8):
+        A = gpu.to_device(a, optimize=True)
+        got = gpu.dot_product_mkl(A, b)
+        assert gpu.mi_get_counter("spmm_last_kpart") == 8.0
+        again = gpu.dot_product_mkl(A, b)
+        A.free()
+    assert rel_err(got, want) <= F32_TOL and np.array_equal(got, again)
+    u = sps.random(500, 400, density=0.01, format="csr", dtype=np.float64, random_state=3)
+    U = gpu.to_device(u).optimize()
+    x = dense((400, 8), np.float64, 4)
+    assert rel_err(gpu.dot_product_mkl(U, x), oracle.spmm(u, x)) <= 1e-12
+    U.free()

@@ -8,6 +8,8 @@ parity checks (the oracle would take minutes to hours at these sizes).
     python tools/bench_ops.py gram   [--rows-log2 20 --cols 16384 --per-row 64 --dense]
     python tools/bench_ops.py bsr    [--rows-log2 18 --block 4 --ncols 128]   BSR x dense: block kernel vs CSR expansion
     python tools/bench_ops.py sp2m   [--scale 20 --per-row 16]                staged product: full vs numeric-only re-run
+    python tools/bench_ops.py spmv | syrk | spmmd  [--reps n]                  the workloads of bench.py's secondaries spmv / gram_sparse /
+                                                                              spmmd, `reps` calls after one warm-up (counter passes)
 
 Prints one JSON line per run.
 SpGEMM checks:  C 1 == A (B 1)   (row sums, via SpMV on the same library, fp64 1e-12 rel);
@@ -27,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("op", choices=["spgemm", "gram", "bsr", "sp2m"])
+    ap.add_argument("op", choices=["spgemm", "gram", "bsr", "sp2m", "spmv", "syrk", "spmmd"])
     ap.add_argument("--block", type=int, default=4, help="bsr: block size")
     ap.add_argument("--ncols", type=int, default=128, help="bsr: dense columns")
     ap.add_argument("--scale", type=int, default=20)
@@ -96,6 +98,44 @@ def main():
                                     y.data_ptr()), "mv")
 
     out = {"op": args.op}
+    if args.op in ("spmv", "syrk", "spmmd"):
+        # bench.py's secondaries of the same names, repeated for the counter passes (bench.attach_traffic)
+        abi = bench.Abi()
+        if args.op == "spmv":
+            ip, idx, val, n = bench.rmat_csr(torch, 20, 32, 7, dev)
+            h = abi.create("s", ip, idx, val, n, n)
+            x = torch.rand(n, device=dev, dtype=torch.float32)
+            y = torch.empty(n, device=dev, dtype=torch.float32)
+            for _ in range(args.reps + 1):
+                abi.mv("s", h, x, y)
+            torch.cuda.synchronize()
+            abi.destroy(h)
+        elif args.op == "syrk":
+            m_, c_ = 1 << 20, 1 << 18
+            u = bench.uniform_csr(torch, m_, 16, 5, dev, ncols=c_)
+            uv = u[2].double()
+            hu = abi.create("d", u[0], u[1], uv, m_, c_)
+            for _ in range(args.reps + 1):
+                hc = abi.handle_t()
+                abi.check(MI.call("mi_sparse_syrk", 11, hu, ct.byref(hc)), "syrk")
+                torch.cuda.synchronize()
+                abi.destroy(hc)
+            abi.destroy(hu)
+        else:
+            n = 1 << 14
+            a = bench.uniform_csr(torch, n, 32, 11, dev)
+            b = bench.uniform_csr(torch, n, 32, 12, dev)
+            av, bv = a[2].double(), b[2].double()
+            ha, hb = abi.create("d", a[0], a[1], av, n, n), abi.create("d", b[0], b[1], bv, n, n)
+            C = torch.empty((n, n), device=dev, dtype=torch.float64)
+            for _ in range(args.reps + 1):
+                abi.check(MI.call("mi_sparse_d_spmmd", 10, ha, hb, 101, C.data_ptr(), n), "spmmd")
+            torch.cuda.synchronize()
+            abi.destroy(ha)
+            abi.destroy(hb)
+        out["calls"] = args.reps + 1
+        print(json.dumps(out), flush=True)
+        return
     if args.op == "bsr":
         # BSR x dense: 2^rows_log2 block rows, 8 random blocks per block row, bs x bs blocks, fp32,
         # row-major dense N columns.  The SAME handle through the block kernel (k_bsr_spmm) and through its CSR expansion.
