@@ -1412,7 +1412,7 @@ def main():
         except Exception:  # noqa: BLE001
             copy_gbs = torch_copy
         roofline["measured_copy_GBps"] = round(copy_gbs, 1)
-        roofline["measured_copy_note"] = ("best of the library's tuned copy kernel (mi_sparse_probe_copy: 2 GiB buffers, 16 variants, hipEvents) "
+        roofline["measured_copy_note"] = ("best of the library's tuned copy kernel (mi_sparse_probe_copy: 2 GiB buffers, 10 variants, hipEvents) "
                                           "and torch's tensor copy (%.0f GB/s); read + write bytes per second; the guide quotes 6.29 TB/s "
                                           "for a float4 copy" % torch_copy)
         roofline["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)
@@ -1595,7 +1595,7 @@ def main():
                                     ("gram_sparse", ["syrk", "--reps", "2"], ("mi::",)),
                                     ("spmmd", ["spmmd", "--reps", "2"], ("k_spmmd", "k_fill_dense"))):
                 if isinstance(secondary.get(key), dict) and "error" not in secondary[key]:
-                    exc = () if key == "spmv" else ("k_spmv", "k_spmm", "k_check_", "k_widen_ptr", "k_count_descents", "k_count_start_descents")
+                    exc = () if key in ("spmv", "spmmd") else ("k_spmv", "k_spmm", "k_check_", "k_widen_ptr", "k_count_descents", "k_count_start_descents")
                     attach_traffic(secondary[key], child, int(child[-1]) + 1, inc, True, exclude=exc, need_free_bytes=8 << 30)
         if "gemm" in want_sec:
             try:
