@@ -522,7 +522,7 @@ constexpr int SORT_RANGE_WORDS = 4096;  // bitmap words: spans of up to 131 072 
 template <typename V, int IPT>
 __global__ void __launch_bounds__(256)
     k_sort_ranges(const int64_t* __restrict__ ptr, int32_t* col, const int64_t* __restrict__ rows, const int64_t* __restrict__ item_off,
-                  int64_t n_rows, int64_t n_items, int64_t cap, int64_t npad, const V* __restrict__ vin, V* __restrict__ vout,
+                  int64_t n_rows, int64_t n_items, int64_t cap, int64_t npad, const V* vin, V* vout,  // (may be the same array: sorted in place)
                   unsigned long long* work_counter)
 {
     MI_DYN_SMEM(smem);
@@ -865,6 +865,9 @@ void sort_csr(char vtype, Csr& a)
     // limit and made every ordered product pay the driver's allocation of recycled memory (2.2 s per call).
     const int64_t sorted_min = a.sorted_min_len > SORT_SMALL_MAX ? a.sorted_min_len : 0;
     const int64_t ranged_thr = (a.range_cap > 0 && a.range_cap <= 4096 && options().sort_ranges && a.range_min_len > SORT_SMALL_MAX) ? a.range_min_len : 0;
+    // (the two layouts are exclusive: a result is either accumulated by rank or written range by range -- were both set, the copy-back of
+    // the short rows would have to use the smaller of the two thresholds)
+    if (sorted_min > 0 && ranged_thr > 0) fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "sort_csr: a result cannot be both rank-ordered and range-written");
     const int64_t partial_thr = sorted_min > 0 ? sorted_min : ranged_thr;  // rows of more entries keep their values in place
     DevBuf fresh;
     void* vout_raw;
@@ -1021,16 +1024,23 @@ static void transpose_radix(char vtype, const Csr& in, Csr& out)
     void* val_t[2] = {nullptr, nullptr};
     const int ntmp = passes > 2 ? 2 : passes - 1;
     const int64_t hist_len = ((int64_t)1 << bits) * ntiles;
-    c.scratch_reserve(sizeof(int32_t) * (size_t)n * 3 + (sizeof(int32_t) + vb) * (size_t)n * (size_t)ntmp +
-                      sizeof(int64_t) * 2 * (size_t)(hist_len + 1) + sizeof(int64_t) * (size_t)(hist_len / 1024 + 64) + 16 * 256);
+    // The entry-sized temporaries -- 12 n + (4 + vb) n ntmp bytes, 9.7 GB for the 2.7e8-entry fp64 case -- come from the block
+    // cache and go back to it when the transpose is done (in the grow-only per-thread scratch arena one large
+    // transpose pinned that many bytes for the life of the thread, out of the cache's reach); the arena keeps the histograms.
+    DevBuf key_b[2], row_b[2], val_b[2], rowidx_b;
+    c.scratch_reserve(sizeof(int64_t) * 2 * (size_t)(hist_len + 1) + sizeof(int64_t) * (size_t)(hist_len / 1024 + 64) + 16 * 256);
     for (int k = 0; k < 2; ++k) {
-        key_t[k] = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)n));  // the final keys too (row pointer)
+        key_b[k].alloc(sizeof(int32_t) * (size_t)n);  // the final keys too (row pointer)
+        key_t[k] = key_b[k].as<int32_t>();
         if (k < ntmp) {
-            row_t[k] = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)n));
-            val_t[k] = c.scratch_alloc(vb * (size_t)n);
+            row_b[k].alloc(sizeof(int32_t) * (size_t)n);
+            val_b[k].alloc(vb * (size_t)n);
+            row_t[k] = row_b[k].as<int32_t>();
+            val_t[k] = val_b[k].p;
         }
     }
-    int32_t* rowidx = static_cast<int32_t*>(c.scratch_alloc(sizeof(int32_t) * (size_t)n));
+    rowidx_b.alloc(sizeof(int32_t) * (size_t)n);
+    int32_t* rowidx = rowidx_b.as<int32_t>();
     MI_LAUNCH(k_expand_rows, grid1d(in.rows * WAVE, 256), dim3(256), c.stream, (const int64_t*)in.ptr, in.rows, rowidx);
     const int64_t hist_n = ((int64_t)1 << bits) * ntiles;
     int64_t* hist = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(hist_n + 1)));
@@ -1065,6 +1075,7 @@ static void transpose_radix(char vtype, const Csr& in, Csr& out)
         vin = vout;
     }
     MI_LAUNCH(k_ptr_from_sorted, grid1d_stride(n + 1, 256), dim3(256), c.stream, kin, n, in.cols, out.ptr);
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // the temporaries go back to the cache: nothing may still read them
 }
 
 void transpose_csr(char vtype, const Csr& in, Csr& out, bool conj)
