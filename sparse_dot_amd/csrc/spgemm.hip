@@ -21,11 +21,12 @@ namespace mi {
 
 constexpr int32_t HASH_EMPTY = -1;
 
-// how a numeric kernel writes a column index of C: key + base, or map[key] (the product ran on a relabelled copy of B)
+// how a numeric kernel writes a column index of C: key + base (B is a column panel of a wider matrix, spgemm_panels).
+// (Round 6 also carried an optional relabelling map here for the hub path: the `map ? map[key] : key + base` in every write-out
+// cost the uniform configs[2] 13 % -- 2.87 -> 3.25 ms -- with the map unused; the hub path maps its columns back in a pass of its own.)
 struct ColOut {
     int32_t base = 0;
-    const int32_t* map = nullptr;
-    __device__ __forceinline__ int32_t operator()(int32_t key) const { return map ? map[key] : key + base; }
+    __device__ __forceinline__ int32_t operator()(int32_t key) const { return key + base; }
 };
 
 __device__ __forceinline__ uint32_t hash_col(int32_t c, int log2s)
@@ -2262,7 +2263,7 @@ struct BigRows {
     DevBuf bounds;             // int32: range starts, P_max = ceil(min(ub, cols) / cap) slots per big row
     DevBuf ext0, extlen;       // per nonzero of A: first counted entry of B's row (int64) and their number (int32) -- k_row_ub
     bool grp = false;          // every row of B has <= 32 entries: the LDS bins up to 512 products run k_spgemm_grp
-    ColOut col_base;           // numeric phase: how a column index is written -- plus a constant (B is a column panel of a wider matrix, spgemm_panels) or through a map (hub path: B was relabelled)
+    ColOut col_base;           // numeric phase: added to every column index written (B is a column panel of a wider matrix, spgemm_panels)
     const int32_t* cfloor = nullptr;  // hub path: per row of A, the first (relabelled) column the range path owns -- the dense blocks left of it are accumulated by k_hub_num
     // upper-triangle product of a column panel: the extents (ext0 / extlen) are cut at the diagonal shifted by the panel's first
     // column and the kernels that read them run as a full product; the two kernels that cut rows of B into column ranges from
@@ -3156,13 +3157,14 @@ static bool spgemm_hub(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, S
             trace_mark("relabelled copy of B", t_last);
             st.big.b_sorted = true;
             st.b_gen = Bs.order_gen;
-            st.big.col_base.map = h->inv.as<int32_t>();
             st.big.want_rank = false;
             spgemm_symbolic<T>(A, Bs, C, st, bd);
             spgemm_numeric<T>(A, Bs, C, st, &bd);
+            if (C.nnz > 0)  // the whole result is in relabelled columns
+                MI_LAUNCH(k_hub_unmap, dim3((unsigned)std::min<int64_t>(ceil_div(C.rows, 4), (int64_t)1 << 20)), dim3(256), c.stream, C.rows,
+                          (const int64_t*)C.ptr, (const int64_t*)nullptr, (const int32_t*)h->inv.as<int32_t>(), C.col);
             C.range_cap = 0;
             c.sync();
-            st.big.col_base.map = nullptr;
             return true;
         }
         const int nbd = (int)tmin.size();
@@ -3300,16 +3302,17 @@ static bool spgemm_hub(const Csr& A, const Csr& B, Csr& C, SpgemmSymbolic& st, S
     st.big.b_sorted = true;
     st.b_gen = h->Bs.order_gen;  // the extents were laid out for the relabelled copy (spgemm_numeric would rebuild them -- whole rows -- for an operand whose entries moved)
     st.big.cfloor = h->cfloor.as<int32_t>();
-    st.big.col_base.map = h->inv.as<int32_t>();
     st.big.want_rank = false;
     st.upper_mode = 0;
     spgemm_symbolic<T>(A, h->Bs, C, st, bd, h.get());
     if (!st.big.have_bounds && bd.max_ub > hub_min)
         fail(MI_SPARSE_STATUS_INTERNAL_ERROR, "hub path: the range path recorded no range starts");
     spgemm_numeric<T>(A, h->Bs, C, st, &bd, h.get());
+    if (C.nnz > 0)  // the range-path part of every row (its first row_nnz entries) is in relabelled columns: map it back
+        MI_LAUNCH(k_hub_unmap, dim3((unsigned)std::min<int64_t>(ceil_div(C.rows, 4), (int64_t)1 << 20)), dim3(256), c.stream, C.rows,
+                  (const int64_t*)C.ptr, (const int64_t*)st.row_nnz.as<int64_t>(), (const int32_t*)h->inv.as<int32_t>(), C.col);
     c.sync();  // the relabelled copies are released on return
     st.big.cfloor = nullptr;
-    st.big.col_base.map = nullptr;
     counters().spgemm_hub_items += (double)h->n_items;
     return true;
 }
