@@ -3425,16 +3425,134 @@ __global__ void __launch_bounds__(256)
 struct SpgemmPanel {
     Csr B, Cp;  // the panel of B (columns rebased); Cp: the panel's own row pointer / entry count (no arrays)
     SpgemmSymbolic st;
+    int64_t col0 = 0;  // first column of the panel in B
 };
+
+// The panels of one product: built by panels_symbolic, consumed (any number of times: the staged API) by panels_numeric.
+struct PanelSet {
+    std::vector<std::unique_ptr<SpgemmPanel>> panels;  // the panels that contribute entries, ascending
+    int64_t np = 0;                                    // panels B was cut into
+    bool upper = false;
+    int64_t a_nnz = 0, b_nnz = 0;
+};
+
+// Symbolic phase of every panel of Bp (rows in column order): row pointer and entry count of C.  Throws ALLOC_FAILED when the
+// panels' copies of B do not fit (the caller falls back).
+template <typename T>
+static void panels_symbolic(const Csr& A, const Csr& Bp, bool upper, Csr& C, PanelSet& ps)
+{
+    Context& c = ctx();
+    auto t_last = std::chrono::steady_clock::now();
+    ps.np = ceil_div(Bp.cols, PANEL_COLS);
+    ps.upper = upper;
+    ps.a_nnz = A.nnz;
+    ps.b_nnz = Bp.nnz;
+    ps.panels.clear();
+    DevBuf lo_b, len_b;
+    lo_b.alloc(sizeof(int64_t) * (size_t)(Bp.rows + 1));
+    len_b.alloc(sizeof(int64_t) * (size_t)(std::max(Bp.rows, A.rows) + 1));
+    const unsigned rgrid = (unsigned)ceil_div(Bp.rows, 256);
+    for (int64_t q = 0; q < ps.np; ++q) {
+        auto pn = std::make_unique<SpgemmPanel>();
+        pn->col0 = q * PANEL_COLS;
+        Csr& Bq = pn->B;
+        Bq.rows = Bp.rows;
+        Bq.cols = std::min(PANEL_COLS, Bp.cols - q * PANEL_COLS);
+        Bq.ptr_own.alloc(sizeof(int64_t) * (size_t)(Bp.rows + 1));
+        Bq.ptr = Bq.ptr_own.as<int64_t>();
+        MI_LAUNCH(k_panel_extent, dim3(rgrid), dim3(256), c.stream, Bp.rows, (const int64_t*)Bp.ptr, (const int32_t*)Bp.col,
+                  q * PANEL_COLS, q * PANEL_COLS + Bq.cols, lo_b.as<int64_t>(), len_b.as<int64_t>());
+        Bq.nnz = exclusive_scan_i64(len_b.as<int64_t>(), Bq.ptr, Bp.rows);
+        if (Bq.nnz == 0) continue;
+        Bq.col_own.alloc(sizeof(int32_t) * (size_t)Bq.nnz);
+        Bq.val_own.alloc(sizeof(T) * (size_t)Bq.nnz);
+        Bq.col = Bq.col_own.as<int32_t>();
+        Bq.val = Bq.val_own.p;
+        MI_LAUNCH((k_panel_fill<T>), dim3((unsigned)ceil_div(Bp.rows * WAVE, 256)), dim3(256), c.stream, Bp.rows,
+                  (const int64_t*)lo_b.as<int64_t>(), (const int64_t*)Bq.ptr, (const int32_t*)Bp.col, (const T*)Bp.val,
+                  (int32_t)(q * PANEL_COLS), Bq.col, static_cast<T*>(Bq.val));
+        Bq.valid = true;
+        cache_set(Bq.sorted, true);
+        Bq.order_gen = next_order_gen();
+        SpgemmBounds bdq = spgemm_bounds<T>(A, Bq, upper, pn->Cp, pn->st, q * PANEL_COLS);
+        spgemm_symbolic<T>(A, Bq, pn->Cp, pn->st, bdq);
+        if (pn->Cp.nnz == 0) continue;
+        ps.panels.push_back(std::move(pn));
+    }
+    trace_mark("panels: symbolic", t_last);
+    int64_t* len = len_b.as<int64_t>();
+    MI_HIP_CHECK(hipMemsetAsync(len, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
+    const unsigned agrid = (unsigned)ceil_div(A.rows, 256);
+    for (auto& pn : ps.panels) MI_LAUNCH(k_panel_add_len, dim3(agrid), dim3(256), c.stream, A.rows, (const int64_t*)pn->Cp.ptr, len);
+    C.rows = A.rows;
+    C.cols = Bp.cols;
+    C.ptr_own.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
+    C.ptr = C.ptr_own.as<int64_t>();
+    C.nnz = exclusive_scan_i64(len, C.ptr, A.rows);
+    C.col = nullptr;
+    C.val = nullptr;
+    C.valid = false;
+    MI_HIP_CHECK(hipStreamSynchronize(c.stream));  // lo_b / len_b go
+}
+
+// Numeric phase of every panel, straight into its pieces of the rows of C (cursor[i] = where row i continues).  `refill`: copy
+// the panels' values out of Bp again first (the staged API: B's values may have changed since the symbolic phase).
+template <typename T>
+static void panels_numeric(const Csr& A, const Csr& Bp, Csr& C, PanelSet& ps, bool refill)
+{
+    Context& c = ctx();
+    auto t_last = std::chrono::steady_clock::now();
+    if (A.nnz != ps.a_nnz || Bp.nnz != ps.b_nnz)
+        fail(MI_SPARSE_STATUS_INVALID_VALUE, "operand structure changed since the symbolic phase (nnz %lld x %lld, was %lld x %lld)",
+             (long long)A.nnz, (long long)Bp.nnz, (long long)ps.a_nnz, (long long)ps.b_nnz);
+    if (!C.col_own.p || C.col_own.bytes < sizeof(int32_t) * (size_t)std::max<int64_t>(C.nnz, 1)) C.col_own.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(C.nnz, 1));
+    if (!C.val_own.p || C.val_own.bytes < sizeof(T) * (size_t)std::max<int64_t>(C.nnz, 1)) C.val_own.alloc(sizeof(T) * (size_t)std::max<int64_t>(C.nnz, 1));
+    C.col = C.col_own.as<int32_t>();
+    C.val = C.val_own.p;
+    int64_t* cursor = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
+    MI_HIP_CHECK(hipMemcpyAsync(cursor, C.ptr, sizeof(int64_t) * (size_t)A.rows, hipMemcpyDeviceToDevice, c.stream));
+    const unsigned agrid = (unsigned)ceil_div(A.rows, 256);
+    int64_t* lo = nullptr;
+    int64_t* len_tmp = nullptr;
+    if (refill) {
+        lo = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(Bp.rows + 1)));
+        len_tmp = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(Bp.rows + 1)));
+    }
+    for (auto& up : ps.panels) {
+        SpgemmPanel& pn = *up;
+        if (refill) {
+            MI_LAUNCH(k_panel_extent, dim3((unsigned)ceil_div(Bp.rows, 256)), dim3(256), c.stream, Bp.rows, (const int64_t*)Bp.ptr,
+                      (const int32_t*)Bp.col, pn.col0, pn.col0 + pn.B.cols, lo, len_tmp);
+            MI_LAUNCH((k_panel_fill<T>), dim3((unsigned)ceil_div(Bp.rows * WAVE, 256)), dim3(256), c.stream, Bp.rows, (const int64_t*)lo,
+                      (const int64_t*)pn.B.ptr, (const int32_t*)Bp.col, (const T*)Bp.val, (int32_t)pn.col0, pn.B.col, static_cast<T*>(pn.B.val));
+        }
+        if (A.order_gen != pn.st.a_gen) {
+            // A's entries moved since the symbolic phase (mi_sparse_order between the stages): the per-entry extents follow its storage order
+            int64_t* ub = static_cast<int64_t*>(c.scratch_alloc(sizeof(int64_t) * (size_t)(A.rows + 1)));
+            launch_row_ub(A, pn.B, pn.st.big.panel_upper ? 2 : pn.st.upper_mode, ub, pn.st.big.ext0.as<int64_t>(), pn.st.big.extlen.as<int32_t>(),
+                          pn.st.big.panel_upper ? (int64_t)pn.st.big.diag_shift : 0);
+            pn.st.a_gen = A.order_gen;
+        }
+        const RowStats rs = device_row_stats(pn.st.row_nnz.as<int64_t>(), A.rows);
+        pn.st.big.col_base.base = (int32_t)pn.col0;  // the numeric kernels write the panel's columns at their place in B
+        run_phase<T, true>(A, pn.B, pn.st.upper_mode, pn.st.row_nnz.as<int64_t>(), rs, nullptr, cursor, C.col, static_cast<T*>(C.val),
+                           pn.st.big);
+        MI_LAUNCH(k_panel_add_len, dim3(agrid), dim3(256), c.stream, A.rows, (const int64_t*)pn.Cp.ptr, cursor);
+    }
+    trace_mark("panels: numeric", t_last);
+    C.valid = true;
+    C.order_gen = next_order_gen();
+    C.sorted = false;
+    C.range_cap = 0;  // a row is the concatenation of the panels' pieces: not one sequence of full ranges
+    C.sorted_min_len = 0;
+    counters().spgemm_panels += (double)ps.np;
+}
 
 // false: not done (the panels' copies of B did not fit) -- the caller takes the global-memory path
 template <typename T>
 static bool spgemm_panels(const Csr& A, const Csr& B, bool upper, Csr& C)
 {
     Context& c = ctx();
-    auto t_last = std::chrono::steady_clock::now();
-    const int64_t np = ceil_div(B.cols, PANEL_COLS);
-    using Panel = SpgemmPanel;
     try {
         // rows of B in column order
         const Csr* Bp = &B;
@@ -3454,78 +3572,16 @@ static bool spgemm_panels(const Csr& A, const Csr& B, bool upper, Csr& C)
             sort_csr(type_char<T>::value, Bs);
             Bp = &Bs;
         }
-        std::vector<std::unique_ptr<Panel>> panels;
-        DevBuf lo_b, len_b;
-        lo_b.alloc(sizeof(int64_t) * (size_t)(B.rows + 1));
-        len_b.alloc(sizeof(int64_t) * (size_t)(std::max(B.rows, A.rows) + 1));
-        const unsigned rgrid = (unsigned)ceil_div(B.rows, 256);
-        std::vector<int64_t> base_of;
-        // symbolic phase of every panel: the row lengths of C are their sums
-        for (int64_t q = 0; q < np; ++q) {
-            auto pn = std::make_unique<Panel>();
-            Csr& Bq = pn->B;
-            Bq.rows = B.rows;
-            Bq.cols = std::min(PANEL_COLS, B.cols - q * PANEL_COLS);
-            Bq.ptr_own.alloc(sizeof(int64_t) * (size_t)(B.rows + 1));
-            Bq.ptr = Bq.ptr_own.as<int64_t>();
-            MI_LAUNCH(k_panel_extent, dim3(rgrid), dim3(256), c.stream, B.rows, (const int64_t*)Bp->ptr, (const int32_t*)Bp->col,
-                      q * PANEL_COLS, q * PANEL_COLS + Bq.cols, lo_b.as<int64_t>(), len_b.as<int64_t>());
-            Bq.nnz = exclusive_scan_i64(len_b.as<int64_t>(), Bq.ptr, B.rows);
-            if (Bq.nnz == 0) continue;
-            Bq.col_own.alloc(sizeof(int32_t) * (size_t)Bq.nnz);
-            Bq.val_own.alloc(sizeof(T) * (size_t)Bq.nnz);
-            Bq.col = Bq.col_own.as<int32_t>();
-            Bq.val = Bq.val_own.p;
-            MI_LAUNCH((k_panel_fill<T>), dim3((unsigned)ceil_div(B.rows * WAVE, 256)), dim3(256), c.stream, B.rows,
-                      (const int64_t*)lo_b.as<int64_t>(), (const int64_t*)Bq.ptr, (const int32_t*)Bp->col, (const T*)Bp->val,
-                      (int32_t)(q * PANEL_COLS), Bq.col, static_cast<T*>(Bq.val));
-            Bq.valid = true;
-            cache_set(Bq.sorted, true);
-            Bq.order_gen = next_order_gen();
-            SpgemmBounds bdq = spgemm_bounds<T>(A, Bq, upper, pn->Cp, pn->st, q * PANEL_COLS);
-            spgemm_symbolic<T>(A, Bq, pn->Cp, pn->st, bdq);
-            if (pn->Cp.nnz == 0) continue;
-            base_of.push_back(q * PANEL_COLS);
-            panels.push_back(std::move(pn));
-        }
-        trace_mark("panels: symbolic", t_last);
-        int64_t* len = len_b.as<int64_t>();
-        MI_HIP_CHECK(hipMemsetAsync(len, 0, sizeof(int64_t) * (size_t)(A.rows + 1), c.stream));
-        const unsigned agrid = (unsigned)ceil_div(A.rows, 256);
-        for (auto& pn : panels) MI_LAUNCH(k_panel_add_len, dim3(agrid), dim3(256), c.stream, A.rows, (const int64_t*)pn->Cp.ptr, len);
-        C.rows = A.rows;
-        C.cols = B.cols;
-        C.ptr_own.alloc(sizeof(int64_t) * (size_t)(A.rows + 1));
-        C.ptr = C.ptr_own.as<int64_t>();
-        C.nnz = exclusive_scan_i64(len, C.ptr, A.rows);
-        C.col_own.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(C.nnz, 1));
-        C.val_own.alloc(sizeof(T) * (size_t)std::max<int64_t>(C.nnz, 1));
-        C.col = C.col_own.as<int32_t>();
-        C.val = C.val_own.p;
-        // numeric phase of every panel, straight into its pieces of the rows of C: cursor[i] = where row i continues
-        int64_t* cursor = len;
-        MI_HIP_CHECK(hipMemcpyAsync(cursor, C.ptr, sizeof(int64_t) * (size_t)A.rows, hipMemcpyDeviceToDevice, c.stream));
-        for (size_t k = 0; k < panels.size(); ++k) {
-            Panel& pn = *panels[k];
-            const RowStats rs = device_row_stats(pn.st.row_nnz.as<int64_t>(), A.rows);
-            pn.st.big.col_base.base = (int32_t)base_of[k];  // the numeric kernels write the panel's columns at their place in B
-            run_phase<T, true>(A, pn.B, pn.st.upper_mode, pn.st.row_nnz.as<int64_t>(), rs, nullptr, cursor, C.col,
-                               static_cast<T*>(C.val), pn.st.big);
-            MI_LAUNCH(k_panel_add_len, dim3(agrid), dim3(256), c.stream, A.rows, (const int64_t*)pn.Cp.ptr, cursor);
-        }
+        PanelSet ps;
+        panels_symbolic<T>(A, *Bp, upper, C, ps);
+        panels_numeric<T>(A, *Bp, C, ps, false);
         c.sync();  // the panels are released on return
-        trace_mark("panels: numeric", t_last);
     } catch (const status_error& e) {
         if (e.status != MI_SPARSE_STATUS_ALLOC_FAILED) throw;
         clear_error();
         c.sync();
         return false;
     }
-    C.valid = true;
-    C.order_gen = next_order_gen();
-    C.sorted = false;
-    C.range_cap = 0;  // a row is the concatenation of the panels' pieces: not one sequence of full ranges
-    counters().spgemm_panels += (double)np;
     if (options().deterministic && C.nnz > 0) spgemm_values_deterministic<T>(A, B, C, upper ? 1 : 0);
     return true;
 }
@@ -3558,6 +3614,7 @@ constexpr int STAGE_FULL_MULT = 90, STAGE_NNZ_COUNT = 91, STAGE_FINALIZE_MULT = 
 
 struct Sp2mState {
     SpgemmSymbolic sym;
+    std::shared_ptr<PanelSet> panels;  // a B wider than the LDS bitmap of the big-row path: the product by column panels (round 6)
     const mi_sparse_matrix* a = nullptr;  // operands the pattern was computed for (identity check only)
     const mi_sparse_matrix* b = nullptr;
     int op_a = 0, op_b = 0;
@@ -3613,9 +3670,37 @@ static void sp2m_run(int op_a, mi_sparse_matrix* ha, int op_b, mi_sparse_matrix*
             using T = decltype(tag);
             if (starts) {  // staged: always two phases -- the pattern is kept for FINALIZE / later numeric re-runs
                 SpgemmBounds bd = spgemm_bounds<T>(a, b, upper, r->csr, st->sym);
-                spgemm_symbolic<T>(a, b, r->csr, st->sym, bd);
+                // rows beyond the LDS hash classes and a B too wide for the LDS bitmap: column panels, as the one-shot product
+                // (round 6; the global-memory hash before).  The panels hold copies of B's entries, so B's rows must be in column
+                // order already (an unsorted B keeps the global-memory hash here: a sorted copy could not follow set_values).
+                const bool wide = bd.max_ub > 4096 && options().spgemm_col_panels && !options().spgemm_force_global && b.nnz > 0 &&
+                                  b.nnz < ((int64_t)1 << 31) && bitmap_lds_bytes(b.cols) > (size_t)140 * 1024 && rows_sorted(b);
+                bool done = false;
+                if (wide) {
+                    try {
+                        auto ps = std::make_shared<PanelSet>();
+                        r->csr = Csr();
+                        panels_symbolic<T>(a, b, upper, r->csr, *ps);
+                        st->panels = ps;
+                        st->sym.done = true;
+                        done = true;
+                    } catch (const status_error& e) {
+                        if (e.status != MI_SPARSE_STATUS_ALLOC_FAILED) throw;
+                        clear_error();
+                        r->csr = Csr();
+                        bd = spgemm_bounds<T>(a, b, upper, r->csr, st->sym);
+                    }
+                }
+                if (!done) spgemm_symbolic<T>(a, b, r->csr, st->sym, bd);
             }
-            if (finishes) spgemm_numeric<T>(a, b, r->csr, st->sym);
+            if (finishes) {
+                if (st->panels) {
+                    panels_numeric<T>(a, b, r->csr, *st->panels, !starts);  // (a later stage: B's values may have been replaced)
+                    if (options().deterministic && r->csr.nnz > 0) spgemm_values_deterministic<T>(a, b, r->csr, upper ? 1 : 0);
+                } else {
+                    spgemm_numeric<T>(a, b, r->csr, st->sym);
+                }
+            }
         });
         if (finishes && !created) {
             // a numeric re-run rewrote the values of an EXISTING result in place: whatever was derived from the old values is

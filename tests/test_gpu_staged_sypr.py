@@ -196,3 +196,55 @@ def test_staged_refinalize_drops_value_copies_of_the_result(gpu):
     finally:
         gpu.mi_set_option("spmm_kpart", 1)
         gpu.mi_set_option("spmm_kpart_min_row", 64)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_staged_product_wide_b_by_column_panels(gpu, dtype):
+    """mi_sparse_sp2m with a B of 2^22 + 77 columns and hub rows in the product: the staged product takes the column panels of
+    the one-shot product (round 6; the global-memory hash before), the panels are kept on the result handle between the stages,
+    and a FINALIZE after set_values(B) refills their value copies; mi_sparse_order(A) between the stages rebuilds the per-entry
+    extents of every panel.  Oracle: scipy in fp64."""
+    import ctypes as ct
+    from sparse_dot_amd._mi_interface import MI
+    rng = np.random.default_rng(15)
+    n, k, W = (1 << 22) + 77, 2000, 1 << 20
+    cols = []
+    for r in range(k):
+        c = rng.integers(0, n, 24)
+        if r % 3 == 0:
+            c = np.concatenate([c, [W - 1, W, 2 * W - 1, 2 * W, 3 * W, 4 * W - 1, 4 * W, n - 1]])
+        cols.append(np.unique(c))
+    ptr = np.concatenate([[0], np.cumsum([c.size for c in cols])])
+    ind = np.concatenate(cols).astype(np.int32)
+    b = sps.csr_matrix((rng.uniform(0.5, 1.5, ind.size), ind, ptr), shape=(k, n)).astype(dtype)
+    a = sps.random(50, k, density=0.004, format="lil", random_state=3, dtype=np.float64)
+    a[4, rng.choice(k, 1100, replace=False)] = 0.75   # hub rows of A
+    a[31, rng.choice(k, 1800, replace=False)] = 1.5
+    a = a.tocsr()
+    a.data[:] = rng.uniform(0.5, 1.5, a.nnz)
+    a = a.astype(dtype)
+    gpu.mi_get_counter("reset")
+    with gpu.StagedProduct(a, b, reorder_output=True) as p:
+        nnz = p.count()
+        assert gpu.mi_get_counter("spgemm_panels") == 0.0  # counted by the numeric phase
+        ref = (a.astype(np.float64) @ b.astype(np.float64)).tocsr()
+        assert nnz == ref.nnz
+        _same(p.finalize(), ref, dtype)
+        assert gpu.mi_get_counter("spgemm_panels") == 5.0
+        a2, b2 = a.copy(), b.copy()
+        a2.data[:] = rng.uniform(0.5, 1.5, a.nnz).astype(dtype)
+        b2.data[:] = rng.uniform(0.5, 1.5, b.nnz).astype(dtype)
+        p.set_values(a=a2.data, b=b2.data)
+        _same(p.finalize(), a2.astype(np.float64) @ b2.astype(np.float64), dtype)
+        _same(p.full(), a2.astype(np.float64) @ b2.astype(np.float64), dtype)
+    # A with unsorted rows, ordered between the stages
+    ua = a.copy()
+    for i in range(ua.shape[0]):
+        lo, hi = ua.indptr[i], ua.indptr[i + 1]
+        o = rng.permutation(hi - lo)
+        ua.indices[lo:hi], ua.data[lo:hi] = ua.indices[lo:hi][o], ua.data[lo:hi][o]
+    ua.has_sorted_indices = False
+    with gpu.StagedProduct(ua, b, reorder_output=True) as p:
+        p.count()
+        assert MI.call("mi_sparse_order", p._ha.ptr) == 0
+        _same(p.finalize(), a.astype(np.float64) @ b.astype(np.float64), dtype)
