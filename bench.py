@@ -232,20 +232,32 @@ def cpu_baseline_gram(a, nrep=3):
                           % (a.shape[0], n, a.nnz, str(e)[:60])}
 
 
-def cpu_baseline_mkl(flops, make_call, sample, nrep=5, unit="GFLOP/s"):
-    """MKL through the build's own shim for one more entry point: `make_call(mkl)` returns (callable to time, cleanup)."""
+def cpu_baseline_mkl_child(op, operands, flops, sample, nrep=5, unit="GFLOP/s"):
+    """MKL through the build's own shim for one more entry point, timed in a CHILD process (tools/mkl_child.py): oneMKL 2021.4's
+    mkl_sparse_syrk aborted with heap corruption inside bench.py's own process (next to torch's OpenMP runtime) and ran cleanly on
+    the same operand in a process of its own; whatever happens to the child, the line survives.  operands: scipy CSR matrices."""
+    import subprocess
+    import tempfile
+    import numpy as np
     try:
-        from oracle import mkl_shim
-        mkl = mkl_shim.MklSpmm()
-        fn, cleanup = make_call(mkl)
-        t = _median(_timed(fn, nrep))
-        cleanup()
-        time.sleep(0.4)  # MKL's OpenMP threads spin for a while after a parallel region: not into the next device measurement
-        return {"value": round(flops / t / 1e9, 3), "unit": unit, "cores": mkl.threads(), "kind": "reference", "ms": round(t * 1e3, 3),
-                "sample": "%s, median of %d calls after 1 warm-up via oracle/mkl_shim.py; %s; host has %d logical cpus"
-                          % (sample, nrep, mkl.version(), os.cpu_count())}
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            paths = []
+            for k, m in enumerate(operands):
+                path = os.path.join(tmp, "m%d.npz" % k)
+                np.savez(path, data=m.data, indices=m.indices, indptr=m.indptr, shape=np.array(m.shape))
+                paths.append(path)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mkl_child.py"), op] + paths + [str(nrep)],
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        if not lines:
+            return {"value": None, "note": "%s: the MKL child died (rc %d) or libmkl_rt is unavailable" % (sample, r.returncode)}
+        d = json.loads(lines[-1])
+        time.sleep(0.4)
+        return {"value": round(flops / (d["ms"] / 1e3) / 1e9, 3), "unit": unit, "cores": d["cores"], "kind": "reference", "ms": round(d["ms"], 3),
+                "sample": "%s, median of %d calls after 1 warm-up in a child process via oracle/mkl_shim.py; %s; host has %d logical cpus"
+                          % (sample, nrep, d["version"], os.cpu_count())}
     except Exception as e:  # noqa: BLE001
-        return {"value": None, "note": "libmkl_rt unavailable or the call failed (%s)" % (str(e)[:120],)}
+        return {"value": None, "note": "%s: %s" % (sample, str(e)[:120])}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -624,12 +636,7 @@ def secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, steps,
         import numpy as np
         import scipy.sparse as sps
         ah = sps.csr_matrix((vals.cpu().numpy(), indices.cpu().numpy(), indptr.cpu().numpy()), shape=(n, n))
-        xh, yh = x.cpu().numpy(), np.zeros(n, dtype=np.float32)
-
-        def mk(mkl):
-            hh = mkl.make(ah)
-            return (lambda: mkl.mv(hh, xh, yh)), (lambda: mkl.destroy(hh))
-        out["spmv"]["cpu_baseline"] = cpu_baseline_mkl(2.0 * nnz, mk, "full workload (mkl_sparse_s_mv, %d nnz)" % nnz)
+        out["spmv"]["cpu_baseline"] = cpu_baseline_mkl_child("mv", [ah], 2.0 * nnz, "full workload (mkl_sparse_s_mv, %d nnz)" % nnz)
         del ah
     m_, c_ = 1 << 20, 1 << 18
     u = uniform_csr(torch, m_, 16, 5, dev, ncols=c_)
@@ -680,38 +687,19 @@ def secondary_spmv_gram_sparse(torch, abi, dev, indptr, indices, vals, n, steps,
     assert gram_parity <= 1e-12, "sparse gram row-sum parity check failed: %g" % gram_parity
     abi.destroy(hu)
     if with_cpu:
-        # MKL's mkl_sparse_syrk in a CHILD process: oneMKL 2021.4 aborts with heap corruption on the full 2^20 x 2^18 operand
-        # (observed on the GPU box: "corrupted size vs. prev_size" inside the call), so the full workload is tried first and a row
-        # sample (the first 2^18 rows: a quarter of the products) second; whatever happens to the child, the line survives
-        import subprocess
-        import tempfile
-        import numpy as np
+        # full workload first; a row sample (the first 2^18 rows: a quarter of the products) if MKL does not survive it
+        import scipy.sparse as sps
         up, ui, ud = u[0].cpu().numpy(), u[1].cpu().numpy(), uv.cpu().numpy()
         base = None
-        notes = []
         for rows_s, what in ((m_, "full workload"), (m_ // 4, "row sample: the first 2^18 of the 2^20 rows")):
-            with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-                e = int(up[rows_s])
-                np.savez(os.path.join(tmp, "u.npz"), data=ud[:e], indices=ui[:e], indptr=up[:rows_s + 1], shape=np.array([rows_s, c_]))
-                try:
-                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mkl_child.py"), "syrk", os.path.join(tmp, "u.npz"), "3"],
-                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
-                    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
-                except Exception as exc:  # noqa: BLE001
-                    r, lines = None, []
-                    notes.append("%s: %s" % (what, str(exc)[:80]))
-            if lines:
-                d = json.loads(lines[-1])
-                lens_s = (u[0][1:rows_s + 1] - u[0][:rows_s]).double()
-                prod_s = float((lens_s * (lens_s + 1) / 2).sum())
-                base = {"value": round(2 * prod_s / (d["ms"] / 1e3) / 1e9, 3), "unit": "GFLOP/s", "cores": d["cores"], "kind": "reference",
-                        "ms": round(d["ms"], 2),
-                        "sample": "%s (mkl_sparse_syrk, multiply only: no export), median of 3 after 1 in a child process via "
-                                  "oracle/mkl_shim.py; %s%s" % (what, d["version"], ("; " + "; ".join(notes)) if notes else "")}
+            e = int(up[rows_s])
+            us = sps.csr_matrix((ud[:e], ui[:e], up[:rows_s + 1]), shape=(rows_s, c_))
+            lens_s = (u[0][1:rows_s + 1] - u[0][:rows_s]).double()
+            prod_s = float((lens_s * (lens_s + 1) / 2).sum())
+            base = cpu_baseline_mkl_child("syrk", [us], 2 * prod_s, "%s (mkl_sparse_syrk, multiply only: no export)" % what, nrep=3)
+            if base.get("value") is not None:
                 break
-            notes.append("%s: MKL died (rc %s)" % (what, r.returncode if r is not None else "?"))
-        out["gram_sparse"]["cpu_baseline"] = base or {"value": None, "note": "; ".join(notes)}
-        time.sleep(0.4)
+        out["gram_sparse"]["cpu_baseline"] = base
     return out
 
 
@@ -768,13 +756,10 @@ def secondary_rows_f3_f4_a4(torch, abi, dev, with_cpu=True):
             ah = sps.csr_matrix((av.cpu().numpy(), a[1].cpu().numpy(), a[0].cpu().numpy()), shape=(n, n))
             bh = sps.csr_matrix((bv.cpu().numpy(), b[1].cpu().numpy(), b[0].cpu().numpy()), shape=(n, n))
             del C
-            outh = np.zeros((n, n), dtype=np.float64)
             prods = float((np.bincount(ah.indices, minlength=n).astype(np.float64) * np.diff(bh.indptr)).sum())
 
-            def mk(mkl):
-                h1, h2 = mkl.make(ah), mkl.make(bh)
-                return (lambda: mkl.spmmd(h1, h2, outh)), (lambda: (mkl.destroy(h1), mkl.destroy(h2)))
-            out["spmmd"]["cpu_baseline"] = cpu_baseline_mkl(2 * prods, mk, "full workload (mkl_sparse_d_spmmd into a preallocated 2 GiB array)", nrep=3)
+            out["spmmd"]["cpu_baseline"] = cpu_baseline_mkl_child("spmmd", [ah, bh], 2 * prods,
+                                                                   "full workload (mkl_sparse_d_spmmd into a preallocated 2 GiB array)", nrep=3)
             out["spmmd"]["value"] = round(2 * prods / t / 1e9, 2)
             out["spmmd"]["unit"] = "GFLOP/s"
     except Exception as exc:  # noqa: BLE001
