@@ -119,6 +119,10 @@ def test_signatures_match_the_reference(sda):
         ("matrix", inspect._empty), ("transpose", False), ("cast", False), ("dense", False), ("debug", False),
         ("reorder_output", False), ("out", None), ("out_scalar", None)]
     assert sda.dot_product_transpose_mkl is sda.gram_matrix_mkl
+    # the resident-handle additions (no analogue in the reference): the inspector stage is opt-in
+    sig = inspect.signature(sda.to_device)
+    assert [(p.name, p.default) for p in sig.parameters.values()] == [("matrix", inspect._empty), ("optimize", False)]
+    assert callable(sda.DeviceMatrix.optimize) and callable(sda.mi_probe_copy_gbs)
 
 
 RAISING = G.cases(raises=True)

@@ -157,3 +157,31 @@ def test_hub_path_declines_politely(gpu):
     ref = sps.triu(x.T @ x).tocsr()
     ref.sort_indices()
     assert np.array_equal(g.indices, ref.indices) and rel_err(g.data, ref.data) <= 1e-12
+
+
+def test_hub_path_bsr_operands_and_deterministic_option(gpu):
+    """BSR operands reach the product as their element CSR (the hub path included); option deterministic keeps the range path
+    (it re-forms the values in a fixed order on the ordered pattern) -- same structure either way."""
+    n = 1 << 12
+    a, b = power_law(n, 1024, 13), power_law(n, n, 14)
+    want = reference(a, b)
+    ab, bb = sps.bsr_matrix(a, blocksize=(2, 2)), sps.bsr_matrix(b, blocksize=(2, 2))
+    with hub_forced(gpu) as h:
+        got = gpu.dot_product_mkl(ab, bb)  # comes back re-blocked (the class of A): compared as a dense array
+        assert h.items() > 0
+    assert sps.isspmatrix_bsr(got) and rel_err(got.toarray(), np.maximum(want.toarray(), 0)) <= 1e-12
+    gpu.mi_set_option("deterministic", 1)
+    try:
+        with hub_forced(gpu) as h:
+            r1 = gpu.dot_product_mkl(a, b, reorder_output=True)
+            r2 = gpu.dot_product_mkl(a, b, reorder_output=True)
+            assert h.items() == 0
+    finally:
+        gpu.mi_set_option("deterministic", 0)
+    assert np.array_equal(r1.indices, want.indices) and np.array_equal(r1.data, r2.data) and rel_err(r1.data, want.data) <= 1e-12
+
+
+def test_copy_probe_reports_a_plausible_rate(gpu):
+    """mi_sparse_probe_copy: the 'measured HBM roofline' of bench.py -- between 1 and 8 TB/s on an MI355X."""
+    gbs = gpu.mi_probe_copy_gbs(1 << 28, 1)
+    assert 1000.0 < gbs < 8000.0
