@@ -518,7 +518,10 @@ __global__ void __launch_bounds__(1024)
 // whose span exceeds the bitmap (very sparse rows) or that hold a repeated column take a bitonic sort of (column, position)
 // keys in the same LDS.  Workgroups of 256 threads pull (row, group of SORT_RANGE_GROUP runs) items from a counter.
 constexpr int SORT_RANGE_GROUP = 16;
-constexpr int SORT_RANGE_WORDS = 4096;  // bitmap words: spans of up to 131 072 columns
+#ifndef MI_SORT_RANGE_WORDS
+#define MI_SORT_RANGE_WORDS 4096
+#endif
+constexpr int SORT_RANGE_WORDS = MI_SORT_RANGE_WORDS;  // bitmap words: spans of up to 131 072 columns
 template <typename V, int IPT>
 __global__ void __launch_bounds__(256)
     k_sort_ranges(const int64_t* __restrict__ ptr, int32_t* col, const int64_t* __restrict__ rows, const int64_t* __restrict__ item_off,
@@ -645,15 +648,35 @@ __global__ void __launch_bounds__(256)
                         runsum += cnt;
                     }
                     __syncthreads();
+                    int rk[IPT];
 #pragma unroll
                     for (int u = 0; u < IPT; ++u) {
+                        rk[u] = 0;
                         if (tid + u * 256 < m) {
                             const int o = cc[u] - lo, w = o >> 5, g2 = w / SORT_BITMAP_GROUP;
                             int r = gpre[g2] + __popc(bits[w] & ((1u << (o & 31)) - 1u));
                             for (int ww = g2 * SORT_BITMAP_GROUP; ww < w; ++ww) r += __popc(bits[ww]);
-                            vout[p0 + r] = vv[u];
-                            col[p0 + r] = cc[u];  // (every entry of the run is in registers: nothing of it is read again)
+                            rk[u] = r;
                         }
+                    }
+                    // Every rank is known: the run goes to its place THROUGH LDS (the bitmap's bytes) and out in storage order.
+                    // Written straight from the registers, every lane's 4- and 8-byte store was its own request to the L2 --
+                    // 1.9e10 of them on the literal configs[2] result, at the ~1.5e11 requests / s the L2s take:
+                    // the 105 ms of the whole ordering (round 6).
+                    __syncthreads();
+                    int32_t* s_col = reinterpret_cast<int32_t*>(smem);
+                    V* s_val = reinterpret_cast<V*>(smem + (((size_t)cap * sizeof(int32_t) + 15) & ~(size_t)15));
+#pragma unroll
+                    for (int u = 0; u < IPT; ++u) {
+                        if (tid + u * 256 < m) {
+                            s_col[rk[u]] = cc[u];
+                            s_val[rk[u]] = vv[u];  // (every entry of the run is in registers: nothing of it is read again)
+                        }
+                    }
+                    __syncthreads();
+                    for (int k = tid; k < m; k += 256) {
+                        col[p0 + k] = s_col[k];
+                        vout[p0 + k] = s_val[k];
                     }
                 }
             }
@@ -815,10 +838,30 @@ bool rows_sorted(const Csr& a)
     if (cache_get(a.sorted) || a.nnz < 2) return true;
     Context& c = ctx();
     unsigned long long* cnt = static_cast<unsigned long long*>(c.scratch_alloc(2 * sizeof(unsigned long long)));
-    MI_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), c.stream));
     // few, long-running workgroups: every wave ends with ONE atomic on a shared counter, and the memory side performs those
     // at ~80 M / s (a workgroup per 256 entries made the check of an unsorted 2.7e8-entry result 50 ms instead of 0.1)
     const int64_t max_blocks = (int64_t)16 * std::max(c.cus, 1);
+    // A large matrix that is NOT sorted (a SpGEMM result about to be ordered: hash order in every row) shows it in its first rows:
+    // those are looked at first, and only a clean prefix pays for the pass over everything (7 ms of the 75 ms that ordering the
+    // 9.7e9-entry result of the literal configs[2] takes, round 6).
+    if (a.nnz >= ((int64_t)1 << 26) && a.rows >= 4096) {
+        const int64_t r_pre = a.rows / 256;
+        int64_t n_pre = 0;
+        MI_HIP_CHECK(hipMemcpyAsync(&n_pre, a.ptr + r_pre, sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
+        MI_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), c.stream));
+        MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+        if (n_pre >= 2) {
+            MI_LAUNCH(k_count_descents, dim3((unsigned)std::min<int64_t>(ceil_div(n_pre, (int64_t)256), max_blocks)), dim3(256), c.stream,
+                      (const int32_t*)a.col, n_pre, cnt);
+            MI_LAUNCH(k_count_start_descents, dim3((unsigned)std::min<int64_t>(ceil_div(r_pre, (int64_t)256), max_blocks)), dim3(256),
+                      c.stream, (const int64_t*)a.ptr, (const int32_t*)a.col, r_pre, cnt);
+            unsigned long long hp[2] = {0, 0};
+            MI_HIP_CHECK(hipMemcpyAsync(hp, cnt, sizeof(hp), hipMemcpyDeviceToHost, c.stream));
+            MI_HIP_CHECK(hipStreamSynchronize(c.stream));
+            if (hp[0] != hp[1]) return false;
+        }
+    }
+    MI_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), c.stream));
     MI_LAUNCH(k_count_descents, dim3((unsigned)std::min<int64_t>(ceil_div(a.nnz, (int64_t)256), max_blocks)), dim3(256), c.stream,
               (const int32_t*)a.col, a.nnz, cnt);
     MI_LAUNCH(k_count_start_descents, dim3((unsigned)std::min<int64_t>(ceil_div(std::max<int64_t>(a.rows, 1), (int64_t)256), max_blocks)),
@@ -943,7 +986,8 @@ void sort_csr(char vtype, Csr& a)
             MI_HIP_CHECK(hipMemsetAsync(cnt3, 0, sizeof(unsigned long long), c.stream));
             const int64_t wgs = std::min<int64_t>(n_range_items, (int64_t)8 * std::max(c.cus, 1));
             const size_t lds_count = sizeof(unsigned) * SORT_RANGE_WORDS + sizeof(int) * (SORT_RANGE_WORDS / SORT_BITMAP_GROUP);
-            const size_t lds = std::max(lds_count, sizeof(uint64_t) * (size_t)npad);
+            const size_t lds_stage = (((size_t)a.range_cap * sizeof(int32_t) + 15) & ~(size_t)15) + (size_t)a.range_cap * sizeof(V);  // the sorted run on its way out
+            const size_t lds = std::max(std::max(lds_count, sizeof(uint64_t) * (size_t)npad), lds_stage);
             auto go = [&](auto ipt_tag) {
                 constexpr int IPT = decltype(ipt_tag)::value;
                 MI_LAUNCH_SMEM((k_sort_ranges<V, IPT>), dim3((unsigned)wgs), dim3(256), lds, c.stream, (const int64_t*)a.ptr, a.col,
