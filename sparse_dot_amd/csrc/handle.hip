@@ -319,6 +319,25 @@ __global__ void __launch_bounds__(256)
         }                                                                              \
     }
 
+// the same for at most 2^30 keys with 32-bit index arithmetic (k_sort_small: the 64-bit form spends more instructions on its
+// indices than on the keys -- 2.66 -> see profiles/r06_order_small_rows_ab.log for the 2.7e8-entry uniform configs[2] result)
+#define MI_BITONIC32(keys, n, tid, nthreads, SYNC)                                     \
+    for (int k_ = 2; k_ <= (n); k_ <<= 1) {                                            \
+        for (int j_ = k_ >> 1; j_ > 0; j_ >>= 1) {                                     \
+            for (int t_ = (tid); t_ < (n) / 2; t_ += (nthreads)) {                     \
+                const int lo_ = ((t_ & ~(j_ - 1)) << 1) | (t_ & (j_ - 1));             \
+                const int hi_ = lo_ + j_;                                              \
+                const bool up_ = ((lo_ & k_) == 0);                                    \
+                const auto a_ = (keys)[lo_], b_ = (keys)[hi_];                         \
+                if ((a_ > b_) == up_) {                                                \
+                    (keys)[lo_] = b_;                                                  \
+                    (keys)[hi_] = a_;                                                  \
+                }                                                                      \
+            }                                                                          \
+            SYNC;                                                                      \
+        }                                                                              \
+    }
+
 constexpr int SORT_SMALL_MAX = 512;    // one wave (64-thread block) per row, keys in LDS
 constexpr int SORT_BLOCK_MAX = 8192;   // one 256-thread block per row, keys in LDS
 constexpr int SORT_ROWS_PER_SMALL_BLOCK = 8;
@@ -353,18 +372,18 @@ __global__ void __launch_bounds__(64)
             if (len == 1 && lane == 0) vout[q0] = vin[p0];
             continue;
         }
-        int64_t n = 2;
-        while (n < len) n <<= 1;
-        for (int64_t k = lane; k < n; k += 64)
-            keys[k] = (k < len) ? (K)(((K)(uint32_t)col[p0 + k] << POS_BITS) | (K)k) : (K)~(K)0;
-        __syncthreads();
-        MI_BITONIC(keys, n, lane, 64, __syncthreads())
-        for (int64_t k = lane; k < len; k += 64) {
+        int n = 2;
+        while (n < (int)len) n <<= 1;
+        for (int k = lane; k < n; k += 64)
+            keys[k] = (k < (int)len) ? (K)(((K)(uint32_t)col[p0 + k] << POS_BITS) | (K)k) : (K)~(K)0;
+        wave_lds_sync();
+        MI_BITONIC32(keys, n, lane, 64, wave_lds_sync())
+        for (int k = lane; k < (int)len; k += 64) {
             const K key = keys[k];
             col[p0 + k] = (int32_t)(key >> POS_BITS);
             vout[q0 + k] = vin[p0 + (int64_t)(key & POS_MASK)];
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
