@@ -1085,6 +1085,11 @@ struct KpWord16 {
     uint64_t a, b;
 };
 
+// (the partial rows are read once, from HBM: non-temporal loads -- 59.8 -> 57.2 us on the headline matrix, product - 0.6 %;
+// a non-temporal store of the result on top changes nothing: profiles/r06_kp_combine_nt_ab.log)
+#ifndef MI_KP_COMBINE_NT
+#define MI_KP_COMBINE_NT 1
+#endif
 // C[rowid[i]] += alpha * (partial[0 * n_long + i] + ... + partial[(P - 1) * n_long + i]): one lane group per long row, the P
 // partial rows in flight together, summed in partition order -- the same bits on every call
 template <typename T, int V, int LPN>
@@ -1100,7 +1105,15 @@ __global__ void __launch_bounds__(256)
         vec<T, V> part[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-            if (t < P) part[t] = *reinterpret_cast<const vec<T, V>*>(partial + ((int64_t)t * n_long + i) * N + j);
+            if (t < P) {
+#if MI_KP_COMBINE_NT
+                if constexpr (sizeof(vec<T, V>) == 16) {
+                    const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(partial + ((int64_t)t * n_long + i) * N + j));
+                    __builtin_memcpy(&part[t], &w, 16);
+                } else
+#endif
+                part[t] = *reinterpret_cast<const vec<T, V>*>(partial + ((int64_t)t * n_long + i) * N + j);
+            }
         vec<T, V> out = *reinterpret_cast<const vec<T, V>*>(crow + j);
         T sum[V];
 #pragma unroll
@@ -1113,6 +1126,10 @@ __global__ void __launch_bounds__(256)
             }
 #pragma unroll
         for (int v = 0; v < V; ++v) out.v[v] = vt<T>::fma(alpha, sum[v], out.v[v]);
+#if MI_KP_COMBINE_NT >= 2
+        if constexpr (sizeof(vec<T, V>) == 16) nt_store16(reinterpret_cast<T*>(crow + j), reinterpret_cast<const T*>(&out));
+        else
+#endif
         *reinterpret_cast<vec<T, V>*>(crow + j) = out;
     }
 }
