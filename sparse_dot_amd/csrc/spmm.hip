@@ -1095,7 +1095,7 @@ struct KpWord16 {
 template <typename T, int V, int LPN>
 __global__ void __launch_bounds__(256)
     k_kp_combine(const T* __restrict__ partial, int64_t n_long, int P, const int32_t* __restrict__ rowid, int64_t N,
-                 T* __restrict__ C, int64_t c_rs, T alpha)
+                 T* __restrict__ C, int64_t c_rs, T alpha, int overwrite)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPN;
     const int li = threadIdx.x % LPN;
@@ -1114,7 +1114,10 @@ __global__ void __launch_bounds__(256)
 #endif
                 part[t] = *reinterpret_cast<const vec<T, V>*>(partial + ((int64_t)t * n_long + i) * N + j);
             }
-        vec<T, V> out = *reinterpret_cast<const vec<T, V>*>(crow + j);
+        // beta == 0 (`overwrite`): the row holds the zeros the short-row kernel wrote for it -- not read back, the result is
+        // alpha * sum as the row-owned kernel forms it
+        vec<T, V> out;
+        if (!overwrite) out = *reinterpret_cast<const vec<T, V>*>(crow + j);
         T sum[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) sum[v] = part[0].v[v];
@@ -1125,7 +1128,7 @@ __global__ void __launch_bounds__(256)
                 for (int v = 0; v < V; ++v) sum[v] = vt<T>::add(sum[v], part[t].v[v]);
             }
 #pragma unroll
-        for (int v = 0; v < V; ++v) out.v[v] = vt<T>::fma(alpha, sum[v], out.v[v]);
+        for (int v = 0; v < V; ++v) out.v[v] = overwrite ? vt<T>::mul(alpha, sum[v]) : vt<T>::fma(alpha, sum[v], out.v[v]);
 #if MI_KP_COMBINE_NT >= 2
         if constexpr (sizeof(vec<T, V>) == 16) nt_store16(reinterpret_cast<T*>(crow + j), reinterpret_cast<const T*>(&out));
         else
@@ -1457,10 +1460,12 @@ void spmm_device(mi_sparse_matrix* h, bool transposed, const Csr& m, int conj_a,
         const int64_t lanes = N / V16;
         if (lanes > 16)
             MI_LAUNCH((k_kp_combine<T, V16, 32>), dim3((unsigned)ceil_div(kp.n_long * 32, 256)), dim3(256), c.stream,
-                      (const T*)partial, kp.n_long, kp.P, (const int32_t*)kp.rowid.as<int32_t>(), N, C, ldc, alpha);
+                      (const T*)partial, kp.n_long, kp.P, (const int32_t*)kp.rowid.as<int32_t>(), N, C, ldc, alpha,
+                      (int)(vt<T>::is_zero(beta) ? 1 : 0));
         else
             MI_LAUNCH((k_kp_combine<T, V16, 8>), dim3((unsigned)ceil_div(kp.n_long * 8, 256)), dim3(256), c.stream,
-                      (const T*)partial, kp.n_long, kp.P, (const int32_t*)kp.rowid.as<int32_t>(), N, C, ldc, alpha);
+                      (const T*)partial, kp.n_long, kp.P, (const int32_t*)kp.rowid.as<int32_t>(), N, C, ldc, alpha,
+                      (int)(vt<T>::is_zero(beta) ? 1 : 0));
         std::lock_guard<std::mutex> lk(h->mtx);
         ++p.uses;
         return;
