@@ -416,3 +416,43 @@ def test_spmm_tagged_gather_large_dense_operand(gpu, k_cols, n_dense, want_mode)
         gpu.mi_set_option("pool_trim", 1)
         B = C = C0 = None
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("where", ["nowhere", "first_rows", "late_row_only"])
+def test_order_of_a_large_matrix_looks_at_its_first_rows_first(where):
+    """mi_sparse_order (reference _common.py:683 mkl_sparse_order) on 6.7e7 entries aliased from caller HBM: rows_sorted() decides
+    from the first rows / 256 rows when they already show a descent (round 6: a SpGEMM result about to be ordered), and must
+    still find a single unsorted row far behind that prefix.  Rows in order stay as they are; every value stays with its column."""
+    import torch
+    MI, matrix_descr, sparse_matrix_t, check = _abi()
+    import sparse_dot_amd as sda
+    dev = torch.device("cuda", 0)
+    sda.mi_set_stream(torch.cuda.current_stream().cuda_stream)
+    rows, per = 1 << 20, 64
+    ncols = 1 << 20
+    j = torch.arange(per, device=dev, dtype=torch.int64)
+    r = torch.arange(rows, device=dev, dtype=torch.int64)
+    col = (j[None, :] * 16000 + (r[:, None] * 7) % 16000).to(torch.int32)        # ascending inside every row, < 2^20
+    assert int(col.max()) < ncols
+    bad = []
+    if where == "first_rows":
+        bad = [3, 100, 4000]
+    elif where == "late_row_only":
+        bad = [rows - 5]            # far beyond rows / 256
+    for b in bad:
+        col[b] = torch.flip(col[b], dims=[0])
+    col = col.reshape(-1).contiguous()
+    val = col.to(torch.float64) * 0.5 + 1.0                                          # value = f(column): pairing is checkable
+    ip = (torch.arange(rows + 1, device=dev, dtype=torch.int64) * per).to(torch.int32)
+    assert col.numel() >= 1 << 26
+    h = sparse_matrix_t()
+    check(MI.call("mi_sparse_d_create_csr", ct.byref(h), 0, rows, ncols, ip.data_ptr(), ip.data_ptr() + 4, col.data_ptr(),
+                  val.data_ptr()), "create")
+    try:
+        check(MI.call("mi_sparse_order", h), "order")
+        torch.cuda.synchronize()
+        c2 = col.reshape(rows, per)
+        assert bool((c2[:, 1:] > c2[:, :-1]).all())                                  # the caller's arrays ARE the matrix: sorted in place
+        assert bool(torch.equal(val, col.to(torch.float64) * 0.5 + 1.0))
+    finally:
+        MI.call("mi_sparse_destroy", h)
